@@ -1,0 +1,169 @@
+/*
+ * lram_hip.h -- C ABI of the MI355X-native recurrent action-inference engine.
+ *
+ * The reference (ml-jku/LRAM) has no C interface: its drop-in boundary for the rollout hot path is the
+ * Python `self.encoder(inputs_embeds, past_key_values, use_cache)` operator of the policy
+ * (src/algos/models/decision_xlstm.py:138-169, src/algos/models/decision_mamba.py:109-166) together
+ * with the embed / head code around it (src/algos/models/online_decision_transformer_model.py:392-461).
+ * Each entry point below names the reference interface it stands in for.  Host code (the lram_amd package)
+ * binds this library with ctypes; INTEGRATION.md shows the stub a maintainer adds on the LRAM side.
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; every pointer argument says host or device.
+ *   - every function returns 0 on success, non-zero on error; lram_last_error() gives the text.
+ *   - one engine = one GPU, one stream per call (caller passes a hipStream_t as void*, NULL = default
+ *     stream); no internal threads; calls on one engine must be externally serialised.
+ *   - all floating point data is fp32, row-major, contiguous unless a stride is given.
+ */
+#ifndef LRAM_HIP_H
+#define LRAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRAM_ABI_VERSION 1
+
+#define LRAM_BACKBONE_XLSTM 0
+#define LRAM_BACKBONE_MAMBA 1
+
+#define LRAM_MAX_BLOCKS 64
+
+/* Model description.  Mirrors the fields the reference reads from `agent_params.huggingface`
+ * (configs/agent_params/huggingface/xlstm_*.yaml, mamba_*.yaml -> xLSTMConfig / MambaConfig,
+ * src/algos/models/decision_xlstm.py:104-116, src/algos/models/decision_mamba.py:15-49) and from
+ * `agent_params.model_kwargs` (configs/agent_params/model_kwargs/multi_domain.yaml). */
+typedef struct lram_config {
+  int32_t abi_version;      /* must be LRAM_ABI_VERSION */
+  int32_t backbone;         /* LRAM_BACKBONE_* */
+  int32_t d_model;          /* hidden_size / embedding_dim / d_model */
+  int32_t n_blocks;         /* n_layer / num_blocks */
+  int32_t tokens_per_step;  /* 3: (state, return-to-go, reward), discrete_decision_transformer_model.py:265-275 */
+  int32_t pred_token;       /* 1: action is read at the rtg token, tok_to_pred_pos["a"] */
+  /* xLSTM */
+  int32_t n_heads;          /* mlstm.num_heads == slstm.num_heads (4) */
+  int32_t conv_k;           /* conv1d_kernel_size (4) */
+  int32_t qkv_blocksize;    /* qkv_proj_blocksize (4) */
+  int32_t inner;            /* mLSTM inner dim = ceil64(2 * d_model) */
+  int32_t ffn_dim;          /* sLSTM-block gated FFN dim = ceil64(1.3 * d_model) */
+  int32_t block_is_slstm[LRAM_MAX_BLOCKS]; /* 1 where the block index is in `slstm_at` */
+  int32_t norm_is_rms;      /* 1 when HF config has rms_norm (decision_xlstm.py:190-191) */
+  float   ln_eps;           /* 1e-5 */
+  /* Mamba */
+  int32_t d_inner;          /* expand * d_model */
+  int32_t d_state;          /* 16 */
+  int32_t d_conv;           /* 4 */
+  int32_t dt_rank;          /* ceil(d_model / 16) */
+  float   norm_eps;         /* 1e-5 */
+  /* token front end / head (multi_domain_discrete_dt_model.py:12-81) */
+  int32_t state_dim;        /* 204 (max_state_dim) */
+  int32_t act_dim;          /* 8 (max_act_dim) */
+  int32_t n_vocab;          /* 274 = discrete_actions + action_channels */
+  int32_t n_discrete;       /* 18, also the tokenizer shift */
+  int32_t action_channels;  /* 256 */
+  float   tok_min;          /* -1 */
+  float   tok_max;          /* +1 */
+} lram_config;
+
+typedef struct lram_engine lram_engine; /* opaque */
+
+/* Text of the last error raised on this thread ("" if none). */
+const char* lram_last_error(void);
+
+/* ABI version the library was built with. */
+int32_t lram_abi_version(void);
+
+/* Create an engine on HIP device `device`.  Replaces the construction of the policy's encoder,
+ * xLSTMEncoder.__init__ / MambaEncoder.__init__ (decision_xlstm.py:119-136, decision_mamba.py:52-107). */
+int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out);
+
+/* Destroy the engine and free all device memory it owns. */
+int32_t lram_destroy(lram_engine* e);
+
+/* Upload one weight tensor (host fp32, `numel` elements) under an engine-side name.  Names and shapes
+ * are listed by lram_amd/weights.py::engine_layout (derived from the reference checkpoint keys,
+ * `policy.state_dict()`, src/algos/decision_transformer_sb3.py:1246-1280).  Replaces load_state_dict. */
+int32_t lram_set_weight(lram_engine* e, const char* name, const float* host_data, size_t numel);
+
+/* Check that every weight the configured model needs is present with the right size; resolves the
+ * kernel-side pointer tables.  Must be called once after the last lram_set_weight. */
+int32_t lram_finalize(lram_engine* e);
+
+/* Allocate (or re-allocate) zeroed recurrent state and activation workspace for `batch` env slots.
+ * Replaces `past_key_values = None` / InferenceParams(max_batch_size) (decision_mamba.py:33-38). */
+int32_t lram_state_alloc(lram_engine* e, int32_t batch);
+
+/* Bytes of recurrent state held per env slot (the S_env of SURVEY.md 8d). */
+int64_t lram_state_bytes_per_env(const lram_engine* e);
+
+/* Zero the recurrent state of the env slots whose mask byte is non-zero (device uint8[batch]); NULL
+ * resets every slot.  Replaces `model.past_key_values = None; model.inference_params.reset()`
+ * (src/callbacks/evaluation.py:116-119,247-250). */
+int32_t lram_reset(lram_engine* e, const uint8_t* dev_env_mask, void* stream);
+
+/* One env-step for all `batch` slots: embed (state, rtg, reward) -> embed_ln -> tokens_per_step
+ * recurrent token steps through the block stack -> post norm -> action head -> argmax -> inv_tokenize.
+ * Replaces policy.forward(..., use_inference_cache=True, past_key_values=...) as called from
+ * get_action_pred (src/algos/discrete_decision_transformer_sb3.py:60-68) for every env at once.
+ *   dev_obs        device float[batch, state_dim]  (zero-padded obs, decision_xlstm.py:16-19), or, when
+ *                  obs_is_embedding != 0, device float[batch, d_model] = embed_image(obs/255) computed by
+ *                  the caller (ImpalaCNN stays in PyTorch/MIOpen)
+ *   dev_rtg        device float[batch]             returns-to-go (already divided by reward_scale)
+ *   dev_reward     device float[batch]             reward token (0 in the reference loop)
+ *   dev_reset_mask device uint8[batch] or NULL     slots to reset before this step
+ *   discrete       0: continuous head (argmax over n_vocab per action dim, de-tokenised to fp32)
+ *                  1: discrete head (argmax over the first n_discrete logits of action dim 0)
+ *   dev_actions    device float[batch, act_dim]    out; discrete: column 0 holds the action index
+ *   dev_tokens     device int32[batch, act_dim] or NULL   out; raw argmax token ids */
+int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding, const float* dev_rtg,
+                  const float* dev_reward, const uint8_t* dev_reset_mask, int32_t discrete,
+                  float* dev_actions, int32_t* dev_tokens, void* stream);
+
+/* Encoder-only operator: inputs_embeds[batch, tokens, d_model] -> last_hidden_state of the same shape
+ * (after post_blocks_norm / norm_f), state advanced by `tokens` (1..4).  This is the exact plug point of
+ * `self.encoder(**encoder_inputs)` (online_decision_transformer_model.py:448). */
+int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_t tokens,
+                          const uint8_t* dev_reset_mask, float* dev_hidden_out, void* stream);
+
+/* Debug/parity taps of the last lram_step: copies into caller device buffers when non-NULL.
+ *   dev_tokens_embed float[batch, tokens_per_step, d_model]  embed_ln output
+ *   dev_hidden       float[batch, tokens_per_step, d_model]  encoder output (after the final norm)
+ *   dev_logits       float[batch, act_dim * n_vocab]         action_net output */
+int32_t lram_get_taps(lram_engine* e, float* dev_tokens_embed, float* dev_hidden, float* dev_logits,
+                      void* stream);
+
+/* Recurrent-state tensors in the reference's `past_key_values` layout.  `which`:
+ *   xLSTM mLSTM block: 0 = C [B,NH,DH,DH]  1 = n [B,NH,DH,1]  2 = m [B,NH,1,1]  3 = conv [B,K,inner]
+ *   xLSTM sLSTM block: 0 = slstm_state [4,B,D] (y,c,n,m)      3 = conv [B,K,D]
+ *   Mamba layer      : 0 = ssm_state [B,d_inner,d_state]      3 = conv_state [B,d_inner,d_conv]
+ * lram_state_numel returns the element count (0 if the tensor does not exist for that block). */
+int64_t lram_state_numel(const lram_engine* e, int32_t block, int32_t which);
+int32_t lram_state_export(lram_engine* e, int32_t block, int32_t which, float* dev_dst, void* stream);
+int32_t lram_state_import(lram_engine* e, int32_t block, int32_t which, const float* dev_src, void* stream);
+
+/* Capture the kernel sequence of lram_step for the current batch / pointer set into a hipGraph and
+ * replay it on later identical calls (launch-latency removal for small batches). enable = 0 disables. */
+int32_t lram_set_graph_mode(lram_engine* e, int32_t enable);
+
+/* Per-kernel timing of the recurrent step, measured with HIP events on the stream the kernels are
+ * launched on.  lram_profile_begin arms it; every later lram_step records one (start, stop) event pair
+ * around the mLSTM cell-update launches (xLSTM) or the selective-state-update launches (Mamba).
+ * lram_profile_end synchronises and returns total milliseconds and number of launches timed. */
+int32_t lram_profile_begin(lram_engine* e);
+int32_t lram_profile_end(lram_engine* e, double* total_ms, int64_t* n_launches);
+
+/* Standalone kernel entry points used by tests and micro-benchmarks. */
+/* C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) (+ residual C_in)   fp32, MFMA 32x32x2 f32 */
+int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
+                      int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
+                      int32_t k, void* stream);
+/* STREAM-like device copy (float4), used by bench.py to measure the achievable HBM rate on the box. */
+int32_t lram_stream_copy(float* dev_dst, const float* dev_src, size_t numel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRAM_HIP_H */

@@ -1,0 +1,183 @@
+// Shared declarations of the engine's HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace lram {
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+#define LRAM_HIP_CHECK(expr)                                                                         \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      throw ::lram::Error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                          ":" + std::to_string(__LINE__) + ")");                                     \
+  } while (0)
+
+#define LRAM_REQUIRE(cond, msg)                                   \
+  do {                                                            \
+    if (!(cond)) throw ::lram::Error(std::string("lram: ") + msg); \
+  } while (0)
+
+constexpr int kMaxTokens = 4;  // tokens per env-step handled by the fused recurrent kernels
+
+// ---------------------------------------------------------------------------------------------
+// GEMM  C[M,N] = A[M,K] * W[N,K]^T  (fp32 in, fp32 MFMA accumulate), optional bias / residual.
+// Two-level batching: z = z1 * nb2 + z2 ; pointer = base + z1 * s?1 + z2 * s?2.
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const float* a = nullptr;
+  const float* w = nullptr;
+  float* c = nullptr;
+  const float* bias = nullptr;  // [N] (per batch: bias + z1*sBias1 + z2*sBias2)
+  const float* residual = nullptr;  // same layout as c (may alias c)
+  int64_t lda = 0, ldw = 0, ldc = 0;
+  int m = 0, n = 0, k = 0;
+  int nb1 = 1, nb2 = 1;
+  int64_t sA1 = 0, sA2 = 0, sW1 = 0, sW2 = 0, sC1 = 0, sC2 = 0, sBias1 = 0, sBias2 = 0;
+};
+void launch_gemm_f32(const GemmArgs& g, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// normalisation / elementwise
+// ---------------------------------------------------------------------------------------------
+// out[r, :] = norm(in[r, :]) * gamma (+ beta);  rms != 0 -> RMSNorm (no mean subtraction).
+void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
+                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream);
+// Mamba block entry: res_out = hidden (+ res_in);  normed = RMSNorm(res_out) * gamma.
+void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
+                         const float* gamma, int rows, int d, float eps, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// front end / head
+// ---------------------------------------------------------------------------------------------
+// x[b,1,:] = rtg[b]*w_rtg + b_rtg ; x[b,2,:] = rew[b]*w_rew + b_rew   (x: [B,T,D], tokens 1 and 2)
+void launch_embed_scalars(float* x, const float* rtg, const float* rew, const float* w_rtg, const float* b_rtg,
+                          const float* w_rew, const float* b_rew, int B, int T, int D, hipStream_t stream);
+// copy caller-provided state embeddings [B,D] into token slot 0 of x [B,T,D]
+void launch_scatter_token0(float* x, const float* emb, int B, int T, int D, hipStream_t stream);
+// argmax over logits [B, act_dim*n_vocab] (+ de-tokenise)
+void launch_action_argmax(const float* logits, float* actions, int32_t* tokens, int B, int act_dim, int n_vocab,
+                          int n_discrete, int action_channels, float tok_min, float tok_max, int discrete,
+                          hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// xLSTM
+// ---------------------------------------------------------------------------------------------
+struct MlstmPreArgs {
+  const float* u;        // [B*T, 2*inner]  proj_up output: x_mlstm | z
+  float* conv_state;     // [B, K, inner]   in/out
+  float* n_state;        // [B, NH, DH]     in/out
+  float* m_state;        // [B, NH]         in/out
+  const float* conv_w;   // [inner, K]      (nn.Conv1d weight [inner,1,K])
+  const float* conv_b;   // [inner]
+  const float* wq;       // [inner/4, 4, 4]
+  const float* wk;
+  const float* wv;
+  const float* wi;       // [NH, 3*inner]
+  const float* bi;       // [NH]
+  const float* wf;
+  const float* bf;
+  float* q;              // [B*T, inner] out
+  float* k;
+  float* v;
+  float* xa;             // [B*T, inner] out  silu(conv)
+  float* scal;           // [B*T, NH, 4] out  (f_t, i_t, denom_t, m_t)
+  const uint8_t* reset;  // [B] or null
+  int B, T, inner, NH, K;
+};
+void launch_mlstm_pre(const MlstmPreArgs& a, hipStream_t stream);
+
+struct MlstmCellArgs {
+  float* C;            // [B, NH, DH, DH] in/out
+  const float* q;      // [B*T, inner]
+  const float* k;
+  const float* v;
+  const float* scal;   // [B*T, NH, 4]
+  float* h;            // [B*T, inner] out: (q^T C_t) / denom_t
+  const uint8_t* reset;
+  int B, T, NH, DH;
+};
+void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream);
+
+// mode 0 (mLSTM): out[r, hd] = (GN(h)[r,hd] * gamma + skip*xa) * silu(z)      z = u[r, inner + hd]
+// mode 1 (sLSTM): x[r, hd] += GN(h)[r,hd] * gamma
+struct GroupNormArgs {
+  const float* h;      // [rows, NH*DH]
+  const float* gamma;  // [NH*DH]  (already 1 + w)
+  const float* beta;   // optional
+  const float* skip;   // mode 0
+  const float* xa;     // mode 0 [rows, NH*DH]
+  const float* u;      // mode 0 [rows, 2*NH*DH]
+  float* out;          // mode 0: g [rows, NH*DH]; mode 1: x [rows, NH*DH] (+=)
+  int rows, NH, DH, mode;
+  float eps;
+};
+void launch_group_norm(const GroupNormArgs& a, hipStream_t stream);
+
+struct SlstmConvArgs {
+  const float* xn;      // [B*T, D]
+  float* conv_state;    // [B, K, D]
+  float* slstm_state;   // [4, B, D]  (zeroed for reset envs)
+  const float* conv_w;  // [D, K]
+  const float* conv_b;
+  float* xc;            // [B*T, D] out silu(conv)
+  const uint8_t* reset;
+  int B, T, D, K;
+};
+void launch_slstm_conv(const SlstmConvArgs& a, hipStream_t stream);
+
+struct SlstmPointwiseArgs {
+  const float* gates;  // [B*T, 4, H] gate-major (i,f,z,o) input pre-activations (Wx)
+  const float* ry;     // [B, 4, H]   recurrent contribution for this token
+  const float* bias;   // [4, H]
+  float* state;        // [4, B, H] in/out
+  float* yout;         // [B*T, H]  y written at row b*T + t
+  int B, T, t, H;
+};
+void launch_slstm_pointwise(const SlstmPointwiseArgs& a, hipStream_t stream);
+
+// a[r, f] = gelu(p[r, f]) * p[r, F + f]      p: [rows, 2F]
+void launch_gelu_gate(const float* p, float* a, int rows, int F, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Mamba
+// ---------------------------------------------------------------------------------------------
+struct MambaConvArgs {
+  const float* xz;      // [B*T, 2*d_inner]  in_proj output: x | z
+  float* conv_state;    // [B, d_inner, K]
+  const float* conv_w;  // [d_inner, K]
+  const float* conv_b;
+  float* xc;            // [B*T, d_inner] out silu(conv)
+  const uint8_t* reset;
+  int B, T, d_inner, K;
+};
+void launch_mamba_conv(const MambaConvArgs& a, hipStream_t stream);
+
+struct MambaSsmArgs {
+  float* ssm_state;     // [B, d_inner, N]
+  const float* xc;      // [B*T, d_inner]
+  const float* dtp;     // [B*T, d_inner]  dt_proj(dt) (no bias)
+  const float* dt_bias; // [d_inner]
+  const float* xdb;     // [B*T, R + 2N]   x_proj output (dt | B | C)
+  const float* A_log;   // [d_inner, N]
+  const float* Dp;      // [d_inner]
+  const float* xz;      // [B*T, 2*d_inner] (z at + d_inner)
+  float* y;             // [B*T, d_inner] out
+  const uint8_t* reset;
+  int B, T, d_inner, N, R;
+};
+void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream);
+
+// misc
+void launch_stream_copy(float* dst, const float* src, size_t numel, hipStream_t stream);
+void launch_zero_rows(float* buf, const uint8_t* mask, int B, int64_t row_elems, int64_t outer, int64_t outer_stride,
+                      hipStream_t stream);
+
+}  // namespace lram

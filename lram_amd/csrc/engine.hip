@@ -1,0 +1,746 @@
+// Engine: owns weights, per-env recurrent state and activation workspace on one MI355X, and issues the
+// kernel sequence of one env-step (layer-major: every block consumes all T tokens of the timestep before
+// the next block runs, so each block's recurrent state is read and written once per env-step).
+// C ABI in include/lram_hip.h.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/lram_hip.h"
+#include "common.h"
+
+using namespace lram;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+  float* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t numel) {
+    release();
+    if (numel == 0) return;
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), numel * sizeof(float)));
+    n = numel;
+  }
+  void zero(hipStream_t s = nullptr) {
+    if (p) LRAM_HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(float), s));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+struct BlockWeights {  // resolved device pointers (nullptr when absent / optional)
+  // common
+  const float *norm_g = nullptr, *norm_b = nullptr;
+  // mLSTM
+  const float *proj_up = nullptr, *conv_w = nullptr, *conv_b = nullptr, *wq = nullptr, *wk = nullptr, *wv = nullptr,
+              *wi = nullptr, *bi = nullptr, *wf = nullptr, *bf = nullptr, *on_g = nullptr, *on_b = nullptr,
+              *skip = nullptr, *proj_down = nullptr;
+  // sLSTM
+  const float *gate_w[4] = {nullptr, nullptr, nullptr, nullptr};  // i, f, z, o slots of the cell
+  const float *rt = nullptr, *rbias = nullptr, *gn_g = nullptr, *gn_b = nullptr, *ffn_norm_g = nullptr,
+              *ffn_norm_b = nullptr, *ffn_up = nullptr, *ffn_down = nullptr;
+  // Mamba
+  const float *in_proj = nullptr, *in_proj_b = nullptr, *x_proj = nullptr, *dt_proj = nullptr, *dt_bias = nullptr,
+              *A_log = nullptr, *Dp = nullptr, *out_proj = nullptr, *out_proj_b = nullptr;
+};
+
+struct BlockState {
+  DevBuf s0;    // mLSTM C | sLSTM state [4,B,D] | Mamba ssm
+  DevBuf n;     // mLSTM n
+  DevBuf m;     // mLSTM m
+  DevBuf conv;  // conv state
+};
+
+struct GraphKey {
+  const void *obs, *rtg, *rew, *mask, *act, *tok;
+  int emb, discrete, B;
+  hipStream_t stream;
+  bool operator==(const GraphKey& o) const {
+    return obs == o.obs && rtg == o.rtg && rew == o.rew && mask == o.mask && act == o.act && tok == o.tok &&
+           emb == o.emb && discrete == o.discrete && B == o.B && stream == o.stream;
+  }
+};
+
+}  // namespace
+
+struct lram_engine {
+  lram_config cfg{};
+  int device = 0;
+  std::map<std::string, DevBuf> weights;
+  bool finalized = false;
+  std::vector<BlockWeights> bw;
+  // front end / head
+  const float *w_state = nullptr, *b_state = nullptr, *w_rtg = nullptr, *b_rtg = nullptr, *w_rew = nullptr,
+              *b_rew = nullptr, *eln_g = nullptr, *eln_b = nullptr, *w_head = nullptr, *b_head = nullptr,
+              *post_g = nullptr, *post_b = nullptr;
+  // state + workspace
+  int B = 0;
+  std::vector<BlockState> st;
+  DevBuf X, XN, TOK, HID, U, Q, K, V, XA, H, G, SCAL, RY, LOGITS, RES, DTP;
+  // graph replay
+  bool graph_mode = false;
+  bool graph_valid = false;
+  GraphKey graph_key{};
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  // profiling of the dominant recurrent kernel
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+
+  ~lram_engine() {
+    drop_graph();
+    for (auto& e : prof_events) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+    for (auto& kv : weights) kv.second.release();
+    release_state();
+  }
+  void drop_graph() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    graph_exec = nullptr;
+    graph = nullptr;
+    graph_valid = false;
+  }
+  void release_state() {
+    for (auto& s : st) {
+      s.s0.release();
+      s.n.release();
+      s.m.release();
+      s.conv.release();
+    }
+    st.clear();
+    for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP}) b->release();
+    B = 0;
+  }
+  int dh() const { return cfg.inner / cfg.n_heads; }
+  int sdh() const { return cfg.d_model / cfg.n_heads; }
+};
+
+namespace {
+
+const float* need(lram_engine* e, const std::string& name, size_t numel) {
+  auto it = e->weights.find(name);
+  if (it == e->weights.end()) throw Error("lram: missing weight '" + name + "'");
+  if (it->second.n != numel)
+    throw Error("lram: weight '" + name + "' has " + std::to_string(it->second.n) + " elements, expected " +
+                std::to_string(numel));
+  return it->second.p;
+}
+const float* optional(lram_engine* e, const std::string& name, size_t numel) {
+  auto it = e->weights.find(name);
+  if (it == e->weights.end()) return nullptr;
+  if (it->second.n != numel)
+    throw Error("lram: weight '" + name + "' has " + std::to_string(it->second.n) + " elements, expected " +
+                std::to_string(numel));
+  return it->second.p;
+}
+
+void validate_config(const lram_config& c) {
+  LRAM_REQUIRE(c.abi_version == LRAM_ABI_VERSION, "config.abi_version does not match the library");
+  LRAM_REQUIRE(c.backbone == LRAM_BACKBONE_XLSTM || c.backbone == LRAM_BACKBONE_MAMBA, "unknown backbone");
+  LRAM_REQUIRE(c.d_model > 0 && c.d_model % 4 == 0 && c.d_model <= 2048, "d_model must be a multiple of 4, <= 2048");
+  LRAM_REQUIRE(c.n_blocks > 0 && c.n_blocks <= LRAM_MAX_BLOCKS, "n_blocks out of range");
+  LRAM_REQUIRE(c.tokens_per_step >= 1 && c.tokens_per_step <= kMaxTokens, "tokens_per_step must be in 1..4");
+  LRAM_REQUIRE(c.pred_token >= 0 && c.pred_token < c.tokens_per_step, "pred_token out of range");
+  LRAM_REQUIRE(c.state_dim > 0 && c.state_dim % 4 == 0, "state_dim must be a positive multiple of 4");
+  LRAM_REQUIRE(c.act_dim > 0 && c.n_vocab > 0 && c.n_discrete >= 0 && c.n_discrete <= c.n_vocab &&
+                   c.action_channels > 0,
+               "bad action head dimensions");
+  if (c.backbone == LRAM_BACKBONE_XLSTM) {
+    LRAM_REQUIRE(c.n_heads > 0 && c.inner > 0 && c.inner % (c.n_heads * 64) == 0,
+                 "xLSTM inner dim must be a multiple of 64 * n_heads");
+    LRAM_REQUIRE(c.d_model % (4 * c.n_heads) == 0, "d_model must be a multiple of 4 * n_heads");
+    LRAM_REQUIRE(c.conv_k == 4, "conv1d_kernel_size must be 4");
+    LRAM_REQUIRE(c.qkv_blocksize == 4, "qkv_proj_blocksize must be 4");
+    bool any_s = false;
+    for (int i = 0; i < c.n_blocks; ++i) any_s |= c.block_is_slstm[i] != 0;
+    if (any_s) LRAM_REQUIRE(c.ffn_dim > 0 && c.ffn_dim % 4 == 0, "ffn_dim must be a positive multiple of 4");
+  } else {
+    LRAM_REQUIRE(c.d_inner > 0 && c.d_inner % 4 == 0 && c.d_conv == 4 && c.d_state > 0 && c.dt_rank > 0,
+                 "bad Mamba dimensions");
+  }
+}
+
+void finalize(lram_engine* e) {
+  const lram_config& c = e->cfg;
+  const size_t D = c.d_model;
+  e->w_state = need(e, "embed_state.weight", D * c.state_dim);
+  e->b_state = need(e, "embed_state.bias", D);
+  e->w_rtg = need(e, "embed_return.weight", D);
+  e->b_rtg = need(e, "embed_return.bias", D);
+  e->w_rew = need(e, "embed_rewards.weight", D);
+  e->b_rew = need(e, "embed_rewards.bias", D);
+  e->eln_g = need(e, "embed_ln.weight", D);
+  e->eln_b = optional(e, "embed_ln.bias", D);
+  e->w_head = need(e, "action_net.weight", (size_t)c.act_dim * c.n_vocab * D);
+  e->b_head = need(e, "action_net.bias", (size_t)c.act_dim * c.n_vocab);
+  e->post_g = need(e, "post_norm.gamma", D);
+  e->post_b = optional(e, "post_norm.beta", D);
+  e->bw.assign(c.n_blocks, BlockWeights());
+  for (int i = 0; i < c.n_blocks; ++i) {
+    BlockWeights& w = e->bw[i];
+    const std::string p = "b" + std::to_string(i) + ".";
+    w.norm_g = need(e, p + "norm.gamma", D);
+    w.norm_b = optional(e, p + "norm.beta", D);
+    if (c.backbone == LRAM_BACKBONE_MAMBA) {
+      const size_t di = c.d_inner, N = c.d_state, R = c.dt_rank;
+      w.in_proj = need(e, p + "in_proj", 2 * di * D);
+      w.in_proj_b = optional(e, p + "in_proj_b", 2 * di);
+      w.conv_w = need(e, p + "conv_w", di * 4);
+      w.conv_b = optional(e, p + "conv_b", di);
+      w.x_proj = need(e, p + "x_proj", (R + 2 * N) * di);
+      w.dt_proj = need(e, p + "dt_proj", di * R);
+      w.dt_bias = need(e, p + "dt_bias", di);
+      w.A_log = need(e, p + "A_log", di * N);
+      w.Dp = need(e, p + "D", di);
+      w.out_proj = need(e, p + "out_proj", D * di);
+      w.out_proj_b = optional(e, p + "out_proj_b", D);
+    } else if (c.block_is_slstm[i]) {
+      const size_t NH = c.n_heads, DH = D / NH, F = c.ffn_dim;
+      w.conv_w = need(e, p + "conv_w", D * 4);
+      w.conv_b = need(e, p + "conv_b", D);
+      w.gate_w[0] = need(e, p + "gate_i", NH * DH * DH);
+      w.gate_w[1] = need(e, p + "gate_f", NH * DH * DH);
+      w.gate_w[2] = need(e, p + "gate_z", NH * DH * DH);
+      w.gate_w[3] = need(e, p + "gate_o", NH * DH * DH);
+      w.rt = need(e, p + "rt", NH * 4 * DH * DH);
+      w.rbias = need(e, p + "rbias", 4 * D);
+      w.gn_g = need(e, p + "gn.gamma", D);
+      w.gn_b = optional(e, p + "gn.beta", D);
+      w.ffn_norm_g = need(e, p + "ffn_norm.gamma", D);
+      w.ffn_norm_b = optional(e, p + "ffn_norm.beta", D);
+      w.ffn_up = need(e, p + "ffn_up", 2 * F * D);
+      w.ffn_down = need(e, p + "ffn_down", D * F);
+    } else {
+      const size_t inner = c.inner, NH = c.n_heads;
+      w.proj_up = need(e, p + "proj_up", 2 * inner * D);
+      w.conv_w = need(e, p + "conv_w", inner * 4);
+      w.conv_b = need(e, p + "conv_b", inner);
+      w.wq = need(e, p + "wq", inner * 4);
+      w.wk = need(e, p + "wk", inner * 4);
+      w.wv = need(e, p + "wv", inner * 4);
+      w.wi = need(e, p + "wi", NH * 3 * inner);
+      w.bi = need(e, p + "bi", NH);
+      w.wf = need(e, p + "wf", NH * 3 * inner);
+      w.bf = need(e, p + "bf", NH);
+      w.on_g = need(e, p + "outnorm.gamma", inner);
+      w.on_b = optional(e, p + "outnorm.beta", inner);
+      w.skip = need(e, p + "skip", inner);
+      w.proj_down = need(e, p + "proj_down", D * inner);
+    }
+  }
+  e->finalized = true;
+}
+
+void state_alloc(lram_engine* e, int B) {
+  LRAM_REQUIRE(e->finalized, "lram_finalize must be called before lram_state_alloc");
+  LRAM_REQUIRE(B > 0 && B <= 65535, "batch must be in 1..65535");
+  LRAM_HIP_CHECK(hipSetDevice(e->device));
+  e->drop_graph();
+  e->release_state();
+  const lram_config& c = e->cfg;
+  const size_t D = c.d_model, BT = (size_t)B * kMaxTokens;
+  e->st.resize(c.n_blocks);
+  for (int i = 0; i < c.n_blocks; ++i) {
+    BlockState& s = e->st[i];
+    if (c.backbone == LRAM_BACKBONE_MAMBA) {
+      s.s0.alloc((size_t)B * c.d_inner * c.d_state);
+      s.conv.alloc((size_t)B * c.d_inner * c.d_conv);
+    } else if (c.block_is_slstm[i]) {
+      s.s0.alloc(4 * (size_t)B * D);
+      s.conv.alloc((size_t)B * c.conv_k * D);
+    } else {
+      const size_t DH = e->dh();
+      s.s0.alloc((size_t)B * c.n_heads * DH * DH);
+      s.n.alloc((size_t)B * c.inner);
+      s.m.alloc((size_t)B * c.n_heads);
+      s.conv.alloc((size_t)B * c.conv_k * c.inner);
+    }
+    s.s0.zero();
+    s.n.zero();
+    s.m.zero();
+    s.conv.zero();
+  }
+  e->X.alloc(BT * D);
+  e->XN.alloc(BT * D);
+  e->TOK.alloc(BT * D);
+  e->HID.alloc(BT * D);
+  e->LOGITS.alloc((size_t)B * c.act_dim * c.n_vocab);
+  if (c.backbone == LRAM_BACKBONE_MAMBA) {
+    const size_t di = c.d_inner;
+    e->RES.alloc(BT * D);
+    e->U.alloc(BT * 2 * di);                        // xz
+    e->XA.alloc(BT * di);                           // xc
+    e->Q.alloc(BT * (c.dt_rank + 2 * c.d_state));   // x_proj output
+    e->DTP.alloc(BT * di);
+    e->H.alloc(BT * di);                            // y
+  } else {
+    const size_t inner = c.inner;
+    const size_t ucols = std::max<size_t>(std::max<size_t>(2 * inner, 4 * D), 2 * (size_t)c.ffn_dim);
+    const size_t icols = std::max<size_t>(std::max<size_t>(inner, D), (size_t)c.ffn_dim);
+    e->U.alloc(BT * ucols);
+    e->Q.alloc(BT * icols);
+    e->K.alloc(BT * icols);
+    e->V.alloc(BT * icols);
+    e->XA.alloc(BT * icols);
+    e->H.alloc(BT * icols);
+    e->G.alloc(BT * icols);
+    e->SCAL.alloc(BT * c.n_heads * 4);
+    e->RY.alloc((size_t)B * 4 * D);
+  }
+  LRAM_HIP_CHECK(hipDeviceSynchronize());
+  e->B = B;
+}
+
+// ---------------------------------------------------------------------------------------------
+// block stack on X [B*T, D] (in place residual stream) -> HID [B*T, D]
+// ---------------------------------------------------------------------------------------------
+void prof_record(lram_engine* e, hipStream_t s, bool start) {
+  if (!e->prof_on) return;
+  if (start) {
+    if (e->prof_used == e->prof_events.size()) {
+      hipEvent_t a, b;
+      LRAM_HIP_CHECK(hipEventCreate(&a));
+      LRAM_HIP_CHECK(hipEventCreate(&b));
+      e->prof_events.emplace_back(a, b);
+    }
+    LRAM_HIP_CHECK(hipEventRecord(e->prof_events[e->prof_used].first, s));
+  } else {
+    LRAM_HIP_CHECK(hipEventRecord(e->prof_events[e->prof_used].second, s));
+    ++e->prof_used;
+  }
+}
+
+void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s) {
+  const lram_config& c = e->cfg;
+  const int B = e->B, D = c.d_model, BT = B * T, NH = c.n_heads;
+  const int inner = c.inner, DH = e->dh(), SDH = e->sdh(), F = c.ffn_dim;
+  float* X = e->X.p;
+  for (int i = 0; i < c.n_blocks; ++i) {
+    const BlockWeights& w = e->bw[i];
+    BlockState& st = e->st[i];
+    launch_row_norm(X, D, e->XN.p, D, w.norm_g, w.norm_b, BT, D, c.ln_eps, c.norm_is_rms, s);
+    if (!c.block_is_slstm[i]) {
+      GemmArgs up;
+      up.a = e->XN.p, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p, up.ldc = 2 * inner;
+      up.m = BT, up.n = 2 * inner, up.k = D;
+      launch_gemm_f32(up, s);
+      MlstmPreArgs pa;
+      pa.u = e->U.p, pa.conv_state = st.conv.p, pa.n_state = st.n.p, pa.m_state = st.m.p;
+      pa.conv_w = w.conv_w, pa.conv_b = w.conv_b, pa.wq = w.wq, pa.wk = w.wk, pa.wv = w.wv;
+      pa.wi = w.wi, pa.bi = w.bi, pa.wf = w.wf, pa.bf = w.bf;
+      pa.q = e->Q.p, pa.k = e->K.p, pa.v = e->V.p, pa.xa = e->XA.p, pa.scal = e->SCAL.p, pa.reset = reset;
+      pa.B = B, pa.T = T, pa.inner = inner, pa.NH = NH, pa.K = c.conv_k;
+      launch_mlstm_pre(pa, s);
+      MlstmCellArgs ca;
+      ca.C = st.s0.p, ca.q = e->Q.p, ca.k = e->K.p, ca.v = e->V.p, ca.scal = e->SCAL.p, ca.h = e->H.p;
+      ca.reset = reset, ca.B = B, ca.T = T, ca.NH = NH, ca.DH = DH;
+      prof_record(e, s, true);
+      launch_mlstm_cell(ca, s);
+      prof_record(e, s, false);
+      GroupNormArgs ga;
+      ga.h = e->H.p, ga.gamma = w.on_g, ga.beta = w.on_b, ga.skip = w.skip, ga.xa = e->XA.p, ga.u = e->U.p;
+      ga.out = e->G.p, ga.rows = BT, ga.NH = NH, ga.DH = DH, ga.mode = 0, ga.eps = c.ln_eps;
+      launch_group_norm(ga, s);
+      GemmArgs dn;
+      dn.a = e->G.p, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
+      dn.m = BT, dn.n = D, dn.k = inner;
+      launch_gemm_f32(dn, s);
+    } else {
+      const int Hs = D;
+      SlstmConvArgs sa;
+      sa.xn = e->XN.p, sa.conv_state = st.conv.p, sa.slstm_state = st.s0.p, sa.conv_w = w.conv_w,
+      sa.conv_b = w.conv_b, sa.xc = e->Q.p, sa.reset = reset, sa.B = B, sa.T = T, sa.D = D, sa.K = c.conv_k;
+      launch_slstm_conv(sa, s);
+      float* gates = e->U.p;  // [BT, 4, H]
+      for (int g = 0; g < 4; ++g) {
+        GemmArgs ga;
+        ga.a = (g < 2) ? e->Q.p : e->XN.p, ga.lda = D, ga.sA1 = SDH;
+        ga.w = w.gate_w[g], ga.ldw = SDH, ga.sW1 = (int64_t)SDH * SDH;
+        ga.c = gates + (int64_t)g * Hs, ga.ldc = 4 * Hs, ga.sC1 = SDH;
+        ga.m = BT, ga.n = SDH, ga.k = SDH, ga.nb1 = NH;
+        launch_gemm_f32(ga, s);
+      }
+      for (int t = 0; t < T; ++t) {
+        GemmArgs ra;
+        ra.a = st.s0.p, ra.lda = Hs, ra.sA1 = SDH, ra.sA2 = 0;
+        ra.w = w.rt, ra.ldw = SDH, ra.sW1 = 4 * (int64_t)SDH * SDH, ra.sW2 = (int64_t)SDH * SDH;
+        ra.c = e->RY.p, ra.ldc = 4 * Hs, ra.sC1 = SDH, ra.sC2 = Hs;
+        ra.m = B, ra.n = SDH, ra.k = SDH, ra.nb1 = NH, ra.nb2 = 4;
+        launch_gemm_f32(ra, s);
+        SlstmPointwiseArgs pw;
+        pw.gates = gates, pw.ry = e->RY.p, pw.bias = w.rbias, pw.state = st.s0.p, pw.yout = e->H.p;
+        pw.B = B, pw.T = T, pw.t = t, pw.H = Hs;
+        launch_slstm_pointwise(pw, s);
+      }
+      GroupNormArgs gn;
+      gn.h = e->H.p, gn.gamma = w.gn_g, gn.beta = w.gn_b, gn.out = X, gn.rows = BT, gn.NH = NH, gn.DH = SDH;
+      gn.mode = 1, gn.eps = c.ln_eps, gn.skip = nullptr, gn.xa = nullptr, gn.u = nullptr;
+      launch_group_norm(gn, s);
+      launch_row_norm(X, D, e->XN.p, D, w.ffn_norm_g, w.ffn_norm_b, BT, D, c.ln_eps, c.norm_is_rms, s);
+      GemmArgs up;
+      up.a = e->XN.p, up.lda = D, up.w = w.ffn_up, up.ldw = D, up.c = e->U.p, up.ldc = 2 * F;
+      up.m = BT, up.n = 2 * F, up.k = D;
+      launch_gemm_f32(up, s);
+      launch_gelu_gate(e->U.p, e->G.p, BT, F, s);
+      GemmArgs dn;
+      dn.a = e->G.p, dn.lda = F, dn.w = w.ffn_down, dn.ldw = F, dn.c = X, dn.ldc = D, dn.residual = X;
+      dn.m = BT, dn.n = D, dn.k = F;
+      launch_gemm_f32(dn, s);
+    }
+  }
+  launch_row_norm(X, D, e->HID.p, D, e->post_g, e->post_b, BT, D, c.ln_eps, c.norm_is_rms, s);
+}
+
+void run_mamba_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s) {
+  const lram_config& c = e->cfg;
+  const int B = e->B, D = c.d_model, BT = B * T, di = c.d_inner, N = c.d_state, R = c.dt_rank;
+  float* X = e->X.p;
+  for (int i = 0; i < c.n_blocks; ++i) {
+    const BlockWeights& w = e->bw[i];
+    BlockState& st = e->st[i];
+    launch_add_rms_norm(X, i == 0 ? nullptr : e->RES.p, e->RES.p, e->XN.p, w.norm_g, BT, D, c.norm_eps, s);
+    GemmArgs in;
+    in.a = e->XN.p, in.lda = D, in.w = w.in_proj, in.ldw = D, in.c = e->U.p, in.ldc = 2 * di, in.bias = w.in_proj_b;
+    in.m = BT, in.n = 2 * di, in.k = D;
+    launch_gemm_f32(in, s);
+    MambaConvArgs ca;
+    ca.xz = e->U.p, ca.conv_state = st.conv.p, ca.conv_w = w.conv_w, ca.conv_b = w.conv_b, ca.xc = e->XA.p;
+    ca.reset = reset, ca.B = B, ca.T = T, ca.d_inner = di, ca.K = c.d_conv;
+    launch_mamba_conv(ca, s);
+    GemmArgs xp;
+    xp.a = e->XA.p, xp.lda = di, xp.w = w.x_proj, xp.ldw = di, xp.c = e->Q.p, xp.ldc = R + 2 * N;
+    xp.m = BT, xp.n = R + 2 * N, xp.k = di;
+    launch_gemm_f32(xp, s);
+    GemmArgs dp;
+    dp.a = e->Q.p, dp.lda = R + 2 * N, dp.w = w.dt_proj, dp.ldw = R, dp.c = e->DTP.p, dp.ldc = di;
+    dp.m = BT, dp.n = di, dp.k = R;
+    launch_gemm_f32(dp, s);
+    MambaSsmArgs sa;
+    sa.ssm_state = st.s0.p, sa.xc = e->XA.p, sa.dtp = e->DTP.p, sa.dt_bias = w.dt_bias, sa.xdb = e->Q.p;
+    sa.A_log = w.A_log, sa.Dp = w.Dp, sa.xz = e->U.p, sa.y = e->H.p, sa.reset = reset;
+    sa.B = B, sa.T = T, sa.d_inner = di, sa.N = N, sa.R = R;
+    prof_record(e, s, true);
+    launch_mamba_ssm(sa, s);
+    prof_record(e, s, false);
+    GemmArgs op;
+    op.a = e->H.p, op.lda = di, op.w = w.out_proj, op.ldw = di, op.c = X, op.ldc = D, op.bias = w.out_proj_b;
+    op.m = BT, op.n = D, op.k = di;
+    launch_gemm_f32(op, s);
+  }
+  launch_add_rms_norm(X, e->RES.p, nullptr, e->HID.p, e->post_g, BT, D, c.norm_eps, s);
+}
+
+void run_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s) {
+  if (e->cfg.backbone == LRAM_BACKBONE_MAMBA)
+    run_mamba_stack(e, T, reset, s);
+  else
+    run_xlstm_stack(e, T, reset, s);
+}
+
+void step_launches(lram_engine* e, const float* obs, int emb, const float* rtg, const float* rew,
+                   const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s) {
+  const lram_config& c = e->cfg;
+  const int B = e->B, D = c.d_model, T = c.tokens_per_step;
+  if (emb) {
+    launch_scatter_token0(e->X.p, obs, B, T, D, s);
+  } else {
+    GemmArgs ge;
+    ge.a = obs, ge.lda = c.state_dim, ge.w = e->w_state, ge.ldw = c.state_dim, ge.c = e->X.p, ge.ldc = (int64_t)T * D;
+    ge.bias = e->b_state, ge.m = B, ge.n = D, ge.k = c.state_dim;
+    launch_gemm_f32(ge, s);
+  }
+  launch_embed_scalars(e->X.p, rtg, rew, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew, B, T, D, s);
+  launch_row_norm(e->X.p, D, e->X.p, D, e->eln_g, e->eln_b, B * T, D, 1e-5f, 0, s);
+  LRAM_HIP_CHECK(hipMemcpyAsync(e->TOK.p, e->X.p, sizeof(float) * (size_t)B * T * D, hipMemcpyDeviceToDevice, s));
+  run_stack(e, T, reset, s);
+  GemmArgs gh;
+  gh.a = e->HID.p + (int64_t)c.pred_token * D, gh.lda = (int64_t)T * D, gh.w = e->w_head, gh.ldw = D;
+  gh.c = e->LOGITS.p, gh.ldc = (int64_t)c.act_dim * c.n_vocab, gh.bias = e->b_head;
+  gh.m = B, gh.n = c.act_dim * c.n_vocab, gh.k = D;
+  launch_gemm_f32(gh, s);
+  launch_action_argmax(e->LOGITS.p, actions, tokens, B, c.act_dim, c.n_vocab, c.n_discrete, c.action_channels,
+                       c.tok_min, c.tok_max, discrete, s);
+}
+
+struct StateView {
+  float* p;
+  size_t n;
+};
+StateView state_view(const lram_engine* e, int block, int which) {
+  if (block < 0 || block >= (int)e->st.size()) return {nullptr, 0};
+  const BlockState& s = e->st[block];
+  const bool mlstm = e->cfg.backbone == LRAM_BACKBONE_XLSTM && !e->cfg.block_is_slstm[block];
+  switch (which) {
+    case 0: return {s.s0.p, s.s0.n};
+    case 1: return mlstm ? StateView{s.n.p, s.n.n} : StateView{nullptr, 0};
+    case 2: return mlstm ? StateView{s.m.p, s.m.n} : StateView{nullptr, 0};
+    case 3: return {s.conv.p, s.conv.n};
+    default: return {nullptr, 0};
+  }
+}
+
+template <typename Fn>
+int32_t guarded(Fn&& fn) {
+  try {
+    fn();
+    g_last_error.clear();
+    return 0;
+  } catch (const std::exception& ex) {
+    g_last_error = ex.what();
+    return 1;
+  } catch (...) {
+    g_last_error = "lram: unknown error";
+    return 1;
+  }
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* lram_last_error(void) { return g_last_error.c_str(); }
+
+int32_t lram_abi_version(void) { return LRAM_ABI_VERSION; }
+
+int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
+  return guarded([&] {
+    LRAM_REQUIRE(cfg != nullptr && out != nullptr, "lram_create: null argument");
+    validate_config(*cfg);
+    int ndev = 0;
+    LRAM_HIP_CHECK(hipGetDeviceCount(&ndev));
+    LRAM_REQUIRE(device >= 0 && device < ndev, "lram_create: no such HIP device");
+    LRAM_HIP_CHECK(hipSetDevice(device));
+    auto e = std::make_unique<lram_engine>();
+    e->cfg = *cfg;
+    e->device = device;
+    *out = e.release();
+  });
+}
+
+int32_t lram_destroy(lram_engine* e) {
+  return guarded([&] {
+    if (e) {
+      (void)hipSetDevice(e->device);
+      delete e;
+    }
+  });
+}
+
+int32_t lram_set_weight(lram_engine* e, const char* name, const float* host_data, size_t numel) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && name && host_data && numel > 0, "lram_set_weight: bad argument");
+    LRAM_HIP_CHECK(hipSetDevice(e->device));
+    DevBuf& b = e->weights[name];
+    b.alloc(numel);
+    LRAM_HIP_CHECK(hipMemcpy(b.p, host_data, numel * sizeof(float), hipMemcpyHostToDevice));
+    e->finalized = false;
+    e->drop_graph();
+  });
+}
+
+int32_t lram_finalize(lram_engine* e) {
+  return guarded([&] {
+    LRAM_REQUIRE(e != nullptr, "lram_finalize: null engine");
+    finalize(e);
+  });
+}
+
+int32_t lram_state_alloc(lram_engine* e, int32_t batch) {
+  return guarded([&] {
+    LRAM_REQUIRE(e != nullptr, "lram_state_alloc: null engine");
+    state_alloc(e, batch);
+  });
+}
+
+int64_t lram_state_bytes_per_env(const lram_engine* e) {
+  if (!e) return 0;
+  const lram_config& c = e->cfg;
+  int64_t elems = 0;
+  for (int i = 0; i < c.n_blocks; ++i) {
+    if (c.backbone == LRAM_BACKBONE_MAMBA) {
+      elems += (int64_t)c.d_inner * (c.d_state + c.d_conv);
+    } else if (c.block_is_slstm[i]) {
+      elems += (int64_t)c.d_model * (4 + c.conv_k);
+    } else {
+      const int64_t DH = c.inner / c.n_heads;
+      elems += (int64_t)c.n_heads * DH * DH + c.inner + c.n_heads + (int64_t)c.conv_k * c.inner;
+    }
+  }
+  return elems * 4;
+}
+
+int32_t lram_reset(lram_engine* e, const uint8_t* dev_env_mask, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0, "lram_reset: state not allocated");
+    LRAM_HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = e->B;
+    for (int i = 0; i < e->cfg.n_blocks; ++i) {
+      BlockState& st = e->st[i];
+      const bool slstm = e->cfg.backbone == LRAM_BACKBONE_XLSTM && e->cfg.block_is_slstm[i];
+      if (slstm)
+        launch_zero_rows(st.s0.p, dev_env_mask, B, e->cfg.d_model, 4, (int64_t)B * e->cfg.d_model, s);
+      else
+        launch_zero_rows(st.s0.p, dev_env_mask, B, (int64_t)(st.s0.n / B), 1, 0, s);
+      if (st.n.p) launch_zero_rows(st.n.p, dev_env_mask, B, (int64_t)(st.n.n / B), 1, 0, s);
+      if (st.m.p) launch_zero_rows(st.m.p, dev_env_mask, B, (int64_t)(st.m.n / B), 1, 0, s);
+      launch_zero_rows(st.conv.p, dev_env_mask, B, (int64_t)(st.conv.n / B), 1, 0, s);
+    }
+  });
+}
+
+int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding, const float* dev_rtg,
+                  const float* dev_reward, const uint8_t* dev_reset_mask, int32_t discrete, float* dev_actions,
+                  int32_t* dev_tokens, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0, "lram_step: state not allocated (call lram_state_alloc)");
+    LRAM_REQUIRE(dev_obs && dev_rtg && dev_reward && dev_actions, "lram_step: null device pointer");
+    LRAM_REQUIRE(e->cfg.tokens_per_step == 3, "lram_step: the (state, rtg, reward) front end needs tokens_per_step == 3");
+    LRAM_HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (e->graph_mode && !e->prof_on) {
+      GraphKey key{};
+      key.obs = dev_obs, key.rtg = dev_rtg, key.rew = dev_reward, key.mask = dev_reset_mask, key.act = dev_actions;
+      key.tok = dev_tokens, key.emb = obs_is_embedding, key.discrete = discrete, key.B = e->B, key.stream = s;
+      if (!(e->graph_valid && key == e->graph_key)) {
+        e->drop_graph();
+        LRAM_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        try {
+          step_launches(e, dev_obs, obs_is_embedding, dev_rtg, dev_reward, dev_reset_mask, discrete, dev_actions,
+                        dev_tokens, s);
+        } catch (...) {
+          hipGraph_t g = nullptr;
+          (void)hipStreamEndCapture(s, &g);
+          if (g) (void)hipGraphDestroy(g);
+          throw;
+        }
+        LRAM_HIP_CHECK(hipStreamEndCapture(s, &e->graph));
+        LRAM_HIP_CHECK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
+        e->graph_key = key;
+        e->graph_valid = true;
+      }
+      LRAM_HIP_CHECK(hipGraphLaunch(e->graph_exec, s));
+    } else {
+      step_launches(e, dev_obs, obs_is_embedding, dev_rtg, dev_reward, dev_reset_mask, discrete, dev_actions,
+                    dev_tokens, s);
+    }
+  });
+}
+
+int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_t tokens,
+                          const uint8_t* dev_reset_mask, float* dev_hidden_out, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0, "lram_encoder_step: state not allocated");
+    LRAM_REQUIRE(dev_inputs_embeds && dev_hidden_out, "lram_encoder_step: null device pointer");
+    LRAM_REQUIRE(tokens >= 1 && tokens <= kMaxTokens, "lram_encoder_step: tokens must be in 1..4");
+    LRAM_HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t bytes = sizeof(float) * (size_t)e->B * tokens * e->cfg.d_model;
+    LRAM_HIP_CHECK(hipMemcpyAsync(e->X.p, dev_inputs_embeds, bytes, hipMemcpyDeviceToDevice, s));
+    run_stack(e, tokens, dev_reset_mask, s);
+    LRAM_HIP_CHECK(hipMemcpyAsync(dev_hidden_out, e->HID.p, bytes, hipMemcpyDeviceToDevice, s));
+  });
+}
+
+int32_t lram_get_taps(lram_engine* e, float* dev_tokens_embed, float* dev_hidden, float* dev_logits, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0, "lram_get_taps: state not allocated");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t btd = sizeof(float) * (size_t)e->B * e->cfg.tokens_per_step * e->cfg.d_model;
+    if (dev_tokens_embed) LRAM_HIP_CHECK(hipMemcpyAsync(dev_tokens_embed, e->TOK.p, btd, hipMemcpyDeviceToDevice, s));
+    if (dev_hidden) LRAM_HIP_CHECK(hipMemcpyAsync(dev_hidden, e->HID.p, btd, hipMemcpyDeviceToDevice, s));
+    if (dev_logits)
+      LRAM_HIP_CHECK(hipMemcpyAsync(dev_logits, e->LOGITS.p, sizeof(float) * e->LOGITS.n, hipMemcpyDeviceToDevice, s));
+  });
+}
+
+int64_t lram_state_numel(const lram_engine* e, int32_t block, int32_t which) {
+  if (!e || e->B <= 0) return 0;
+  return (int64_t)state_view(e, block, which).n;
+}
+
+int32_t lram_state_export(lram_engine* e, int32_t block, int32_t which, float* dev_dst, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0 && dev_dst, "lram_state_export: bad argument");
+    StateView v = state_view(e, block, which);
+    LRAM_REQUIRE(v.p != nullptr, "lram_state_export: no such state tensor");
+    LRAM_HIP_CHECK(hipMemcpyAsync(dev_dst, v.p, v.n * sizeof(float), hipMemcpyDeviceToDevice,
+                                  static_cast<hipStream_t>(stream)));
+  });
+}
+
+int32_t lram_state_import(lram_engine* e, int32_t block, int32_t which, const float* dev_src, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0 && dev_src, "lram_state_import: bad argument");
+    StateView v = state_view(e, block, which);
+    LRAM_REQUIRE(v.p != nullptr, "lram_state_import: no such state tensor");
+    LRAM_HIP_CHECK(hipMemcpyAsync(v.p, dev_src, v.n * sizeof(float), hipMemcpyDeviceToDevice,
+                                  static_cast<hipStream_t>(stream)));
+  });
+}
+
+int32_t lram_set_graph_mode(lram_engine* e, int32_t enable) {
+  return guarded([&] {
+    LRAM_REQUIRE(e != nullptr, "lram_set_graph_mode: null engine");
+    e->graph_mode = enable != 0;
+    if (!e->graph_mode) e->drop_graph();
+  });
+}
+
+int32_t lram_profile_begin(lram_engine* e) {
+  return guarded([&] {
+    LRAM_REQUIRE(e != nullptr, "lram_profile_begin: null engine");
+    e->prof_on = true;
+    e->prof_used = 0;
+  });
+}
+
+int32_t lram_profile_end(lram_engine* e, double* total_ms, int64_t* n_launches) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && total_ms && n_launches, "lram_profile_end: bad argument");
+    double tot = 0.0;
+    for (size_t i = 0; i < e->prof_used; ++i) {
+      LRAM_HIP_CHECK(hipEventSynchronize(e->prof_events[i].second));
+      float ms = 0.f;
+      LRAM_HIP_CHECK(hipEventElapsedTime(&ms, e->prof_events[i].first, e->prof_events[i].second));
+      tot += ms;
+    }
+    *total_ms = tot;
+    *n_launches = (int64_t)e->prof_used;
+    e->prof_on = false;
+    e->prof_used = 0;
+  });
+}
+
+int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
+                      const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
+  return guarded([&] {
+    GemmArgs g;
+    g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
+    g.residual = accumulate ? dev_c : nullptr;
+    g.m = m, g.n = n, g.k = k;
+    launch_gemm_f32(g, static_cast<hipStream_t>(stream));
+  });
+}
+
+int32_t lram_stream_copy(float* dev_dst, const float* dev_src, size_t numel, void* stream) {
+  return guarded([&] { launch_stream_copy(dev_dst, dev_src, numel, static_cast<hipStream_t>(stream)); });
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+// fp32 GEMM on the CDNA4 matrix cores:  C[M,N] = A[M,K] * W[N,K]^T (+ bias) (+ residual)
+//
+// Replaces the cuBLAS `nn.Linear` calls of the reference hot path: mLSTM proj_up /
+// proj_down, sLSTM gate / recurrent / FFN projections, Mamba in/x/dt/out projections, embed_state,
+// action_net.  fp32 inputs and `v_mfma_f32_32x32x2_f32` accumulation: bit-for-bit a k-ordered fmaf
+// chain, so logits keep full fp32 accuracy (actions are argmax'ed and must match the fp32 CPU path).
+//
+// Tiling: 256 threads = 4 waves (2 x 2), block tile 128 x 128 x 32, wave tile 64 x 64 = 2 x 2 MFMA
+// 32x32 accumulators (64 VGPR).  Both operands are K-contiguous, staged global -> registers -> LDS
+// (row pitch 36 floats: ds_read_b128 of 16 consecutive rows hits 16 distinct 4-bank slots), next
+// K-tile's global loads are issued before the MFMAs of the current one.
+#include "common.h"
+
+namespace lram {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int BM = 128, BN = 128, BK = 32, PITCH = 36;
+
+template <bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * PITCH];
+  float* As = lds;
+  float* Bs = lds + BM * PITCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // batch pointers
+  const int z = blockIdx.y;
+  const int z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const float* A = g.a + z1 * g.sA1 + z2 * g.sA2;
+  const float* W = g.w + z1 * g.sW1 + z2 * g.sW2;
+  float* C = g.c + z1 * g.sC1 + z2 * g.sC2;
+  const float* R = HAS_RES ? g.residual + z1 * g.sC1 + z2 * g.sC2 : nullptr;
+  const float* bias = HAS_BIAS ? g.bias + z1 * g.sBias1 + z2 * g.sBias2 : nullptr;
+
+  // XCD-aware tile order: blocks b, b+8, ... share an XCD (and its L2); give each XCD a contiguous run
+  // of tiles so that neighbouring N-tiles of one M-tile (same A rows) hit the same L2.
+  const int tiles_n = (g.n + BN - 1) / BN;
+  const int tiles_m = (g.m + BM - 1) / BM;
+  const int nwg = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+  const int tm_idx = bid / tiles_n;
+  const int tn_idx = bid - tm_idx * tiles_n;
+  const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+
+  // global -> register staging: 4 float4 of A and 4 of W per thread per K-tile
+  const int lr = tid >> 3;        // 0..31 row within a 32-row slab
+  const int lc = (tid & 7) << 2;  // k offset 0,4,..,28
+  float4 ra[4], rb[4];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = lr + 32 * i;
+      const int kk = k0 + lc;
+      const int gm = m0 + r, gn = n0 + r;
+      ra[i] = (gm < g.m && kk < g.k) ? *reinterpret_cast<const float4*>(A + (int64_t)gm * g.lda + kk)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = (gn < g.n && kk < g.k) ? *reinterpret_cast<const float4*>(W + (int64_t)gn * g.ldw + kk)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = lr + 32 * i;
+      *reinterpret_cast<float4*>(As + r * PITCH + lc) = ra[i];
+      *reinterpret_cast<float4*>(Bs + r * PITCH + lc) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const float* a_base = As + (64 * wm + li) * PITCH + 4 * lh;
+  const float* b_base = Bs + (64 * wn + li) * PITCH + 4 * lh;
+
+  const int nk = (g.k + BK - 1) / BK;
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+#pragma unroll
+    for (int kc = 0; kc < BK / 8; ++kc) {
+      float4 af[2], bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = *reinterpret_cast<const float4*>(a_base + 32 * t * PITCH + 8 * kc);
+        bf[t] = *reinterpret_cast<const float4*>(b_base + 32 * t * PITCH + 8 * kc);
+      }
+      // lane half h supplies k = 8*kc + 4*h + j to MFMA j: A and W use the same k for the same (h, j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + 64 * wn + 32 * j + li;
+      if (col >= g.n) continue;
+      const float bv = HAS_BIAS ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < g.m) {
+          float v = acc[i][j][r] + bv;
+          if (HAS_RES) v += R[(int64_t)row * g.ldc + col];
+          C[(int64_t)row * g.ldc + col] = v;
+        }
+      }
+    }
+}
+}  // namespace
+
+void launch_gemm_f32(const GemmArgs& g, hipStream_t stream) {
+  LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
+  LRAM_REQUIRE((g.k & 3) == 0 && (g.lda & 3) == 0 && (g.ldw & 3) == 0, "gemm: K, lda, ldw must be multiples of 4");
+  LRAM_REQUIRE(((g.sA1 | g.sA2 | g.sW1 | g.sW2) & 3) == 0, "gemm: batch strides of A/W must be multiples of 4");
+  const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
+  dim3 grid(tiles, g.nb1 * g.nb2);
+  dim3 block(256);
+  const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
+  if (hb && hr)
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, stream, g);
+  else if (hb)
+    hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, stream, g);
+  else if (hr)
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace lram

@@ -1,0 +1,264 @@
+// Row norms, token front end, action head argmax / de-tokenisation, utility copies.
+//
+// Reference functions replaced: nn.LayerNorm `embed_ln`, xlstm LayerNorm / LlamaRMSNorm
+// (src/algos/models/rms_norm.py:17-22), embed_return / embed_rewards Linear(1, D)
+// (src/algos/models/online_decision_transformer_model.py:522-530), torch.argmax +
+// MinMaxTokenizer.inv_tokenize (src/algos/models/multi_domain_discrete_dt_model.py:83-94,
+// src/tokenizers_custom/minmax_tokenizer.py:31-47).
+#include "common.h"
+#include "device_math.h"
+
+namespace lram {
+namespace {
+
+constexpr int kNormMaxV = 8;  // float4 per lane: d <= 2048
+
+// One wave per row.  LayerNorm: (x - mean) / sqrt(var + eps) * gamma + beta (biased variance, two pass);
+// RMSNorm: gamma * (x * rsqrt(mean(x^2) + eps)).
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t in_stride, float* out,
+                                                       int64_t out_stride, const float* gamma, const float* beta,
+                                                       int rows, int d, float eps, int rms) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = d >> 2;
+  const float* src = in + (int64_t)row * in_stride;
+  float4 v[kNormMaxV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < kNormMaxV; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = i < nv ? *reinterpret_cast<const float4*>(src + 4 * i) : f4_zero();
+    s += v[j].x + v[j].y + v[j].z + v[j].w;
+  }
+  const float mean = rms ? 0.f : wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < kNormMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+      const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+      q += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float rstd = rms ? rsqrtf(var + eps) : 1.f / sqrtf(var + eps);
+  float* dst = out + (int64_t)row * out_stride;
+#pragma unroll
+  for (int j = 0; j < kNormMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i >= nv) continue;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * i);
+    float4 o;
+    o.x = (v[j].x - mean) * rstd * g.x;
+    o.y = (v[j].y - mean) * rstd * g.y;
+    o.z = (v[j].z - mean) * rstd * g.z;
+    o.w = (v[j].w - mean) * rstd * g.w;
+    if (beta != nullptr) {
+      const float4 bb = *reinterpret_cast<const float4*>(beta + 4 * i);
+      o.x += bb.x;
+      o.y += bb.y;
+      o.z += bb.z;
+      o.w += bb.w;
+    }
+    *reinterpret_cast<float4*>(dst + 4 * i) = o;
+  }
+}
+
+// Mamba Block entry ([3P] mamba_ssm layer_norm_fn(prenorm=True, residual_in_fp32)):
+// res_out = hidden + res_in ; normed = res_out * rsqrt(mean(res_out^2) + eps) * gamma
+__global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, const float* res_in, float* res_out,
+                                                           float* normed, const float* gamma, int rows, int d,
+                                                           float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nv = d >> 2;
+  const int64_t base = (int64_t)row * d;
+  float4 v[kNormMaxV];
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < kNormMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+      float4 x = *reinterpret_cast<const float4*>(hidden + base + 4 * i);
+      if (res_in != nullptr) {
+        const float4 r = *reinterpret_cast<const float4*>(res_in + base + 4 * i);
+        x.x += r.x;
+        x.y += r.y;
+        x.z += r.z;
+        x.w += r.w;
+      }
+      v[j] = x;
+      if (res_out != nullptr) *reinterpret_cast<float4*>(res_out + base + 4 * i) = x;
+      q += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+    } else {
+      v[j] = f4_zero();
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+  for (int j = 0; j < kNormMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i >= nv) continue;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * i);
+    float4 o;
+    o.x = v[j].x * rstd * g.x;
+    o.y = v[j].y * rstd * g.y;
+    o.z = v[j].z * rstd * g.z;
+    o.w = v[j].w * rstd * g.w;
+    *reinterpret_cast<float4*>(normed + base + 4 * i) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_scalars_kernel(float* x, const float* rtg, const float* rew,
+                                                            const float* w_rtg, const float* b_rtg,
+                                                            const float* w_rew, const float* b_rew, int B, int T,
+                                                            int D) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * D) return;
+  const int b = (int)(gid / D);
+  const int d = (int)(gid - (int64_t)b * D);
+  float* row = x + (int64_t)b * T * D;
+  row[D + d] = rtg[b] * w_rtg[d] + b_rtg[d];
+  row[2 * D + d] = rew[b] * w_rew[d] + b_rew[d];
+}
+
+__global__ __launch_bounds__(256) void scatter_token0_kernel(float* x, const float* emb, int B, int T, int D) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * D) return;
+  const int b = (int)(gid / D);
+  const int d = (int)(gid - (int64_t)b * D);
+  x[(int64_t)b * T * D + d] = emb[gid];
+}
+
+// One wave per (env, action dim): first index of the maximum (torch.argmax tie rule), then
+// inv_tokenize: max(tok - shift, 0) * ((max - min) / channels) + min.
+__global__ __launch_bounds__(256) void action_argmax_kernel(const float* logits, float* actions, int32_t* tokens,
+                                                            int B, int act_dim, int n_vocab, int n_discrete,
+                                                            int action_channels, float tok_min, float tok_max,
+                                                            int discrete) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ndim = discrete ? 1 : act_dim;
+  if (item >= B * ndim) return;
+  const int b = item / ndim, j = item - b * ndim;
+  const float* lg = logits + (int64_t)b * act_dim * n_vocab + (int64_t)j * n_vocab;
+  const int n = discrete ? n_discrete : n_vocab;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lane; i < n; i += 64) {
+    const float v = lg[i];
+    if (v > best || (v == best && i < bi)) {
+      best = v;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (lane == 0) {
+    if (tokens != nullptr) tokens[(int64_t)b * act_dim + j] = bi;
+    float out;
+    if (discrete) {
+      out = (float)bi;
+    } else {
+      int t = bi - n_discrete;
+      t = t < 0 ? 0 : t;
+      const float bin_width = (tok_max - tok_min) / (float)action_channels;
+      out = (float)t * bin_width + tok_min;
+    }
+    actions[(int64_t)b * act_dim + j] = out;
+  }
+}
+
+__global__ __launch_bounds__(256) void stream_copy_kernel(float4* dst, const float4* src, size_t n4) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+// buf viewed as [outer][B][row_elems] with outer stride `outer_stride`; zero row b where mask[b] != 0
+// (mask == nullptr: every row).
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* buf, const uint8_t* mask, int B, int64_t row_elems,
+                                                        int64_t outer_stride) {
+  const int b = blockIdx.y;
+  const int o = blockIdx.z;
+  if (mask != nullptr && mask[b] == 0) return;
+  float* row = buf + (int64_t)o * outer_stride + (int64_t)b * row_elems;
+  const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthr = (int64_t)gridDim.x * blockDim.x;
+  if ((row_elems & 3) == 0 && (outer_stride & 3) == 0) {
+    for (int64_t i = tid0; i < (row_elems >> 2); i += nthr) reinterpret_cast<float4*>(row)[i] = f4_zero();
+  } else {
+    for (int64_t i = tid0; i < row_elems; i += nthr) row[i] = 0.f;
+  }
+}
+
+}  // namespace
+
+void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
+                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream) {
+  LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "row norm: d must be a multiple of 4 and <= 2048");
+  hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, in_stride, out, out_stride,
+                     gamma, beta, rows, d, eps, rms);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
+                         const float* gamma, int rows, int d, float eps, hipStream_t stream) {
+  LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "rms norm: d must be a multiple of 4 and <= 2048");
+  hipLaunchKernelGGL(add_rms_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, hidden, res_in, res_out,
+                     normed, gamma, rows, d, eps);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_embed_scalars(float* x, const float* rtg, const float* rew, const float* w_rtg, const float* b_rtg,
+                          const float* w_rew, const float* b_rew, int B, int T, int D, hipStream_t stream) {
+  LRAM_REQUIRE(T >= 3, "embed: tokens_per_step must be >= 3 (state, rtg, reward)");
+  const int64_t n = (int64_t)B * D;
+  hipLaunchKernelGGL(embed_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, rtg, rew,
+                     w_rtg, b_rtg, w_rew, b_rew, B, T, D);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_scatter_token0(float* x, const float* emb, int B, int T, int D, hipStream_t stream) {
+  const int64_t n = (int64_t)B * D;
+  hipLaunchKernelGGL(scatter_token0_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, emb, B, T,
+                     D);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_action_argmax(const float* logits, float* actions, int32_t* tokens, int B, int act_dim, int n_vocab,
+                          int n_discrete, int action_channels, float tok_min, float tok_max, int discrete,
+                          hipStream_t stream) {
+  const int items = B * (discrete ? 1 : act_dim);
+  hipLaunchKernelGGL(action_argmax_kernel, dim3((items + 3) / 4), dim3(256), 0, stream, logits, actions, tokens, B,
+                     act_dim, n_vocab, n_discrete, action_channels, tok_min, tok_max, discrete);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_stream_copy(float* dst, const float* src, size_t numel, hipStream_t stream) {
+  LRAM_REQUIRE(numel % 4 == 0, "stream copy: numel must be a multiple of 4");
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, stream, reinterpret_cast<float4*>(dst),
+                     reinterpret_cast<const float4*>(src), numel / 4);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_zero_rows(float* buf, const uint8_t* mask, int B, int64_t row_elems, int64_t outer, int64_t outer_stride,
+                      hipStream_t stream) {
+  const int64_t n4 = row_elems >> 2;
+  int gx = (int)((n4 + 255) / 256);
+  gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(gx, B, (unsigned)outer), dim3(256), 0, stream, buf, mask, B, row_elems,
+                     outer_stride);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace lram

@@ -1,0 +1,574 @@
+// Recurrent xLSTM kernels for gfx950: the mLSTM matrix-memory update (the HBM-bound hot kernel), its
+// conv / qkv / gate front end, the multi-head group norm epilogue, and the sLSTM scalar cell.
+//
+// What they replace on the reference path: N3 recurrent_step_stabilized_simple
+// (~15 eager ops), N5 conv1d_step, N6 LinearHeadwiseExpand, N7 MultiHeadLayerNorm, N1 sLSTM pointwise.
+// All of a timestep's T (= 3) tokens are applied inside one launch per layer: the matrix memory C is
+// read once and written once per env-step instead of once per token.
+#include "common.h"
+#include "device_math.h"
+
+namespace lram {
+
+// =============================================================================================
+// mLSTM front end: one workgroup per env.
+//   conv1d_step (K taps, depthwise) -> SiLU -> block-diagonal q/k (from the conv branch) and v (from the
+//   pre-conv branch) -> gate pre-activations Wi.[q,k,v]+bi, Wf.[q,k,v]+bf (block reduction) -> stabilised
+//   gate scalars f_t, i_t, m_t -> normaliser state n_t and denominators max(|q.n_t|, exp(-m_t)) + 1e-6.
+// Writes q,k,v,xa rows, the per-(token, head) scalars, and the updated conv / n / m state.
+// =============================================================================================
+namespace {
+
+constexpr int kPreThreads = 256;
+constexpr int kMaxGroups = 3;  // channel groups (of 4) per thread: inner <= 3072
+
+template <int T, int NH>
+__global__ __launch_bounds__(kPreThreads) void mlstm_pre_kernel(MlstmPreArgs a) {
+  constexpr int NRED = 2 * T * NH;
+  __shared__ float red[4][NRED];
+  __shared__ float gate_i[T][NH], gate_f[T][NH];
+  __shared__ float s_f[T][NH], s_i[T][NH], s_m[T][NH];
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int inner = a.inner;
+  const int DH = inner / NH;
+  const int ngroups = inner >> 2;
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+
+  float pi[T][NH], pf[T][NH];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) pi[t][h] = pf[t][h] = 0.f;
+
+  // ---- phase 1: conv, qkv, gate partial sums -------------------------------------------------
+  for (int cg = tid; cg < ngroups; cg += kPreThreads) {
+    const int c0 = cg << 2;
+    // conv window per channel: win[k] holds tap k for the 4 channels (oldest first)
+    float4 win[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      win[k] = (rs || k >= a.K) ? f4_zero()
+                                : *reinterpret_cast<const float4*>(a.conv_state + ((int64_t)b * a.K + k) * inner + c0);
+    // conv weights [inner, K] (K == 4 taps contiguous per channel)
+    float4 cw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cw[c] = *reinterpret_cast<const float4*>(a.conv_w + (int64_t)(c0 + c) * 4);
+    const float4 cb = *reinterpret_cast<const float4*>(a.conv_b + c0);
+    float4 wq[4], wk[4], wv[4];  // row o of the 4x4 block: w[o] . x
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      wq[o] = *reinterpret_cast<const float4*>(a.wq + (int64_t)cg * 16 + o * 4);
+      wk[o] = *reinterpret_cast<const float4*>(a.wk + (int64_t)cg * 16 + o * 4);
+      wv[o] = *reinterpret_cast<const float4*>(a.wv + (int64_t)cg * 16 + o * 4);
+    }
+    float4 qt[T], kt[T], vt[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int64_t row = (int64_t)b * T + t;
+      const float4 xm = *reinterpret_cast<const float4*>(a.u + row * 2 * inner + c0);
+      win[0] = win[1];
+      win[1] = win[2];
+      win[2] = win[3];
+      win[3] = xm;
+      float4 y;
+      y.x = win[0].x * cw[0].x + win[1].x * cw[0].y + win[2].x * cw[0].z + win[3].x * cw[0].w + cb.x;
+      y.y = win[0].y * cw[1].x + win[1].y * cw[1].y + win[2].y * cw[1].z + win[3].y * cw[1].w + cb.y;
+      y.z = win[0].z * cw[2].x + win[1].z * cw[2].y + win[2].z * cw[2].z + win[3].z * cw[2].w + cb.z;
+      y.w = win[0].w * cw[3].x + win[1].w * cw[3].y + win[2].w * cw[3].z + win[3].w * cw[3].w + cb.w;
+      float4 xa;
+      xa.x = silu_f(y.x);
+      xa.y = silu_f(y.y);
+      xa.z = silu_f(y.z);
+      xa.w = silu_f(y.w);
+      auto bd = [](const float4* w, const float4& x) {
+        float4 r;
+        r.x = w[0].x * x.x + w[0].y * x.y + w[0].z * x.z + w[0].w * x.w;
+        r.y = w[1].x * x.x + w[1].y * x.y + w[1].z * x.z + w[1].w * x.w;
+        r.z = w[2].x * x.x + w[2].y * x.y + w[2].z * x.z + w[2].w * x.w;
+        r.w = w[3].x * x.x + w[3].y * x.y + w[3].z * x.z + w[3].w * x.w;
+        return r;
+      };
+      qt[t] = bd(wq, xa);
+      kt[t] = bd(wk, xa);
+      vt[t] = bd(wv, xm);
+      *reinterpret_cast<float4*>(a.q + row * inner + c0) = qt[t];
+      *reinterpret_cast<float4*>(a.k + row * inner + c0) = kt[t];
+      *reinterpret_cast<float4*>(a.v + row * inner + c0) = vt[t];
+      *reinterpret_cast<float4*>(a.xa + row * inner + c0) = xa;
+    }
+    // conv state after the T tokens (reference layout [B, K, inner], newest tap last)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < a.K) *reinterpret_cast<float4*>(a.conv_state + ((int64_t)b * a.K + k) * inner + c0) = win[k];
+    // gate partial sums over this thread's 4 channels of q, k and v
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float* wi = a.wi + (int64_t)h * 3 * inner + c0;
+      const float* wf = a.wf + (int64_t)h * 3 * inner + c0;
+      const float4 iq = *reinterpret_cast<const float4*>(wi), ik = *reinterpret_cast<const float4*>(wi + inner),
+                   iv = *reinterpret_cast<const float4*>(wi + 2 * inner);
+      const float4 fq = *reinterpret_cast<const float4*>(wf), fk = *reinterpret_cast<const float4*>(wf + inner),
+                   fv = *reinterpret_cast<const float4*>(wf + 2 * inner);
+      auto dot = [](const float4& x, const float4& y) { return x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; };
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        pi[t][h] += dot(iq, qt[t]) + dot(ik, kt[t]) + dot(iv, vt[t]);
+        pf[t][h] += dot(fq, qt[t]) + dot(fk, kt[t]) + dot(fv, vt[t]);
+      }
+    }
+  }
+  // block reduction of the 2*T*NH partial sums
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float si = wave_sum(pi[t][h]);
+      const float sf = wave_sum(pf[t][h]);
+      if (lane == 0) {
+        red[wave][(t * NH + h) * 2 + 0] = si;
+        red[wave][(t * NH + h) * 2 + 1] = sf;
+      }
+    }
+  __syncthreads();
+  if (tid < T * NH) {
+    const int t = tid / NH, h = tid - t * NH;
+    float si = 0.f, sf = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      si += red[w][tid * 2 + 0];
+      sf += red[w][tid * 2 + 1];
+    }
+    gate_i[t][h] = si + a.bi[h];
+    gate_f[t][h] = sf + a.bf[h];
+  }
+  __syncthreads();
+  // ---- phase 2: stabilised gate scalars (sequential over the T tokens, one thread per head) --
+  if (tid < NH) {
+    const int h = tid;
+    float m = rs ? 0.f : a.m_state[(int64_t)b * NH + h];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float lf = log_sigmoid(gate_f[t][h]);
+      const float mn = fmaxf(lf + m, gate_i[t][h]);
+      s_f[t][h] = expf(lf + m - mn);
+      s_i[t][h] = expf(gate_i[t][h] - mn);
+      s_m[t][h] = mn;
+      m = mn;
+    }
+    a.m_state[(int64_t)b * NH + h] = m;
+  }
+  __syncthreads();
+  // ---- phase 3: normaliser state n_t = f_t n_{t-1} + i_t k_t/sqrt(DH) and q_t . n_t -----------
+  float pq[T][NH];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) pq[t][h] = 0.f;
+  const float sqrt_dh = sqrtf((float)DH);
+  for (int cg = tid; cg < ngroups; cg += kPreThreads) {
+    const int c0 = cg << 2;
+    const int hh = c0 / DH;
+    float4 n = rs ? f4_zero() : *reinterpret_cast<const float4*>(a.n_state + (int64_t)b * inner + c0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int64_t row = (int64_t)b * T + t;
+      const float4 qv = *reinterpret_cast<const float4*>(a.q + row * inner + c0);
+      const float4 kv = *reinterpret_cast<const float4*>(a.k + row * inner + c0);
+      float f = 0.f, i = 0.f;
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        if (h == hh) {
+          f = s_f[t][h];
+          i = s_i[t][h];
+        }
+      n.x = f * n.x + i * (kv.x / sqrt_dh);
+      n.y = f * n.y + i * (kv.y / sqrt_dh);
+      n.z = f * n.z + i * (kv.z / sqrt_dh);
+      n.w = f * n.w + i * (kv.w / sqrt_dh);
+      const float d = qv.x * n.x + qv.y * n.y + qv.z * n.z + qv.w * n.w;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) pq[t][h] += (h == hh) ? d : 0.f;
+    }
+    *reinterpret_cast<float4*>(a.n_state + (int64_t)b * inner + c0) = n;
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float s = wave_sum(pq[t][h]);
+      if (lane == 0) red[wave][t * NH + h] = s;
+    }
+  __syncthreads();
+  if (tid < T * NH) {
+    const int t = tid / NH, h = tid - t * NH;
+    const float qn = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    const float denom = fmaxf(fabsf(qn), expf(-s_m[t][h])) + 1e-6f;
+    float4 o = make_float4(s_f[t][h], s_i[t][h], denom, s_m[t][h]);
+    *reinterpret_cast<float4*>(a.scal + (((int64_t)b * T + t) * NH + h) * 4) = o;
+  }
+}
+
+// =============================================================================================
+// mLSTM cell: C_t = f_t C_{t-1} + i_t (k_t/sqrt(DH)) v_t^T ;  h_t = (q_t^T C_t) / denom_t   for t = 1..T
+// One workgroup per (env, head, column slice of CW = 4*LPR columns).  Each lane owns 4 adjacent columns
+// (16 B, coalesced: a wave reads 64/LPR rows x LPR*16 B contiguous), the 256/LPR row groups stride over
+// the DH rows; every C element is loaded once, updated T times in registers and stored once.
+// =============================================================================================
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kCellThreads = 256;
+constexpr int kCellUnroll = 8;
+
+template <int T, int LPR>
+__global__ __launch_bounds__(kCellThreads) void mlstm_cell_kernel(MlstmCellArgs a) {
+  constexpr int CW = 4 * LPR;
+  constexpr int RP = kCellThreads / LPR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int DH = a.DH;
+  float* qs = smem;                 // [T][DH]
+  float* aks = smem + T * DH;       // [T][DH]   i_t * k_t / sqrt(DH)
+  float* red = smem + 2 * T * DH;   // [RP][T][CW]
+
+  const int b = blockIdx.z, h = blockIdx.y, slice = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int cl = tid % LPR, rg = tid / LPR;
+  const int inner = a.NH * DH;
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+
+  float f[T], ig[T], den[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float4 s = *reinterpret_cast<const float4*>(a.scal + (((int64_t)b * T + t) * a.NH + h) * 4);
+    f[t] = s.x;
+    ig[t] = s.y;
+    den[t] = s.z;
+  }
+  const float sqrt_dh = sqrtf((float)DH);
+  for (int r = tid; r < DH; r += kCellThreads) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r;
+      qs[t * DH + r] = a.q[off];
+      aks[t * DH + r] = ig[t] * (a.k[off] / sqrt_dh);
+    }
+  }
+  const int col0 = slice * CW + 4 * cl;
+  v4f vv[T], acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    vv[t] = *reinterpret_cast<const v4f*>(a.v + ((int64_t)b * T + t) * inner + (int64_t)h * DH + col0);
+    acc[t] = (v4f)(0.f);
+  }
+  __syncthreads();
+
+  // C is streamed exactly once per env-step: non-temporal loads/stores keep it out of the caches' way.
+  float* Cb = a.C + (((int64_t)b * a.NH + h) * DH) * DH + col0;
+  for (int r0 = rg; r0 < DH; r0 += RP * kCellUnroll) {
+    v4f c[kCellUnroll];
+#pragma unroll
+    for (int u = 0; u < kCellUnroll; ++u) {
+      const int r = r0 + u * RP;
+      c[u] = (r < DH && !rs) ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(Cb + (int64_t)r * DH))
+                             : (v4f)(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < kCellUnroll; ++u) {
+      const int r = r0 + u * RP;
+      if (r < DH) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float av = aks[t * DH + r];
+          const float qv = qs[t * DH + r];
+          c[u] = f[t] * c[u] + av * vv[t];
+          acc[t] += qv * c[u];
+        }
+        __builtin_nontemporal_store(c[u], reinterpret_cast<v4f*>(Cb + (int64_t)r * DH));
+      }
+    }
+  }
+  // reduce the RP row groups' partial q^T C
+#pragma unroll
+  for (int t = 0; t < T; ++t) *reinterpret_cast<v4f*>(red + ((rg * T + t) * CW) + 4 * cl) = acc[t];
+  __syncthreads();
+  for (int idx = tid; idx < T * CW; idx += kCellThreads) {
+    const int t = idx / CW, c = idx - t * CW;
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < RP; ++g) s += red[(g * T + t) * CW + c];
+    float d = den[0];
+#pragma unroll
+    for (int tt = 1; tt < T; ++tt) d = (t == tt) ? den[tt] : d;
+    a.h[((int64_t)b * T + t) * inner + (int64_t)h * DH + slice * CW + c] = s / d;
+  }
+}
+
+// =============================================================================================
+// MultiHeadLayerNorm (group norm over DH per head) + mLSTM output gating, or + residual (sLSTM).
+// One wave per (row, head); DH <= 768.
+// =============================================================================================
+constexpr int kGnMaxV = 3;
+
+__global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
+  const int row = blockIdx.x, h = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int DH = a.DH, D = a.NH * a.DH;
+  const int nv = DH >> 2;
+  const float* src = a.h + (int64_t)row * D + (int64_t)h * DH;
+  float4 v[kGnMaxV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = i < nv ? *reinterpret_cast<const float4*>(src + 4 * i) : f4_zero();
+    s += v[j].x + v[j].y + v[j].z + v[j].w;
+  }
+  const float mean = wave_sum(s) / (float)DH;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+      const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+      q += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+  }
+  const float var = wave_sum(q) / (float)DH;
+  const float rstd = 1.f / sqrtf(var + a.eps);
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i >= nv) continue;
+    const int hd = h * DH + 4 * i;
+    const float4 g = *reinterpret_cast<const float4*>(a.gamma + hd);
+    float4 o;
+    o.x = (v[j].x - mean) * rstd * g.x;
+    o.y = (v[j].y - mean) * rstd * g.y;
+    o.z = (v[j].z - mean) * rstd * g.z;
+    o.w = (v[j].w - mean) * rstd * g.w;
+    if (a.beta != nullptr) {
+      const float4 bb = *reinterpret_cast<const float4*>(a.beta + hd);
+      o.x += bb.x;
+      o.y += bb.y;
+      o.z += bb.z;
+      o.w += bb.w;
+    }
+    float* dst = a.out + (int64_t)row * D + hd;
+    if (a.mode == 0) {
+      const float4 sk = *reinterpret_cast<const float4*>(a.skip + hd);
+      const float4 xa = *reinterpret_cast<const float4*>(a.xa + (int64_t)row * D + hd);
+      const float4 z = *reinterpret_cast<const float4*>(a.u + (int64_t)row * 2 * D + D + hd);
+      o.x = (o.x + sk.x * xa.x) * silu_f(z.x);
+      o.y = (o.y + sk.y * xa.y) * silu_f(z.y);
+      o.z = (o.z + sk.z * xa.z) * silu_f(z.z);
+      o.w = (o.w + sk.w * xa.w) * silu_f(z.w);
+      *reinterpret_cast<float4*>(dst) = o;
+    } else {
+      float4 x = *reinterpret_cast<const float4*>(dst);
+      x.x += o.x;
+      x.y += o.y;
+      x.z += o.z;
+      x.w += o.w;
+      *reinterpret_cast<float4*>(dst) = x;
+    }
+  }
+}
+
+// =============================================================================================
+// sLSTM: conv1d_step + SiLU on the block input (per env, T tokens), reset of the scalar state.
+// =============================================================================================
+template <int T>
+__global__ __launch_bounds__(256) void slstm_conv_kernel(SlstmConvArgs a) {
+  const int ngroups = a.D >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)a.B * ngroups) return;
+  const int b = (int)(gid / ngroups);
+  const int c0 = (int)(gid - (int64_t)b * ngroups) << 2;
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+  const int D = a.D;
+  float4 win[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    win[k] = (rs || k >= a.K) ? f4_zero()
+                              : *reinterpret_cast<const float4*>(a.conv_state + ((int64_t)b * a.K + k) * D + c0);
+  float4 cw[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) cw[c] = *reinterpret_cast<const float4*>(a.conv_w + (int64_t)(c0 + c) * 4);
+  const float4 cb = *reinterpret_cast<const float4*>(a.conv_b + c0);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int64_t row = (int64_t)b * T + t;
+    const float4 x = *reinterpret_cast<const float4*>(a.xn + row * D + c0);
+    win[0] = win[1];
+    win[1] = win[2];
+    win[2] = win[3];
+    win[3] = x;
+    float4 y;
+    y.x = win[0].x * cw[0].x + win[1].x * cw[0].y + win[2].x * cw[0].z + win[3].x * cw[0].w + cb.x;
+    y.y = win[0].y * cw[1].x + win[1].y * cw[1].y + win[2].y * cw[1].z + win[3].y * cw[1].w + cb.y;
+    y.z = win[0].z * cw[2].x + win[1].z * cw[2].y + win[2].z * cw[2].z + win[3].z * cw[2].w + cb.z;
+    y.w = win[0].w * cw[3].x + win[1].w * cw[3].y + win[2].w * cw[3].z + win[3].w * cw[3].w + cb.w;
+    float4 o;
+    o.x = silu_f(y.x);
+    o.y = silu_f(y.y);
+    o.z = silu_f(y.z);
+    o.w = silu_f(y.w);
+    *reinterpret_cast<float4*>(a.xc + row * D + c0) = o;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < a.K) *reinterpret_cast<float4*>(a.conv_state + ((int64_t)b * a.K + k) * D + c0) = win[k];
+  if (rs) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      *reinterpret_cast<float4*>(a.slstm_state + ((int64_t)s * a.B + b) * D + c0) = f4_zero();
+  }
+}
+
+// sLSTM pointwise cell update for token t ([3P] slstm_pointwise: per-element n == 0 first-step rule).
+__global__ __launch_bounds__(256) void slstm_pointwise_kernel(SlstmPointwiseArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  if (gid >= (int64_t)a.B * H) return;
+  const int b = (int)(gid / H);
+  const int c = (int)(gid - (int64_t)b * H);
+  const int64_t row = (int64_t)b * a.T + a.t;
+  const float* g = a.gates + row * 4 * H + c;
+  const float* r = a.ry + (int64_t)b * 4 * H + c;
+  const float iraw = g[0] + r[0] + a.bias[c];
+  const float fraw = g[H] + r[H] + a.bias[H + c];
+  const float zraw = g[2 * H] + r[2 * H] + a.bias[2 * H + c];
+  const float oraw = g[3 * H] + r[3 * H] + a.bias[3 * H + c];
+  const int64_t BH = (int64_t)a.B * H;
+  float* st = a.state + (int64_t)b * H + c;
+  const float cs = st[BH], ns = st[2 * BH], ms = st[3 * BH];
+  const float logfplusm = ms + log_sigmoid(fraw);
+  const float mnew = (ns == 0.f) ? iraw : fmaxf(iraw, logfplusm);
+  const float ogate = sigmoid_f(oraw);
+  const float igate = fminf(expf(iraw - mnew), 1.f);
+  const float fgate = fminf(expf(logfplusm - mnew), 1.f);
+  const float cnew = fgate * cs + igate * tanhf(zraw);
+  const float nnew = fgate * ns + igate;
+  const float ynew = ogate * cnew / nnew;
+  st[0] = ynew;
+  st[BH] = cnew;
+  st[2 * BH] = nnew;
+  st[3 * BH] = mnew;
+  a.yout[row * H + c] = ynew;
+}
+
+__global__ __launch_bounds__(256) void gelu_gate_kernel(const float* p, float* out, int64_t rows, int F) {
+  const int nv = F >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= rows * nv) return;
+  const int64_t r = gid / nv;
+  const int c = (int)(gid - r * nv) << 2;
+  const float4 g = *reinterpret_cast<const float4*>(p + r * 2 * F + c);
+  const float4 u = *reinterpret_cast<const float4*>(p + r * 2 * F + F + c);
+  float4 o;
+  o.x = gelu_f(g.x) * u.x;
+  o.y = gelu_f(g.y) * u.y;
+  o.z = gelu_f(g.z) * u.z;
+  o.w = gelu_f(g.w) * u.w;
+  *reinterpret_cast<float4*>(out + r * F + c) = o;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <int T>
+static void launch_pre_t(const MlstmPreArgs& a, hipStream_t s) {
+  dim3 grid(a.B), block(kPreThreads);
+  switch (a.NH) {
+    case 1: hipLaunchKernelGGL((mlstm_pre_kernel<T, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((mlstm_pre_kernel<T, 2>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((mlstm_pre_kernel<T, 4>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((mlstm_pre_kernel<T, 8>), grid, block, 0, s, a); break;
+    default: throw Error("lram: mLSTM num_heads must be 1, 2, 4 or 8");
+  }
+}
+
+void launch_mlstm_pre(const MlstmPreArgs& a, hipStream_t stream) {
+  LRAM_REQUIRE(a.K >= 1 && a.K <= 4, "mLSTM conv1d_kernel_size must be in 1..4");
+  LRAM_REQUIRE(a.inner % (4 * a.NH) == 0, "mLSTM inner dim must be a multiple of 4*num_heads");
+  LRAM_REQUIRE(a.inner <= 4 * kPreThreads * kMaxGroups, "mLSTM inner dim too large");
+  LRAM_REQUIRE(a.K == 4, "conv weights are packed with 4 taps per channel");
+  switch (a.T) {
+    case 1: launch_pre_t<1>(a, stream); break;
+    case 2: launch_pre_t<2>(a, stream); break;
+    case 3: launch_pre_t<3>(a, stream); break;
+    case 4: launch_pre_t<4>(a, stream); break;
+    default: throw Error("lram: tokens per step must be in 1..4");
+  }
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+template <int T, int LPR>
+static void launch_cell_tl(const MlstmCellArgs& a, hipStream_t s) {
+  constexpr int CW = 4 * LPR, RP = kCellThreads / LPR;
+  dim3 grid(a.DH / CW, a.NH, a.B), block(kCellThreads);
+  const size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW);
+  hipLaunchKernelGGL((mlstm_cell_kernel<T, LPR>), grid, block, shmem, s, a);
+}
+
+template <int T>
+static void launch_cell_t(const MlstmCellArgs& a, hipStream_t s) {
+  if (a.DH % 256 == 0)
+    launch_cell_tl<T, 64>(a, s);
+  else if (a.DH % 128 == 0)
+    launch_cell_tl<T, 32>(a, s);
+  else if (a.DH % 64 == 0)
+    launch_cell_tl<T, 16>(a, s);
+  else
+    throw Error("lram: mLSTM head dim must be a multiple of 64");
+}
+
+void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream) {
+  switch (a.T) {
+    case 1: launch_cell_t<1>(a, stream); break;
+    case 2: launch_cell_t<2>(a, stream); break;
+    case 3: launch_cell_t<3>(a, stream); break;
+    case 4: launch_cell_t<4>(a, stream); break;
+    default: throw Error("lram: tokens per step must be in 1..4");
+  }
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_group_norm(const GroupNormArgs& a, hipStream_t stream) {
+  LRAM_REQUIRE(a.DH % 4 == 0 && a.DH <= 4 * 64 * kGnMaxV, "group norm: head dim must be a multiple of 4 and <= 768");
+  hipLaunchKernelGGL(group_norm_kernel, dim3(a.rows, a.NH), dim3(64), 0, stream, a);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_slstm_conv(const SlstmConvArgs& a, hipStream_t stream) {
+  LRAM_REQUIRE(a.K == 4 && a.D % 4 == 0, "sLSTM conv: K must be 4 and D a multiple of 4");
+  const int64_t n = (int64_t)a.B * (a.D >> 2);
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  switch (a.T) {
+    case 1: hipLaunchKernelGGL(slstm_conv_kernel<1>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(slstm_conv_kernel<2>, grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(slstm_conv_kernel<3>, grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(slstm_conv_kernel<4>, grid, block, 0, stream, a); break;
+    default: throw Error("lram: tokens per step must be in 1..4");
+  }
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_slstm_pointwise(const SlstmPointwiseArgs& a, hipStream_t stream) {
+  const int64_t n = (int64_t)a.B * a.H;
+  hipLaunchKernelGGL(slstm_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_gelu_gate(const float* p, float* out, int rows, int F, hipStream_t stream) {
+  LRAM_REQUIRE(F % 4 == 0, "gelu gate: F must be a multiple of 4");
+  const int64_t n = (int64_t)rows * (F >> 2);
+  hipLaunchKernelGGL(gelu_gate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p, out,
+                     (int64_t)rows, F);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace lram

@@ -1,0 +1,184 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): discrete actions bit-exact, continuous actions within 1e-4; hidden
+states / recurrent state within fp32 tolerance stated per test."""
+import pytest
+import torch
+
+from lram_amd import init_state_dict, preset
+from oracle import dt_ref
+from tests.helpers import assert_actions_match, make_inputs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(spec, sd, B):
+    from lram_amd.engine import Engine
+    return Engine(spec, sd, B, device="cuda:0")
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (96, 2192, 512), (300, 80, 1536), (1000, 1408, 512),
+                                   (37, 204, 204), (4096, 512, 1024), (5, 8, 4)])
+def test_gemm_f32_matches_fp64(hip_lib, m, n, k):
+    from lram_amd.engine import gemm_f32
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g)
+    bias = torch.randn(n, generator=g)
+    ref = (a.double() @ w.double().t() + bias.double())
+    out = gemm_f32(a.cuda(), w.cuda(), bias.cuda())
+    torch.cuda.synchronize()
+    # fp32 fma chain over k: error bound ~ k * eps * |a||w|
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-6 * k ** 0.5 * 16, (m, n, k, err)
+    # accumulate (residual) form, asymmetric check of row/col mapping: C += A W^T
+    base = torch.randn(m, n, generator=g)
+    out2 = gemm_f32(a.cuda(), w.cuda(), None, out=base.clone().cuda(), accumulate=True)
+    torch.cuda.synchronize()
+    ref2 = base.double() + a.double() @ w.double().t()
+    assert (out2.cpu().double() - ref2).abs().max().item() < 2e-6 * k ** 0.5 * 16
+
+
+def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=2e-4, state_tol=2e-4, spec=None):
+    spec = preset(name) if spec is None else spec
+    sd = init_state_dict(spec, seed=seed)
+    eng = _engine(spec, sd, B)
+    if graph:
+        eng.set_graph_mode(True)
+    ora = dt_ref.OraclePolicy(spec, sd)
+    ties = 0
+    # fixed device buffers so that graph mode sees stable pointers
+    d_obs = torch.empty(B, spec.state_dim, device="cuda:0")
+    d_rtg = torch.empty(B, device="cuda:0")
+    d_rew = torch.empty(B, device="cuda:0")
+    d_mask = torch.empty(B, dtype=torch.uint8, device="cuda:0")
+    for t, (obs, rtg, rew, mask) in enumerate(make_inputs(spec, B, steps, seed=1234 + seed)):
+        d_obs.copy_(obs), d_rtg.copy_(rtg), d_rew.copy_(rew), d_mask.copy_(mask)
+        a_gpu, tok = eng.step(d_obs, d_rtg, d_rew, d_mask, discrete=discrete)
+        a_ref, dbg = ora.step(obs, rtg, rew, mask, discrete=discrete, return_debug=True)
+        torch.cuda.synchronize()
+        tokens, hidden, logits = eng.taps()
+        assert rel_err(tokens, dbg["tokens"]) < 1e-5, f"{name} step {t}: embed tokens"
+        assert rel_err(hidden, dbg["hidden"]) < hidden_tol, f"{name} step {t}: hidden {rel_err(hidden, dbg['hidden'])}"
+        a_cmp = a_gpu[:, :1] if discrete else a_gpu
+        ties += assert_actions_match(a_cmp, a_ref, dbg["logits"], spec, discrete, what=f"{name} step {t}")
+    # final recurrent state against the oracle's, in the reference's past_key_values layout
+    pkv = eng.export_past_key_values()
+    if spec.backbone == "mamba":
+        for i in range(spec.n_blocks):
+            assert rel_err(pkv[i][0], ora.state[i][0]) < state_tol
+            assert rel_err(pkv[i][1], ora.state[i][1]) < state_tol
+    else:
+        for i in range(spec.n_blocks):
+            blk, ref = pkv[f"block_{i}"], ora.state[f"block_{i}"]
+            assert rel_err(blk["conv_state"][0], ref["conv_state"][0]) < state_tol
+            if "mlstm_state" in blk:
+                for j in range(3):
+                    assert rel_err(blk["mlstm_state"][j], ref["mlstm_state"][j]) < state_tol, (i, j)
+            else:
+                assert rel_err(blk["slstm_state"], ref["slstm_state"]) < state_tol, i
+    eng.close()
+    return ties
+
+
+def test_xlstm_tiny_trajectory(hip_lib):
+    assert _run_parity("xlstm_tiny", B=8, steps=12) == 0
+
+
+def test_xlstm_c1_b32(hip_lib):
+    # BASELINE config 1: xLSTM[1:0] 2-layer d_model=128, batch 32
+    assert _run_parity("xlstm_c1", B=32, steps=16) == 0
+
+
+def test_xlstm_16m_shapes(hip_lib):
+    # BASELINE config 2 shapes (xLSTM[7:1] 16M) at an oracle-sized batch
+    assert _run_parity("xlstm_16m", B=12, steps=6) == 0
+
+
+def test_xlstm_206m_shapes_two_blocks(hip_lib):
+    # config 4/5 geometry (D=1280, inner 2560, DH 640, sLSTM head dim 320) cut to 3 blocks to stay small
+    from lram_amd.config import ModelSpec
+    spec = ModelSpec(backbone="xlstm", d_model=1280, n_blocks=3, slstm_at=[1])
+    assert _run_parity("xlstm_206m_cut", B=3, steps=4, spec=spec) == 0
+
+
+def test_mamba_tiny_trajectory(hip_lib):
+    assert _run_parity("mamba_tiny", B=8, steps=12) == 0
+
+
+def test_mamba_48m_shapes(hip_lib):
+    assert _run_parity("mamba_48m", B=6, steps=4) == 0
+
+
+def test_discrete_head_bit_exact(hip_lib):
+    assert _run_parity("xlstm_tiny", B=16, steps=8, seed=3, discrete=True) == 0
+
+
+def test_graph_replay_matches(hip_lib):
+    assert _run_parity("xlstm_tiny", B=8, steps=10, seed=5, graph=True) == 0
+
+
+def test_rms_norm_and_ln_bias_variants(hip_lib):
+    from lram_amd.config import ModelSpec
+    for kw in (dict(rms_norm=True), dict(ln_bias=True)):
+        spec = ModelSpec(backbone="xlstm", d_model=128, n_blocks=3, slstm_at=[2], state_dim=20, act_dim=4, **kw)
+        assert _run_parity("variant", B=4, steps=5, spec=spec) == 0
+
+
+def test_encoder_step_operator(hip_lib):
+    """`self.encoder(inputs_embeds, use_cache=True)` plug point, T = 1..4 tokens per call."""
+    from oracle import xlstm_ref
+    spec = preset("xlstm_tiny")
+    sd = init_state_dict(spec, seed=7)
+    B = 5
+    eng = _engine(spec, sd, B)
+    state = None
+    g = torch.Generator().manual_seed(9)
+    for T in (3, 1, 4, 2):
+        x = torch.randn(B, T, spec.d_model, generator=g)
+        ref, state = xlstm_ref.encoder_forward_cached(spec, {k: v for k, v in sd.items()}, x, state)
+        out = eng.encoder_step(x.cuda())
+        torch.cuda.synchronize()
+        assert rel_err(out, ref) < 2e-4, T
+    eng.close()
+
+
+def test_state_import_export_roundtrip_and_reset(hip_lib):
+    spec = preset("xlstm_tiny")
+    sd = init_state_dict(spec, seed=11)
+    B = 4
+    eng = _engine(spec, sd, B)
+    seq = make_inputs(spec, B, 3)
+    for obs, rtg, rew, mask in seq:
+        eng.step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+    pkv = eng.export_past_key_values()
+    a1, _ = eng.step(seq[0][0].cuda(), seq[0][1].cuda(), seq[0][2].cuda(), None)
+    a1 = a1.clone()
+    eng.import_past_key_values(pkv)
+    a2, _ = eng.step(seq[0][0].cuda(), seq[0][1].cuda(), seq[0][2].cuda(), None)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2)
+    # masked reset == fresh engine for those envs
+    m = torch.tensor([1, 0, 1, 0], dtype=torch.uint8).cuda()
+    eng.reset(m)
+    st = eng.export_past_key_values()
+    for blk in st.values():
+        for key, val in blk.items():
+            for t in (val if isinstance(val, tuple) else (val,)):
+                rows = t[:, [0, 2]] if key == "slstm_state" else t[[0, 2]]
+                assert float(rows.abs().max()) == 0.0
+    eng.close()
+
+
+def test_errors_are_loud(hip_lib):
+    from lram_amd.engine import Engine, LramError
+    spec = preset("xlstm_tiny")
+    sd = init_state_dict(spec, seed=0)
+    bad = dict(sd)
+    del bad["encoder.layers.blocks.0.xlstm.proj_up.weight"]
+    with pytest.raises(KeyError):
+        Engine(spec, bad, 2, device="cuda:0")
+    eng = Engine(spec, sd, 2, device="cuda:0")
+    with pytest.raises(ValueError):
+        eng.step(torch.zeros(3, spec.state_dim).cuda(), torch.zeros(2).cuda(), torch.zeros(2).cuda())
+    eng.close()
