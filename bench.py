@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec (action-inference) of the recurrent rollout hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic env inputs: B env slots per GPU each
+advance one timestep (embed (s, rtg, r) -> 3 recurrent token steps through the block stack -> action head
+-> argmax -> de-tokenise), plus, for N > 1, the all-gather of the action tensor (RCCL).  Inputs (observations,
+returns-to-go, reset masks for every step) are resident in HBM before the timed region starts.
+Workload = BASELINE.json's metric configuration: xLSTM[7:1] 16M, batch 4096 env slots per GPU (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = mLSTM
+cell update, HIP-event timed on its own stream inside the timed region) and `cpu_baseline` (the CPU oracle
+timed on the host cores on a bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s float4 copy measured)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cell_kernel_algorithmic_bytes(spec, B, T):
+    """Algorithmic bytes of ONE mLSTM cell-update launch (one layer, B envs, T tokens): matrix memory C read
+    once + written once, q/k/v vectors read, h written, gate scalars read.  (DESIGN.md 'Kernels')"""
+    per_env = 2 * spec.n_heads * spec.head_dim ** 2 * 4 + T * 4 * spec.inner * 4 + T * spec.n_heads * 16
+    return per_env * B
+
+
+def ssm_kernel_algorithmic_bytes(spec, B, T):
+    per_env = 2 * spec.d_inner * spec.d_state * 4 + T * (4 * spec.d_inner + 2 * spec.d_state) * 4
+    return per_env * B
+
+
+def cpu_baseline(spec, sd, seconds_budget=20.0):
+    """The oracle (oracle/dt_ref.py, the parity checker) timed on the host cores: `kind: port`."""
+    from oracle.dt_ref import OraclePolicy
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    B = 64
+    g = torch.Generator().manual_seed(1234)
+    obs = torch.rand(B, spec.state_dim, generator=g) * 2 - 1
+    rtg = torch.full((B,), 4.5)
+    rew = torch.zeros(B)
+
+    def timed_steps(nthreads, max_s, max_n):
+        torch.set_num_threads(nthreads)
+        ora = OraclePolicy(spec, sd)
+        ora.step(obs, rtg, rew)  # warm-up (allocations, thread pool)
+        t0, n = time.time(), 0
+        while n < max_n and (n == 0 or time.time() - t0 < max_s):
+            ora.step(obs, rtg, rew)
+            n += 1
+        return n, time.time() - t0
+
+    # PyTorch-eager on many small ops does not scale to every core of a big host: calibrate the thread
+    # count on one timestep each (smallest first, stop when it gets slower), then time with the best.
+    best_thr, best_t = None, None
+    for thr in sorted({min(avail, c) for c in (8, 32, 128)}):
+        n, w = timed_steps(thr, 0.0, 1)
+        if best_t is None or w < best_t:
+            best_thr, best_t = thr, w
+        elif w > 1.5 * best_t:
+            break
+    n, wall = timed_steps(best_thr, seconds_budget, 64)
+    return {"value": B * n / wall, "unit": "env-steps/s", "cores": best_thr, "kind": "port",
+            "sample": f"CPU oracle (PyTorch-eager fp32 restatement of the same path), same model and weights, "
+                      f"B={B} envs x {n} timesteps after 1 warm-up, {wall:.1f} s wall, {best_thr} torch threads "
+                      f"(fastest of a 8/32/128 calibration; host exposes {avail} cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=4096, help="env slots per GPU")
+    ap.add_argument("--config", default="xlstm_16m", help="preset name (lram_amd.config.preset)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from lram_amd import build, dist as ldist, init_state_dict, preset
+    from lram_amd.engine import Engine, stream_copy
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the engine has no CPU fallback")
+    rank, world, local_rank = ldist.init_distributed()
+    if world != args.gpus:
+        log(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if rank == 0:
+        build.build(force=False, verbose=False)
+    ldist.barrier()
+
+    spec = preset(args.config)
+    sd = init_state_dict(spec, seed=0)
+    B, T, K, W = args.batch, spec.tokens_per_step, args.steps, args.warmup
+    eng = Engine(spec, sd, B, device=dev)
+    if args.graph:
+        eng.set_graph_mode(True)
+
+    # ---- synthetic inputs, all resident in HBM before timing (DummyEnv-style) ----------
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    n_ring = 8
+    obs_ring = torch.zeros(n_ring, B, spec.state_dim, device=dev)
+    from lram_amd.rollout import CHEETAH_RUN_OBS_INDEX
+    idx = torch.tensor([i for i in CHEETAH_RUN_OBS_INDEX if i < spec.state_dim], device=dev)
+    obs_ring[:, :, idx] = torch.rand(n_ring, B, idx.numel(), generator=g, device=dev) * 2 - 1
+    ep_len, rtg0, scale = 1000, 451.274 / 100.0, 100.0  # cheetah-run target / reward_scale
+    phase = torch.arange(B, device=dev) % ep_len
+    steps_total = K + W
+    tt = torch.arange(steps_total, device=dev).view(-1, 1)
+    age = (phase.view(1, -1) + tt) % ep_len                       # steps since that env's last reset
+    masks = (age == 0).to(torch.uint8).contiguous()
+    masks[0] = 1                                                  # every env starts an episode
+    rtgs = (rtg0 - age.float() * (1.0 / scale)).contiguous()     # env reward 1 per step
+    reward_tok = torch.zeros(B, device=dev)                       # reward token is 0 in the reference loop (Q3)
+    torch.cuda.synchronize()
+
+    def one_step(t):
+        a, _ = eng.step(obs_ring[t % n_ring], rtgs[t], reward_tok, masks[t])
+        if world > 1:
+            a = ldist.all_gather_actions(a)
+        return a
+
+    for t in range(W):
+        one_step(t)
+    timing = not args.no_kernel_timing and not args.graph
+    ldist.barrier()
+    torch.cuda.synchronize()
+    if timing:
+        eng.profile_begin()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        last = one_step(t)
+    torch.cuda.synchronize()
+    ldist.barrier()
+    wall = time.perf_counter() - t0
+    kern_ms, kern_n = eng.profile_end() if timing else (0.0, 0)
+    wall = ldist.max_over_ranks(wall, dev)
+
+    total_env_steps = B * world * K
+    value = total_env_steps / wall
+
+    # ---- roofline of the dominant kernel -----------------------------------------------------------
+    if spec.backbone == "xlstm":
+        kname, abytes = "mlstm_cell_kernel", cell_kernel_algorithmic_bytes(spec, B, T)
+    else:
+        kname, abytes = "mamba_ssm_kernel", ssm_kernel_algorithmic_bytes(spec, B, T)
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": None, "traffic": None, "algorithmic_bytes_per_launch": abytes}
+    if kern_n > 0:
+        avg_ms = kern_ms / kern_n
+        ach = abytes / (avg_ms * 1e-3) / 1e9
+        roofline.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, avg_launch_ms=avg_ms, launches_timed=kern_n,
+                        kernel_share_of_step=kern_ms / (wall * 1e3))
+    pmc_file = os.path.join(ROOT, "profiles", "r01_cell_kernel_hbm_traffic.json")
+    if os.path.exists(pmc_file):  # PMC bytes per launch come from a separate rocprofv3 --pmc pass (profiles/)
+        try:
+            with open(pmc_file) as fh:
+                pm = json.load(fh)
+            if pm.get("config") == args.config and pm.get("batch") == B:
+                roofline["traffic"] = pm.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    # STREAM-like copy on this box, for context (not the roofline peak)
+    n_copy = 256 * 1024 * 1024
+    src = torch.empty(n_copy, device=dev)
+    dst = torch.empty(n_copy, device=dev)
+    stream_copy(dst, src)
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(5):
+        stream_copy(dst, src)
+    torch.cuda.synchronize()
+    copy_gbps = 5 * 2 * n_copy * 4 / (time.perf_counter() - c0) / 1e9
+    del src, dst
+
+    out = {
+        "metric": "env-steps/sec (action-inference)", "value": value, "unit": "env-steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: xLSTM[7:1] 16M rollout, {B} env slots per GPU, 3 tokens/timestep, "
+                               "cheetah-run-shaped obs (17 of 204 dims), continuous 8x274 head"
+                   if args.config == "xlstm_16m" else f"{args.config}, {B} env slots per GPU",
+                   "batch_per_gpu": B, "global_batch": B * world, "tokens_per_step": T,
+                   "state_bytes_per_env": spec.state_bytes_per_env(), "parallelism": f"env-shard x{world}",
+                   "graph": bool(args.graph)},
+        "roofline": roofline,
+        "hbm_copy_measured_GBps": copy_gbps,
+        "algorithmic_bytes_per_env_step": 2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim,
+    }
+    out["whole_step_algorithmic_GBps"] = out["algorithmic_bytes_per_env_step"] * value / world / 1e9
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        eng.close()
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(spec, sd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

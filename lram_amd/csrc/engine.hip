@@ -92,6 +92,7 @@ struct lram_engine {
   GraphKey graph_key{};
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  hipStream_t capture_stream = nullptr;  // capture needs a non-default stream; replay runs on the caller's
   // profiling of the dominant recurrent kernel
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -99,6 +100,7 @@ struct lram_engine {
 
   ~lram_engine() {
     drop_graph();
+    if (capture_stream) (void)hipStreamDestroy(capture_stream);
     for (auto& e : prof_events) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
@@ -620,17 +622,19 @@ int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding
       key.tok = dev_tokens, key.emb = obs_is_embedding, key.discrete = discrete, key.B = e->B, key.stream = s;
       if (!(e->graph_valid && key == e->graph_key)) {
         e->drop_graph();
-        LRAM_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        if (!e->capture_stream) LRAM_HIP_CHECK(hipStreamCreateWithFlags(&e->capture_stream, hipStreamNonBlocking));
+        hipStream_t cs = e->capture_stream;
+        LRAM_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         try {
           step_launches(e, dev_obs, obs_is_embedding, dev_rtg, dev_reward, dev_reset_mask, discrete, dev_actions,
-                        dev_tokens, s);
+                        dev_tokens, cs);
         } catch (...) {
           hipGraph_t g = nullptr;
-          (void)hipStreamEndCapture(s, &g);
+          (void)hipStreamEndCapture(cs, &g);
           if (g) (void)hipGraphDestroy(g);
           throw;
         }
-        LRAM_HIP_CHECK(hipStreamEndCapture(s, &e->graph));
+        LRAM_HIP_CHECK(hipStreamEndCapture(cs, &e->graph));
         LRAM_HIP_CHECK(hipGraphInstantiate(&e->graph_exec, e->graph, nullptr, nullptr, 0));
         e->graph_key = key;
         e->graph_valid = true;
