@@ -1,0 +1,131 @@
+"""Internal-consistency checks of the oracle (the reference has no tests for the xlstm / mamba_ssm boundary,
+SURVEY.md 4): step<->parallel, batched<->single env, first-step rule variants, reset semantics, and the
+independent pure-torch Mamba implementation that ships with `transformers`."""
+import pytest
+import torch
+
+from lram_amd import init_state_dict, preset
+from lram_amd.config import ModelSpec
+from oracle import dt_ref, mamba_ref, xlstm_ref
+from tests.helpers import make_inputs, rel_err
+
+
+def test_mlstm_step_equals_parallel_form():
+    spec = preset("xlstm_c1")
+    sd = init_state_dict(spec, seed=2)
+    x = torch.randn(3, 12, spec.d_model, generator=torch.Generator().manual_seed(0))
+    hs, _ = xlstm_ref.encoder_forward_cached(spec, sd, x, None)
+    hp = xlstm_ref.stack_forward_parallel(spec, sd, x)
+    # the two forms differ only through eps * exp(m) in the denominator (see oracle/xlstm_ref.py)
+    assert rel_err(hs, hp) < 5e-5
+
+
+@pytest.mark.parametrize("name", ["xlstm_tiny", "mamba_tiny"])
+def test_batched_equals_single_env(name):
+    """Guards cross-env leakage and the sLSTM `n == 0` rule: B envs at once == each env alone."""
+    spec = preset(name)
+    sd = init_state_dict(spec, seed=3)
+    B, steps = 5, 6
+    seq = make_inputs(spec, B, steps, seed=77, reset_prob=0.3)
+    full = dt_ref.OraclePolicy(spec, sd)
+    singles = [dt_ref.OraclePolicy(spec, sd) for _ in range(B)]
+    for obs, rtg, rew, mask in seq:
+        a = full.step(obs, rtg, rew, mask)
+        for b in range(B):
+            ab = singles[b].step(obs[b:b + 1], rtg[b:b + 1], rew[b:b + 1], mask[b:b + 1])
+            assert float((a[b] - ab[0]).abs().max()) <= 1e-4, (name, b)
+
+
+def test_slstm_first_step_rule_variants_coincide():
+    """per-env all(n == 0) (CPU package path at batch 1) == per-element n == 0 (CUDA kernel) on a trajectory:
+    n is zero everywhere before an env's first step and strictly positive afterwards."""
+    torch.manual_seed(0)
+    B, H = 3, 32
+    states = torch.zeros(4, B, H)
+    for t in range(6):
+        Wx, Ry, b = torch.randn(B, 4, H) * 2, torch.randn(B, 4, H), torch.randn(4, H)
+        new = xlstm_ref.slstm_pointwise(Wx, Ry, b, states)
+        raw = Wx + Ry + b
+        lfm = states[3] + torch.nn.functional.logsigmoid(raw[:, 1])
+        m_elem = torch.where(states[2] == 0.0, raw[:, 0], torch.max(raw[:, 0], lfm))
+        assert torch.equal(new[3], m_elem)
+        assert bool((new[2] > 0).all())
+        states = new
+        if t == 2:  # reset env 1 mid-trajectory
+            states = states.clone()
+            states[:, 1] = 0
+
+
+def test_reset_mask_equals_fresh_policy():
+    spec = preset("xlstm_tiny")
+    sd = init_state_dict(spec, seed=4)
+    B = 3
+    seq = make_inputs(spec, B, 4, seed=5, reset_prob=0.0)
+    pol = dt_ref.OraclePolicy(spec, sd)
+    for obs, rtg, rew, _ in seq:
+        pol.step(obs, rtg, rew, None)
+    obs, rtg, rew, _ = seq[0]
+    a = pol.step(obs, rtg, rew, torch.tensor([0, 1, 0], dtype=torch.uint8))
+    fresh = dt_ref.OraclePolicy(spec, sd).step(obs, rtg, rew, None)
+    assert torch.equal(a[1], fresh[1]) and not torch.equal(a[0], fresh[0])
+
+
+def test_state_layout_matches_reference_past_key_values():
+    spec = preset("xlstm_16m")
+    st = xlstm_ref.zero_state(spec, 2)
+    assert st["block_0"]["mlstm_state"][0].shape == (2, 4, 256, 256)
+    assert st["block_0"]["mlstm_state"][1].shape == (2, 4, 256, 1)
+    assert st["block_0"]["mlstm_state"][2].shape == (2, 4, 1, 1)
+    assert st["block_0"]["conv_state"][0].shape == (2, 4, 1024)
+    assert st["block_1"]["slstm_state"].shape == (4, 2, 512)
+    assert st["block_1"]["conv_state"][0].shape == (2, 4, 512)
+    ms = mamba_ref.zero_state(preset("mamba_48m"), 2)
+    assert ms[0][0].shape == (2, 1536, 4) and ms[0][1].shape == (2, 1536, 16)
+
+
+def test_mamba_step_matches_transformers_mixer():
+    """T sequential oracle steps == the full-sequence scan of transformers' pure-torch MambaMixer."""
+    tm = pytest.importorskip("transformers.models.mamba.modeling_mamba")
+    from transformers import MambaConfig
+    D, N, K, R, T, B = 64, 16, 4, 4, 7, 3
+    cfg = MambaConfig(hidden_size=D, state_size=N, conv_kernel=K, expand=2, time_step_rank=R, num_hidden_layers=1,
+                      use_bias=False, use_conv_bias=True, vocab_size=8)
+    try:
+        mixer = tm.MambaMixer(cfg, layer_idx=0).eval()
+    except Exception as exc:  # API drift in transformers
+        pytest.skip(f"cannot construct MambaMixer: {exc}")
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for p in mixer.parameters():
+            if p.dim() >= 2 and p is not mixer.A_log:
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / p.shape[-1] ** 0.5))
+        mixer.A_log.add_(torch.randn(mixer.A_log.shape, generator=g) * 0.1)
+    x = torch.randn(B, T, D, generator=g)
+    with torch.no_grad():
+        try:
+            y_hf = mixer.slow_forward(x) if hasattr(mixer, "slow_forward") else mixer(x)
+        except Exception as exc:
+            pytest.skip(f"transformers MambaMixer forward not runnable here: {exc}")
+    sd = {"m." + k: v.detach() for k, v in mixer.state_dict().items()}
+    conv = torch.zeros(B, 2 * D, K)
+    ssm = torch.zeros(B, 2 * D, N)
+    outs = []
+    for t in range(T):
+        o, conv, ssm = mamba_ref.mamba_step(sd, "m.", x[:, t], conv, ssm, R, N)
+        outs.append(o)
+    assert rel_err(torch.stack(outs, 1), y_hf) < 1e-5
+
+
+def test_impala_cnn_shapes_and_image_path():
+    spec = ModelSpec(backbone="xlstm", d_model=128, n_blocks=1, state_dim=20, act_dim=4)
+    sd = init_state_dict(spec, seed=6, with_image_encoder=True)
+    assert sd["embed_image.linear.0.weight"].shape == (128, 2048)  # 32 ch x 8 x 8 for 64x64 input
+    pol = dt_ref.OraclePolicy(spec, sd)
+    img = torch.randint(0, 256, (2, 3, 64, 64), dtype=torch.uint8)
+    a = pol.step(img, torch.ones(2), torch.zeros(2), discrete=True)
+    assert a.shape == (2, 1) and a.dtype == torch.int64 and int(a.max()) < spec.n_discrete
+    # the product's torch image encoder computes the same embedding as the oracle's functional restatement
+    from lram_amd.image_encoder import ImageEncoder
+    enc = ImageEncoder.from_state_dict(sd, spec.image_shape, spec.d_model)
+    ref = dt_ref.impala_cnn(sd, "embed_image.", img.float() / 255.0)
+    assert rel_err(enc(img), ref) < 1e-6
