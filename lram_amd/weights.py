@@ -124,26 +124,32 @@ def init_state_dict(spec: ModelSpec, seed: int = 0, scheme: str = "exercise", wi
         weights zero with forget bias linspace(3, 6), Mamba A_log = log(1..N), D = 1, dt bias = softplus^-1
         of log-uniform [1e-3, 1e-1]) -- the distribution a freshly constructed reference model has.
     """
-    g = torch.Generator().manual_seed(seed)
+    # Portable generator: PCG64 uniform floats are exact integer->float conversions, so the same seed gives
+    # bit-identical weights on every host (torch.randn / exp / log go through SIMD-dependent libm paths).
+    rng = np.random.Generator(np.random.PCG64(seed))
     lay = reference_layout(spec, with_image_encoder)
     sd: Dict[str, torch.Tensor] = {}
 
     def randn(shape, std):
-        return torch.randn(shape, generator=g, dtype=torch.float32) * std
+        """zero-mean uniform with standard deviation `std`"""
+        u = rng.random(tuple(shape), dtype=np.float32) * np.float32(2.0) - np.float32(1.0)
+        return torch.from_numpy(u * np.float32(std * math.sqrt(3.0)))
+
+    def f64(arr):
+        return torch.from_numpy(np.asarray(arr, dtype=np.float64).astype(np.float32))
 
     for name, shape in lay.items():
         fan_in = shape[-1] if len(shape) >= 2 else 1
         if name.endswith("A_log"):
-            A = torch.arange(1, shape[1] + 1, dtype=torch.float32).repeat(shape[0], 1)
-            t = torch.log(A)
+            t = f64(np.log(np.arange(1, shape[1] + 1, dtype=np.float64))).repeat(shape[0], 1)
             if scheme == "exercise":
                 t = t + randn(shape, 0.1)
         elif name.endswith("mixer.D"):
             t = torch.ones(shape) + (randn(shape, 0.1) if scheme == "exercise" else 0)
         elif name.endswith("dt_proj.bias"):
-            u = torch.rand(shape, generator=g)
-            dt = torch.exp(u * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3)).clamp(min=1e-4)
-            t = dt + torch.log(-torch.expm1(-dt))
+            u = rng.random(tuple(shape), dtype=np.float32).astype(np.float64)
+            dt = np.maximum(np.exp(u * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3)), 1e-4)
+            t = f64(dt + np.log(-np.expm1(-dt)))
         elif name.endswith("learnable_skip"):
             t = torch.ones(shape) + (randn(shape, 0.1) if scheme == "exercise" else 0)
         elif ("norm" in name and name.endswith(".weight") and "embed_ln" not in name and spec.backbone == "xlstm"
@@ -160,7 +166,7 @@ def init_state_dict(spec: ModelSpec, seed: int = 0, scheme: str = "exercise", wi
             blk = int(name.split("blocks.")[1].split(".")[0])
             ratio = blk / (spec.n_blocks - 1) if spec.n_blocks > 1 else 0.0
             # [3P] powerlaw_blockdependent forget-gate bias (slot 1 = "f")
-            t[:, 1, :] = -(-5.0 + 12.0 * (torch.arange(dh) / max(dh - 1, 1)) ** (0.3 + 1.3 * ratio))
+            t[:, 1, :] = f64(-(-5.0 + 12.0 * (np.arange(dh, dtype=np.float64) / max(dh - 1, 1)) ** (0.3 + 1.3 * ratio)))
             if scheme == "exercise":
                 t = t * 0.25 + randn(shape, 0.2)
         elif name.endswith("mlstm_cell.fgate.bias"):

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 --pmc counter_collection CSVs to per-launch HBM bytes of the recurrent kernel.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE reports half the
+bytes of a wide (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE is exact for 16 B/lane stores.
+The library's stream_copy_kernel (1 GiB read + 1 GiB written, same access width) runs in the same process
+and calibrates both factors."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out_dir, tag, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+KERNELS = {"cell": ("mlstm_cell_kernel", "mamba_ssm_kernel"), "copy": ("stream_copy_kernel",)}
+res = {}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob(os.path.join(out_dir, counter, "**", "*counter_collection.csv"), recursive=True)
+    vals = {"cell": [], "copy": []}
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            for key, names in KERNELS.items():
+                if any(n in row["Kernel_Name"] for n in names):
+                    vals[key].append(float(row["Counter_Value"]))
+    # median = steady-state launch (the first timestep resets every env and skips the C read)
+    res[counter] = {k: (sorted(v)[len(v) // 2] if v else None, len(v)) for k, v in vals.items()}
+print(res)
+GiB = 1024 ** 3
+fetch_cell, nfc = res["FETCH_SIZE"]["cell"]
+write_cell, nwc = res["WRITE_SIZE"]["cell"]
+fetch_copy, _ = res["FETCH_SIZE"]["copy"]
+write_copy, _ = res["WRITE_SIZE"]["copy"]
+summary = {"config": tag, "batch": batch, "raw_KiB_median_per_launch": {k: {kk: vv[0] for kk, vv in v.items()} for k, v in res.items()},
+           "launches": {"fetch": nfc, "write": nwc}}
+if fetch_cell is not None and write_cell is not None:
+    rd = fetch_cell * 1024 * 2.0
+    wr = write_cell * 1024
+    summary.update(read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
+                   corrections="FETCH_SIZE KiB x1024 x2 (gfx950 wide-read undercount), WRITE_SIZE KiB x1024")
+    if fetch_copy and write_copy:
+        summary["calibration_stream_copy"] = {"fetch_reported_over_true": fetch_copy * 1024 / GiB,
+                                              "write_reported_over_true": write_copy * 1024 / GiB}
+os.makedirs("profiles", exist_ok=True)
+path = f"profiles/r01_cell_kernel_hbm_traffic{'' if tag == 'xlstm_16m' else '_' + tag}.json"
+json.dump(summary, open(path, "w"), indent=1)
+print(json.dumps(summary, indent=1))

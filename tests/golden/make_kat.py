@@ -30,11 +30,17 @@ KATS = {"xlstm_tiny": dict(B=4, steps=8, seed=21, discrete=False),
 
 
 def weights_digest(sd):
+    """sha256 over names and bytes.  init_state_dict draws from PCG64 with exact integer->float arithmetic, so
+    the digest is host-independent (transcendental inits are computed in float64 and rounded once)."""
     h = hashlib.sha256()
     for k in sorted(sd):
         h.update(k.encode())
         h.update(sd[k].contiguous().numpy().tobytes())
     return h.hexdigest()
+
+
+def weights_l1(sd):
+    return float(sum(float(v.double().abs().sum()) for v in sd.values()))
 
 
 def run(name, B, steps, seed, discrete, preset_name=None):
@@ -58,6 +64,7 @@ def run(name, B, steps, seed, discrete, preset_name=None):
         out["state0_a"] = c.numpy()[:, :, :8, :8].copy()  # corner of the matrix memory (keeps the file small)
         out["state0_b"] = n.numpy()
     out["weights_sha256"] = np.array(weights_digest(sd))
+    out["weights_l1"] = np.array(weights_l1(sd))
     out["meta"] = np.array(f"preset={preset_name or name} B={B} steps={steps} seed={seed} discrete={discrete}")
     return out
 

