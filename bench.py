@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="env slots per GPU")
     ap.add_argument("--config", default="xlstm_16m", help="preset name (lram_amd.config.preset)")
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph")
+    ap.add_argument("--micro", type=int, default=0, help="env slices pipelined on separate streams (0 = auto, 1 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -117,6 +118,7 @@ def main():
     eng = Engine(spec, sd, B, device=dev)
     if args.graph:
         eng.set_graph_mode(True)
+    eng.set_micro_batches(args.micro)
 
     # ---- synthetic inputs, all resident in HBM before timing (DummyEnv-style) ----------
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -168,18 +170,42 @@ def main():
         kname, abytes = "mamba_ssm_kernel", ssm_kernel_algorithmic_bytes(spec, B, T)
     roofline = {"bound": "hbm", "kernel": kname, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": None, "traffic": None, "algorithmic_bytes_per_launch": abytes}
+    n_rec_blocks = (spec.n_blocks - len(spec.slstm_at)) if spec.backbone == "xlstm" else spec.n_blocks
     if kern_n > 0:
+        # with the micro-batch pipeline one launch covers one env slice: bytes per launch follow from the
+        # number of launches actually timed (launches x slice == mLSTM blocks x B per step)
+        launches_per_step = kern_n / K
+        abytes = abytes * n_rec_blocks / launches_per_step
+        roofline["algorithmic_bytes_per_launch"] = abytes
+        roofline["launches_per_step"] = launches_per_step
         avg_ms = kern_ms / kern_n
         ach = abytes / (avg_ms * 1e-3) / 1e9
         roofline.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, avg_launch_ms=avg_ms, launches_timed=kern_n,
                         kernel_share_of_step=kern_ms / (wall * 1e3))
+    if timing and spec.backbone == "xlstm" and args.micro != 1:
+        # the same kernel with the chip to itself (no overlapping slice): 8 extra, untimed-for-`value` steps
+        eng.set_micro_batches(1)
+        one_step(W)
+        torch.cuda.synchronize()
+        eng.profile_begin()
+        for t in range(W, W + 8):
+            one_step(t)
+        torch.cuda.synchronize()
+        ms1, n1 = eng.profile_end()
+        full = cell_kernel_algorithmic_bytes(spec, B, T)
+        roofline["standalone"] = {"avg_launch_ms": ms1 / n1, "achieved": full / (ms1 / n1 * 1e-3) / 1e9,
+                                  "frac": full / (ms1 / n1 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                  "algorithmic_bytes_per_launch": full,
+                                  "note": "micro-batch pipeline off: one launch per block over all env slots"}
+        eng.set_micro_batches(args.micro)
     pmc_file = os.path.join(ROOT, "profiles", "r01_cell_kernel_hbm_traffic.json")
     if os.path.exists(pmc_file):  # PMC bytes per launch come from a separate rocprofv3 --pmc pass (profiles/)
         try:
             with open(pmc_file) as fh:
                 pm = json.load(fh)
-            if pm.get("config") == args.config and pm.get("batch") == B:
-                roofline["traffic"] = pm.get("hbm_bytes_per_launch")
+            if pm.get("config") == args.config and pm.get("batch") == B and "hbm_bytes_per_env_per_launch" in pm:
+                envs_per_launch = B * n_rec_blocks / roofline.get("launches_per_step", n_rec_blocks)
+                roofline["traffic"] = pm["hbm_bytes_per_env_per_launch"] * envs_per_launch
         except Exception:
             pass
 
@@ -205,7 +231,7 @@ def main():
                    if args.config == "xlstm_16m" else f"{args.config}, {B} env slots per GPU",
                    "batch_per_gpu": B, "global_batch": B * world, "tokens_per_step": T,
                    "state_bytes_per_env": spec.state_bytes_per_env(), "parallelism": f"env-shard x{world}",
-                   "graph": bool(args.graph)},
+                   "graph": bool(args.graph), "micro_batches": args.micro},
         "roofline": roofline,
         "hbm_copy_measured_GBps": copy_gbps,
         "algorithmic_bytes_per_env_step": 2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim,

@@ -148,6 +148,12 @@ int32_t lram_state_import(lram_engine* e, int32_t block, int32_t which, const fl
  * replay it on later identical calls (launch-latency removal for small batches). enable = 0 disables. */
 int32_t lram_set_graph_mode(lram_engine* e, int32_t enable);
 
+/* Micro-batch pipeline (xLSTM): the env slots are processed as `n` slices on engine-owned HIP streams; the
+ * HBM-bound matrix-memory kernels of all slices run back to back on one stream while the other slices'
+ * fp32-MFMA projections overlap them.  n = 1 disables it, 0 = automatic (2 slices from 512 env slots), max 8.
+ * Results do not depend on n (envs are independent). */
+int32_t lram_set_micro_batches(lram_engine* e, int32_t n);
+
 /* Per-kernel timing of the recurrent step, measured with HIP events on the stream the kernels are
  * launched on.  lram_profile_begin arms it; every later lram_step records one (start, stop) event pair
  * around the mLSTM cell-update launches (xLSTM) or the selective-state-update launches (Mamba).

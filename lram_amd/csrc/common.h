@@ -103,6 +103,8 @@ struct MlstmCellArgs {
   float* h;            // [B*T, inner] out: (q^T C_t) / denom_t
   const uint8_t* reset;
   int B, T, NH, DH;
+  int unroll = 8;         // rows in flight per thread (8 or 16)
+  int min_lds_bytes = 0;  // > 0: request at least this much LDS per workgroup (occupancy cap, see launcher)
 };
 void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream);
 
@@ -130,6 +132,7 @@ struct SlstmConvArgs {
   float* xc;            // [B*T, D] out silu(conv)
   const uint8_t* reset;
   int B, T, D, K;
+  int state_B;          // env count of the full state tensor (stride of its leading [4] axis)
 };
 void launch_slstm_conv(const SlstmConvArgs& a, hipStream_t stream);
 
@@ -140,6 +143,7 @@ struct SlstmPointwiseArgs {
   float* state;        // [4, B, H] in/out
   float* yout;         // [B*T, H]  y written at row b*T + t
   int B, T, t, H;
+  int state_B;         // env count of the full state tensor
 };
 void launch_slstm_pointwise(const SlstmPointwiseArgs& a, hipStream_t stream);
 

@@ -3,6 +3,7 @@
 // the next block runs, so each block's recurrent state is read and written once per env-step).
 // C ABI in include/lram_hip.h.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -86,6 +87,7 @@ struct lram_engine {
   int B = 0;
   std::vector<BlockState> st;
   DevBuf X, XN, TOK, HID, U, Q, K, V, XA, H, G, SCAL, RY, LOGITS, RES, DTP;
+  size_t ucols = 0, icols = 0;  // allocated row pitch of U and of Q/K/V/XA/H/G (slice offsets use these)
   // graph replay
   bool graph_mode = false;
   bool graph_valid = false;
@@ -93,6 +95,14 @@ struct lram_engine {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   hipStream_t capture_stream = nullptr;  // capture needs a non-default stream; replay runs on the caller's
+  // micro-batch pipeline: env slices on their own streams, cell kernels serialised on hbm_stream
+  int n_micro = 0;  // 0 = auto
+  int cell_unroll = 16;   // C rows in flight per thread (LRAM_CELL_UNROLL overrides: 8 / 16 / 32)
+  int cell_lds_pad = -1;  // -1 = auto;  // bytes of LDS the cell kernel requests per workgroup while pipelined (occupancy cap)
+  std::vector<hipStream_t> micro_streams;
+  hipStream_t hbm_stream = nullptr;
+  std::vector<hipEvent_t> sync_events;
+  size_t sync_used = 0;
   // profiling of the dominant recurrent kernel
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -101,6 +111,9 @@ struct lram_engine {
   ~lram_engine() {
     drop_graph();
     if (capture_stream) (void)hipStreamDestroy(capture_stream);
+    if (hbm_stream) (void)hipStreamDestroy(hbm_stream);
+    for (hipStream_t ms : micro_streams) (void)hipStreamDestroy(ms);
+    for (hipEvent_t ev : sync_events) (void)hipEventDestroy(ev);
     for (auto& e : prof_events) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
@@ -292,6 +305,7 @@ void state_alloc(lram_engine* e, int B) {
     const size_t inner = c.inner;
     const size_t ucols = std::max<size_t>(std::max<size_t>(2 * inner, 4 * D), 2 * (size_t)c.ffn_dim);
     const size_t icols = std::max<size_t>(std::max<size_t>(inner, D), (size_t)c.ffn_dim);
+    e->ucols = ucols, e->icols = icols;
     e->U.alloc(BT * ucols);
     e->Q.alloc(BT * icols);
     e->K.alloc(BT * icols);
@@ -325,85 +339,207 @@ void prof_record(lram_engine* e, hipStream_t s, bool start) {
   }
 }
 
-void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s) {
-  const lram_config& c = e->cfg;
-  const int B = e->B, D = c.d_model, BT = B * T, NH = c.n_heads;
-  const int inner = c.inner, DH = e->dh(), SDH = e->sdh(), F = c.ffn_dim;
-  float* X = e->X.p;
-  for (int i = 0; i < c.n_blocks; ++i) {
-    const BlockWeights& w = e->bw[i];
-    BlockState& st = e->st[i];
-    launch_row_norm(X, D, e->XN.p, D, w.norm_g, w.norm_b, BT, D, c.ln_eps, c.norm_is_rms, s);
-    if (!c.block_is_slstm[i]) {
-      GemmArgs up;
-      up.a = e->XN.p, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p, up.ldc = 2 * inner;
-      up.m = BT, up.n = 2 * inner, up.k = D;
-      launch_gemm_f32(up, s);
-      MlstmPreArgs pa;
-      pa.u = e->U.p, pa.conv_state = st.conv.p, pa.n_state = st.n.p, pa.m_state = st.m.p;
-      pa.conv_w = w.conv_w, pa.conv_b = w.conv_b, pa.wq = w.wq, pa.wk = w.wk, pa.wv = w.wv;
-      pa.wi = w.wi, pa.bi = w.bi, pa.wf = w.wf, pa.bf = w.bf;
-      pa.q = e->Q.p, pa.k = e->K.p, pa.v = e->V.p, pa.xa = e->XA.p, pa.scal = e->SCAL.p, pa.reset = reset;
-      pa.B = B, pa.T = T, pa.inner = inner, pa.NH = NH, pa.K = c.conv_k;
-      launch_mlstm_pre(pa, s);
-      MlstmCellArgs ca;
-      ca.C = st.s0.p, ca.q = e->Q.p, ca.k = e->K.p, ca.v = e->V.p, ca.scal = e->SCAL.p, ca.h = e->H.p;
-      ca.reset = reset, ca.B = B, ca.T = T, ca.NH = NH, ca.DH = DH;
-      prof_record(e, s, true);
-      launch_mlstm_cell(ca, s);
-      prof_record(e, s, false);
-      GroupNormArgs ga;
-      ga.h = e->H.p, ga.gamma = w.on_g, ga.beta = w.on_b, ga.skip = w.skip, ga.xa = e->XA.p, ga.u = e->U.p;
-      ga.out = e->G.p, ga.rows = BT, ga.NH = NH, ga.DH = DH, ga.mode = 0, ga.eps = c.ln_eps;
-      launch_group_norm(ga, s);
-      GemmArgs dn;
-      dn.a = e->G.p, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
-      dn.m = BT, dn.n = D, dn.k = inner;
-      launch_gemm_f32(dn, s);
-    } else {
-      const int Hs = D;
-      SlstmConvArgs sa;
-      sa.xn = e->XN.p, sa.conv_state = st.conv.p, sa.slstm_state = st.s0.p, sa.conv_w = w.conv_w,
-      sa.conv_b = w.conv_b, sa.xc = e->Q.p, sa.reset = reset, sa.B = B, sa.T = T, sa.D = D, sa.K = c.conv_k;
-      launch_slstm_conv(sa, s);
-      float* gates = e->U.p;  // [BT, 4, H]
-      for (int g = 0; g < 4; ++g) {
-        GemmArgs ga;
-        ga.a = (g < 2) ? e->Q.p : e->XN.p, ga.lda = D, ga.sA1 = SDH;
-        ga.w = w.gate_w[g], ga.ldw = SDH, ga.sW1 = (int64_t)SDH * SDH;
-        ga.c = gates + (int64_t)g * Hs, ga.ldc = 4 * Hs, ga.sC1 = SDH;
-        ga.m = BT, ga.n = SDH, ga.k = SDH, ga.nb1 = NH;
-        launch_gemm_f32(ga, s);
-      }
-      for (int t = 0; t < T; ++t) {
-        GemmArgs ra;
-        ra.a = st.s0.p, ra.lda = Hs, ra.sA1 = SDH, ra.sA2 = 0;
-        ra.w = w.rt, ra.ldw = SDH, ra.sW1 = 4 * (int64_t)SDH * SDH, ra.sW2 = (int64_t)SDH * SDH;
-        ra.c = e->RY.p, ra.ldc = 4 * Hs, ra.sC1 = SDH, ra.sC2 = Hs;
-        ra.m = B, ra.n = SDH, ra.k = SDH, ra.nb1 = NH, ra.nb2 = 4;
-        launch_gemm_f32(ra, s);
-        SlstmPointwiseArgs pw;
-        pw.gates = gates, pw.ry = e->RY.p, pw.bias = w.rbias, pw.state = st.s0.p, pw.yout = e->H.p;
-        pw.B = B, pw.T = T, pw.t = t, pw.H = Hs;
-        launch_slstm_pointwise(pw, s);
-      }
-      GroupNormArgs gn;
-      gn.h = e->H.p, gn.gamma = w.gn_g, gn.beta = w.gn_b, gn.out = X, gn.rows = BT, gn.NH = NH, gn.DH = SDH;
-      gn.mode = 1, gn.eps = c.ln_eps, gn.skip = nullptr, gn.xa = nullptr, gn.u = nullptr;
-      launch_group_norm(gn, s);
-      launch_row_norm(X, D, e->XN.p, D, w.ffn_norm_g, w.ffn_norm_b, BT, D, c.ln_eps, c.norm_is_rms, s);
-      GemmArgs up;
-      up.a = e->XN.p, up.lda = D, up.w = w.ffn_up, up.ldw = D, up.c = e->U.p, up.ldc = 2 * F;
-      up.m = BT, up.n = 2 * F, up.k = D;
-      launch_gemm_f32(up, s);
-      launch_gelu_gate(e->U.p, e->G.p, BT, F, s);
-      GemmArgs dn;
-      dn.a = e->G.p, dn.lda = F, dn.w = w.ffn_down, dn.ldw = F, dn.c = X, dn.ldc = D, dn.residual = X;
-      dn.m = BT, dn.n = D, dn.k = F;
-      launch_gemm_f32(dn, s);
-    }
+// A contiguous range of env slots processed on its own stream.  All activation buffers are indexed by
+// row b*T + t, so a slice simply works on rows [b0*T, (b0+nb)*T) of the shared buffers.
+struct Slice {
+  int b0, nb;
+  hipStream_t s;
+};
+
+// `dst` waits for everything enqueued so far on `src` (event from the engine's pool; also legal under
+// stream capture, where it becomes a graph edge).
+void stream_after(lram_engine* e, hipStream_t dst, hipStream_t src) {
+  if (dst == src) return;
+  if (e->sync_used == e->sync_events.size()) {
+    hipEvent_t ev;
+    LRAM_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    e->sync_events.push_back(ev);
   }
-  launch_row_norm(X, D, e->HID.p, D, e->post_g, e->post_b, BT, D, c.ln_eps, c.norm_is_rms, s);
+  hipEvent_t ev = e->sync_events[e->sync_used++];
+  LRAM_HIP_CHECK(hipEventRecord(ev, src));
+  LRAM_HIP_CHECK(hipStreamWaitEvent(dst, ev, 0));
+}
+
+// Slices for this call.  One slice on the caller's stream unless micro-batching is on: then n_micro slices on
+// engine-owned streams plus one stream that serialises the HBM-bound cell kernels (see run_xlstm_stack).
+std::vector<Slice> make_slices(lram_engine* e, hipStream_t s, hipStream_t* hbm) {
+  int n = e->n_micro;
+  if (n == 0) n = (e->cfg.backbone == LRAM_BACKBONE_XLSTM && e->B >= 512) ? 2 : 1;  // auto
+  if (e->cfg.backbone != LRAM_BACKBONE_XLSTM) n = 1;
+  if (e->graph_mode) n = 1;  // graph replay targets small, launch-bound batches: one slice, one stream
+  n = std::max(1, std::min(n, std::min(e->B, 8)));
+  *hbm = s;
+  if (n == 1) return {Slice{0, e->B, s}};
+  while ((int)e->micro_streams.size() < n) {
+    hipStream_t ns;
+    LRAM_HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+    e->micro_streams.push_back(ns);
+  }
+  if (!e->hbm_stream) LRAM_HIP_CHECK(hipStreamCreateWithFlags(&e->hbm_stream, hipStreamNonBlocking));
+  *hbm = e->hbm_stream;
+  std::vector<Slice> out;
+  const int base = e->B / n, rem = e->B % n;
+  int b0 = 0;
+  for (int i = 0; i < n; ++i) {
+    const int nb = base + (i < rem ? 1 : 0);
+    out.push_back(Slice{b0, nb, e->micro_streams[i]});
+    b0 += nb;
+  }
+  return out;
+}
+
+void fork_slices(lram_engine* e, const std::vector<Slice>& sl, hipStream_t hbm, hipStream_t s) {
+  for (const Slice& x : sl) stream_after(e, x.s, s);
+  stream_after(e, hbm, s);
+}
+void join_slices(lram_engine* e, const std::vector<Slice>& sl, hipStream_t hbm, hipStream_t s) {
+  for (const Slice& x : sl) stream_after(e, s, x.s);
+  stream_after(e, s, hbm);
+}
+
+// ---- mLSTM block, split at the cell kernel -----------------------------------------------------------
+void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl) {
+  const lram_config& c = e->cfg;
+  const int D = c.d_model, inner = c.inner, NH = c.n_heads, rows = sl.nb * T;
+  const size_t r0 = (size_t)sl.b0 * T, b0 = sl.b0;
+  const BlockWeights& w = e->bw[i];
+  BlockState& st = e->st[i];
+  launch_row_norm(e->X.p + r0 * D, D, e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps, c.norm_is_rms, sl.s);
+  GemmArgs up;
+  up.a = e->XN.p + r0 * D, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p + r0 * e->ucols, up.ldc = 2 * inner;
+  up.m = rows, up.n = 2 * inner, up.k = D;
+  launch_gemm_f32(up, sl.s);
+  MlstmPreArgs pa;
+  pa.u = e->U.p + r0 * e->ucols, pa.conv_state = st.conv.p + b0 * c.conv_k * inner, pa.n_state = st.n.p + b0 * inner;
+  pa.m_state = st.m.p + b0 * NH;
+  pa.conv_w = w.conv_w, pa.conv_b = w.conv_b, pa.wq = w.wq, pa.wk = w.wk, pa.wv = w.wv;
+  pa.wi = w.wi, pa.bi = w.bi, pa.wf = w.wf, pa.bf = w.bf;
+  pa.q = e->Q.p + r0 * e->icols, pa.k = e->K.p + r0 * e->icols, pa.v = e->V.p + r0 * e->icols;
+  pa.xa = e->XA.p + r0 * e->icols;
+  pa.scal = e->SCAL.p + r0 * NH * 4, pa.reset = reset ? reset + b0 : nullptr;
+  pa.B = sl.nb, pa.T = T, pa.inner = inner, pa.NH = NH, pa.K = c.conv_k;
+  launch_mlstm_pre(pa, sl.s);
+}
+
+void mlstm_cell(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl, hipStream_t s) {
+  const lram_config& c = e->cfg;
+  const int inner = c.inner, NH = c.n_heads, DH = e->dh();
+  const size_t r0 = (size_t)sl.b0 * T, b0 = sl.b0;
+  MlstmCellArgs ca;
+  ca.C = e->st[i].s0.p + b0 * NH * DH * DH, ca.q = e->Q.p + r0 * e->icols, ca.k = e->K.p + r0 * e->icols;
+  ca.v = e->V.p + r0 * e->icols, ca.scal = e->SCAL.p + r0 * NH * 4, ca.h = e->H.p + r0 * e->icols;
+  ca.reset = reset ? reset + b0 : nullptr, ca.B = sl.nb, ca.T = T, ca.NH = NH, ca.DH = DH;
+  // Large launches: one cell workgroup per CU (84 KB of LDS each; a second one does not fit, two 37 KB GEMM
+  // workgroups of the other slice do).  Measured on MI355X at B=4096/16M: 1.61 ms -> 1.47 ms per launch
+  // (5.5 -> 6.0 TB/s) standalone; see DESIGN.md section 6.
+  const long wgs = (long)sl.nb * NH * ((DH % 256 == 0) ? DH / 256 : (DH % 128 == 0) ? DH / 128 : DH / 64);
+  ca.min_lds_bytes = e->cell_lds_pad >= 0 ? e->cell_lds_pad : (wgs >= 1024 ? 84 * 1024 : 0);
+  ca.unroll = e->cell_unroll;
+  prof_record(e, s, true);
+  launch_mlstm_cell(ca, s);
+  prof_record(e, s, false);
+}
+
+void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
+  const lram_config& c = e->cfg;
+  const int D = c.d_model, inner = c.inner, NH = c.n_heads, DH = e->dh(), rows = sl.nb * T;
+  const size_t r0 = (size_t)sl.b0 * T;
+  const BlockWeights& w = e->bw[i];
+  GroupNormArgs ga;
+  ga.h = e->H.p + r0 * e->icols, ga.gamma = w.on_g, ga.beta = w.on_b, ga.skip = w.skip, ga.xa = e->XA.p + r0 * e->icols;
+  ga.u = e->U.p + r0 * e->ucols, ga.out = e->G.p + r0 * e->icols, ga.rows = rows, ga.NH = NH, ga.DH = DH, ga.mode = 0;
+  ga.eps = c.ln_eps;
+  launch_group_norm(ga, sl.s);
+  float* X = e->X.p + r0 * D;
+  GemmArgs dn;
+  dn.a = e->G.p + r0 * e->icols, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
+  dn.m = rows, dn.n = D, dn.k = inner;
+  launch_gemm_f32(dn, sl.s);
+}
+
+void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl) {
+  const lram_config& c = e->cfg;
+  const int D = c.d_model, NH = c.n_heads, SDH = e->sdh(), F = c.ffn_dim, Hs = D, rows = sl.nb * T;
+  const size_t r0 = (size_t)sl.b0 * T, b0 = sl.b0;
+  const BlockWeights& w = e->bw[i];
+  BlockState& st = e->st[i];
+  hipStream_t s = sl.s;
+  float* X = e->X.p + r0 * D;
+  float* XN = e->XN.p + r0 * D;
+  float* XC = e->Q.p + r0 * e->icols;          // silu(conv(xn))
+  float* gates = e->U.p + r0 * e->ucols;  // [rows, 4, H]
+  float* RY = e->RY.p + b0 * 4 * Hs;     // [nb, 4, H]
+  float* Y = e->H.p + r0 * e->icols;          // [rows, H]
+  float* Ubuf = e->U.p + r0 * e->ucols;
+  float* Gbuf = e->G.p + r0 * e->icols;
+  float* state = st.s0.p + b0 * Hs;      // [4, B, H] viewed from env b0 (leading-axis stride e->B * H)
+  launch_row_norm(X, D, XN, D, w.norm_g, w.norm_b, rows, D, c.ln_eps, c.norm_is_rms, s);
+  SlstmConvArgs sa;
+  sa.xn = XN, sa.conv_state = st.conv.p + b0 * c.conv_k * D, sa.slstm_state = state, sa.conv_w = w.conv_w;
+  sa.conv_b = w.conv_b, sa.xc = XC, sa.reset = reset ? reset + b0 : nullptr, sa.B = sl.nb, sa.T = T, sa.D = D;
+  sa.K = c.conv_k, sa.state_B = e->B;
+  launch_slstm_conv(sa, s);
+  for (int g = 0; g < 4; ++g) {
+    GemmArgs ga;
+    ga.a = (g < 2) ? XC : XN, ga.lda = D, ga.sA1 = SDH;
+    ga.w = w.gate_w[g], ga.ldw = SDH, ga.sW1 = (int64_t)SDH * SDH;
+    ga.c = gates + (int64_t)g * Hs, ga.ldc = 4 * Hs, ga.sC1 = SDH;
+    ga.m = rows, ga.n = SDH, ga.k = SDH, ga.nb1 = NH;
+    launch_gemm_f32(ga, s);
+  }
+  for (int t = 0; t < T; ++t) {
+    GemmArgs ra;
+    ra.a = state, ra.lda = Hs, ra.sA1 = SDH, ra.sA2 = 0;
+    ra.w = w.rt, ra.ldw = SDH, ra.sW1 = 4 * (int64_t)SDH * SDH, ra.sW2 = (int64_t)SDH * SDH;
+    ra.c = RY, ra.ldc = 4 * Hs, ra.sC1 = SDH, ra.sC2 = Hs;
+    ra.m = sl.nb, ra.n = SDH, ra.k = SDH, ra.nb1 = NH, ra.nb2 = 4;
+    launch_gemm_f32(ra, s);
+    SlstmPointwiseArgs pw;
+    pw.gates = gates, pw.ry = RY, pw.bias = w.rbias, pw.state = state, pw.yout = Y;
+    pw.B = sl.nb, pw.T = T, pw.t = t, pw.H = Hs, pw.state_B = e->B;
+    launch_slstm_pointwise(pw, s);
+  }
+  GroupNormArgs gn;
+  gn.h = Y, gn.gamma = w.gn_g, gn.beta = w.gn_b, gn.out = X, gn.rows = rows, gn.NH = NH, gn.DH = SDH;
+  gn.mode = 1, gn.eps = c.ln_eps, gn.skip = nullptr, gn.xa = nullptr, gn.u = nullptr;
+  launch_group_norm(gn, s);
+  launch_row_norm(X, D, XN, D, w.ffn_norm_g, w.ffn_norm_b, rows, D, c.ln_eps, c.norm_is_rms, s);
+  GemmArgs up;
+  up.a = XN, up.lda = D, up.w = w.ffn_up, up.ldw = D, up.c = Ubuf, up.ldc = 2 * F;
+  up.m = rows, up.n = 2 * F, up.k = D;
+  launch_gemm_f32(up, s);
+  launch_gelu_gate(Ubuf, Gbuf, rows, F, s);
+  GemmArgs dn;
+  dn.a = Gbuf, dn.lda = F, dn.w = w.ffn_down, dn.ldw = F, dn.c = X, dn.ldc = D, dn.residual = X;
+  dn.m = rows, dn.n = D, dn.k = F;
+  launch_gemm_f32(dn, s);
+}
+
+// Block stack on X [B*T, D] (in-place residual stream) -> HID.  With more than one slice the HBM-bound cell
+// kernels of all slices are serialised on `hbm` while each slice's projections / norms run on its own stream:
+// while slice A's matrix memory streams through HBM, slice B's fp32-MFMA GEMMs use the otherwise idle matrix
+// cores (and vice versa one half-layer later).
+void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vector<Slice>& sl, hipStream_t hbm) {
+  const lram_config& c = e->cfg;
+  const int D = c.d_model;
+  for (int i = 0; i < c.n_blocks; ++i) {
+    if (c.block_is_slstm[i]) {
+      for (const Slice& x : sl) slstm_block(e, i, T, reset, x);
+      continue;
+    }
+    for (const Slice& x : sl) {
+      mlstm_front(e, i, T, reset, x);
+      stream_after(e, hbm, x.s);
+      mlstm_cell(e, i, T, reset, x, hbm);
+      stream_after(e, x.s, hbm);
+    }
+    for (const Slice& x : sl) mlstm_back(e, i, T, x);
+  }
+  for (const Slice& x : sl) {
+    const size_t r0 = (size_t)x.b0 * T;
+    launch_row_norm(e->X.p + r0 * D, D, e->HID.p + r0 * D, D, e->post_g, e->post_b, x.nb * T, D, c.ln_eps,
+                    c.norm_is_rms, x.s);
+  }
 }
 
 void run_mamba_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s) {
@@ -445,36 +581,52 @@ void run_mamba_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s)
   launch_add_rms_norm(X, e->RES.p, nullptr, e->HID.p, e->post_g, BT, D, c.norm_eps, s);
 }
 
-void run_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s) {
+void run_stack(lram_engine* e, int T, const uint8_t* reset, const std::vector<Slice>& sl, hipStream_t hbm) {
   if (e->cfg.backbone == LRAM_BACKBONE_MAMBA)
-    run_mamba_stack(e, T, reset, s);
+    run_mamba_stack(e, T, reset, sl[0].s);
   else
-    run_xlstm_stack(e, T, reset, s);
+    run_xlstm_stack(e, T, reset, sl, hbm);
 }
 
 void step_launches(lram_engine* e, const float* obs, int emb, const float* rtg, const float* rew,
                    const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s) {
   const lram_config& c = e->cfg;
-  const int B = e->B, D = c.d_model, T = c.tokens_per_step;
-  if (emb) {
-    launch_scatter_token0(e->X.p, obs, B, T, D, s);
-  } else {
-    GemmArgs ge;
-    ge.a = obs, ge.lda = c.state_dim, ge.w = e->w_state, ge.ldw = c.state_dim, ge.c = e->X.p, ge.ldc = (int64_t)T * D;
-    ge.bias = e->b_state, ge.m = B, ge.n = D, ge.k = c.state_dim;
-    launch_gemm_f32(ge, s);
+  const int D = c.d_model, T = c.tokens_per_step;
+  e->sync_used = 0;
+  hipStream_t hbm;
+  const std::vector<Slice> sl = make_slices(e, s, &hbm);
+  const bool multi = sl.size() > 1;
+  if (multi) fork_slices(e, sl, hbm, s);
+  for (const Slice& x : sl) {
+    const size_t r0 = (size_t)x.b0 * T, b0 = x.b0;
+    float* X = e->X.p + r0 * D;
+    if (emb) {
+      launch_scatter_token0(X, obs + b0 * D, x.nb, T, D, x.s);
+    } else {
+      GemmArgs ge;
+      ge.a = obs + b0 * c.state_dim, ge.lda = c.state_dim, ge.w = e->w_state, ge.ldw = c.state_dim, ge.c = X;
+      ge.ldc = (int64_t)T * D, ge.bias = e->b_state, ge.m = x.nb, ge.n = D, ge.k = c.state_dim;
+      launch_gemm_f32(ge, x.s);
+    }
+    launch_embed_scalars(X, rtg + b0, rew + b0, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew, x.nb, T, D, x.s);
+    launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * T, D, 1e-5f, 0, x.s);
+    LRAM_HIP_CHECK(hipMemcpyAsync(e->TOK.p + r0 * D, X, sizeof(float) * (size_t)x.nb * T * D, hipMemcpyDeviceToDevice,
+                                  x.s));
   }
-  launch_embed_scalars(e->X.p, rtg, rew, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew, B, T, D, s);
-  launch_row_norm(e->X.p, D, e->X.p, D, e->eln_g, e->eln_b, B * T, D, 1e-5f, 0, s);
-  LRAM_HIP_CHECK(hipMemcpyAsync(e->TOK.p, e->X.p, sizeof(float) * (size_t)B * T * D, hipMemcpyDeviceToDevice, s));
-  run_stack(e, T, reset, s);
-  GemmArgs gh;
-  gh.a = e->HID.p + (int64_t)c.pred_token * D, gh.lda = (int64_t)T * D, gh.w = e->w_head, gh.ldw = D;
-  gh.c = e->LOGITS.p, gh.ldc = (int64_t)c.act_dim * c.n_vocab, gh.bias = e->b_head;
-  gh.m = B, gh.n = c.act_dim * c.n_vocab, gh.k = D;
-  launch_gemm_f32(gh, s);
-  launch_action_argmax(e->LOGITS.p, actions, tokens, B, c.act_dim, c.n_vocab, c.n_discrete, c.action_channels,
-                       c.tok_min, c.tok_max, discrete, s);
+  run_stack(e, T, reset, sl, hbm);
+  const int64_t nlog = (int64_t)c.act_dim * c.n_vocab;
+  for (const Slice& x : sl) {
+    const size_t r0 = (size_t)x.b0 * T, b0 = x.b0;
+    GemmArgs gh;
+    gh.a = e->HID.p + (r0 + c.pred_token) * D, gh.lda = (int64_t)T * D, gh.w = e->w_head, gh.ldw = D;
+    gh.c = e->LOGITS.p + b0 * nlog, gh.ldc = nlog, gh.bias = e->b_head;
+    gh.m = x.nb, gh.n = (int)nlog, gh.k = D;
+    launch_gemm_f32(gh, x.s);
+    launch_action_argmax(e->LOGITS.p + b0 * nlog, actions + b0 * c.act_dim, tokens ? tokens + b0 * c.act_dim : nullptr,
+                         x.nb, c.act_dim, c.n_vocab, c.n_discrete, c.action_channels, c.tok_min, c.tok_max, discrete,
+                         x.s);
+  }
+  if (multi) join_slices(e, sl, hbm, s);
 }
 
 struct StateView {
@@ -531,6 +683,8 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     auto e = std::make_unique<lram_engine>();
     e->cfg = *cfg;
     e->device = device;
+    if (const char* v = std::getenv("LRAM_CELL_LDS_PAD_KB")) e->cell_lds_pad = std::atoi(v) * 1024;
+    if (const char* v = std::getenv("LRAM_CELL_UNROLL")) e->cell_unroll = std::atoi(v);
     *out = e.release();
   });
 }
@@ -657,7 +811,12 @@ int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = sizeof(float) * (size_t)e->B * tokens * e->cfg.d_model;
     LRAM_HIP_CHECK(hipMemcpyAsync(e->X.p, dev_inputs_embeds, bytes, hipMemcpyDeviceToDevice, s));
-    run_stack(e, tokens, dev_reset_mask, s);
+    e->sync_used = 0;
+    hipStream_t hbm;
+    const std::vector<Slice> sl = make_slices(e, s, &hbm);
+    if (sl.size() > 1) fork_slices(e, sl, hbm, s);
+    run_stack(e, tokens, dev_reset_mask, sl, hbm);
+    if (sl.size() > 1) join_slices(e, sl, hbm, s);
     LRAM_HIP_CHECK(hipMemcpyAsync(dev_hidden_out, e->HID.p, bytes, hipMemcpyDeviceToDevice, s));
   });
 }
@@ -704,6 +863,14 @@ int32_t lram_set_graph_mode(lram_engine* e, int32_t enable) {
     LRAM_REQUIRE(e != nullptr, "lram_set_graph_mode: null engine");
     e->graph_mode = enable != 0;
     if (!e->graph_mode) e->drop_graph();
+  });
+}
+
+int32_t lram_set_micro_batches(lram_engine* e, int32_t n) {
+  return guarded([&] {
+    LRAM_REQUIRE(e != nullptr && n >= 0 && n <= 8, "lram_set_micro_batches: n must be in 0..8 (0 = auto)");
+    e->n_micro = n;
+    e->drop_graph();
   });
 }
 

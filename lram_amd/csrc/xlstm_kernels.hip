@@ -5,6 +5,8 @@
 // (~15 eager ops), N5 conv1d_step, N6 LinearHeadwiseExpand, N7 MultiHeadLayerNorm, N1 sLSTM pointwise.
 // All of a timestep's T (= 3) tokens are applied inside one launch per layer: the matrix memory C is
 // read once and written once per env-step instead of once per token.
+#include <algorithm>
+
 #include "common.h"
 #include "device_math.h"
 
@@ -219,9 +221,8 @@ __global__ __launch_bounds__(kPreThreads) void mlstm_pre_kernel(MlstmPreArgs a) 
 // =============================================================================================
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int kCellThreads = 256;
-constexpr int kCellUnroll = 8;
 
-template <int T, int LPR>
+template <int T, int LPR, int kCellUnroll>
 __global__ __launch_bounds__(kCellThreads) void mlstm_cell_kernel(MlstmCellArgs a) {
   constexpr int CW = 4 * LPR;
   constexpr int RP = kCellThreads / LPR;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void slstm_conv_kernel(SlstmConvArgs a) {
   if (rs) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      *reinterpret_cast<float4*>(a.slstm_state + ((int64_t)s * a.B + b) * D + c0) = f4_zero();
+      *reinterpret_cast<float4*>(a.slstm_state + ((int64_t)s * a.state_B + b) * D + c0) = f4_zero();
   }
 }
 
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void slstm_pointwise_kernel(SlstmPointwiseArgs
   const float fraw = g[H] + r[H] + a.bias[H + c];
   const float zraw = g[2 * H] + r[2 * H] + a.bias[2 * H + c];
   const float oraw = g[3 * H] + r[3 * H] + a.bias[3 * H + c];
-  const int64_t BH = (int64_t)a.B * H;
+  const int64_t BH = (int64_t)a.state_B * H;
   float* st = a.state + (int64_t)b * H + c;
   const float cs = st[BH], ns = st[2 * BH], ms = st[3 * BH];
   const float logfplusm = ms + log_sigmoid(fraw);
@@ -506,12 +507,34 @@ void launch_mlstm_pre(const MlstmPreArgs& a, hipStream_t stream) {
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
-template <int T, int LPR>
-static void launch_cell_tl(const MlstmCellArgs& a, hipStream_t s) {
+template <int T, int LPR, int UNR>
+static void launch_cell_tlu(const MlstmCellArgs& a, hipStream_t s) {
   constexpr int CW = 4 * LPR, RP = kCellThreads / LPR;
   dim3 grid(a.DH / CW, a.NH, a.B), block(kCellThreads);
-  const size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW);
-  hipLaunchKernelGGL((mlstm_cell_kernel<T, LPR>), grid, block, shmem, s, a);
+  size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW);
+  // Occupancy cap: `min_lds_bytes` of LDS per workgroup limits how many workgroups share a CU.  Fewer, longer
+  // sequential streams per CU use HBM better, and the cap leaves LDS / registers for another slice's fp32-MFMA
+  // GEMM workgroups (37 KB LDS each) when the engine overlaps the two.
+  shmem = std::max(shmem, (size_t)a.min_lds_bytes);
+  if (shmem > 48 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_cell_kernel<T, LPR, UNR>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL((mlstm_cell_kernel<T, LPR, UNR>), grid, block, shmem, s, a);
+}
+
+template <int T, int LPR>
+static void launch_cell_tl(const MlstmCellArgs& a, hipStream_t s) {
+  if (a.unroll >= 32)
+    launch_cell_tlu<T, LPR, 32>(a, s);
+  else if (a.unroll >= 16)
+    launch_cell_tlu<T, LPR, 16>(a, s);
+  else
+    launch_cell_tlu<T, LPR, 8>(a, s);
 }
 
 template <int T>

@@ -55,6 +55,7 @@ _SYMBOLS = {
     "lram_state_export": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
     "lram_state_import": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
     "lram_set_graph_mode": (ctypes.c_int32, [_VP, ctypes.c_int32]),
+    "lram_set_micro_batches": (ctypes.c_int32, [_VP, ctypes.c_int32]),
     "lram_profile_begin": (ctypes.c_int32, [_VP]),
     "lram_profile_end": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "lram_gemm_f32": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
@@ -300,6 +301,10 @@ class Engine:
     # -- launch-latency removal / measurement ----------------------------------------------------
     def set_graph_mode(self, enable: bool):
         _check(self.lib, self.lib.lram_set_graph_mode(self._h, int(enable)))
+
+    def set_micro_batches(self, n: int):
+        """Env slices pipelined on separate HIP streams (0 = auto, 1 = off); results are independent of n."""
+        _check(self.lib, self.lib.lram_set_micro_batches(self._h, int(n)))
 
     def profile_begin(self):
         _check(self.lib, self.lib.lram_profile_begin(self._h))

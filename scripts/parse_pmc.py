@@ -12,6 +12,7 @@ import os
 import sys
 
 out_dir, tag, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+n_micro = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # env slices per step: one launch covers batch / n_micro envs
 KERNELS = {"cell": ("mlstm_cell_kernel", "mamba_ssm_kernel"), "copy": ("stream_copy_kernel",)}
 res = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -32,12 +33,13 @@ fetch_cell, nfc = res["FETCH_SIZE"]["cell"]
 write_cell, nwc = res["WRITE_SIZE"]["cell"]
 fetch_copy, _ = res["FETCH_SIZE"]["copy"]
 write_copy, _ = res["WRITE_SIZE"]["copy"]
-summary = {"config": tag, "batch": batch, "raw_KiB_median_per_launch": {k: {kk: vv[0] for kk, vv in v.items()} for k, v in res.items()},
+summary = {"config": tag, "batch": batch, "micro_batches": n_micro, "envs_per_launch": batch // n_micro, "raw_KiB_median_per_launch": {k: {kk: vv[0] for kk, vv in v.items()} for k, v in res.items()},
            "launches": {"fetch": nfc, "write": nwc}}
 if fetch_cell is not None and write_cell is not None:
     rd = fetch_cell * 1024 * 2.0
     wr = write_cell * 1024
     summary.update(read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr,
+                   hbm_bytes_per_env_per_launch=(rd + wr) / (batch // n_micro),
                    corrections="FETCH_SIZE KiB x1024 x2 (gfx950 wide-read undercount), WRITE_SIZE KiB x1024")
     if fetch_copy and write_copy:
         summary["calibration_stream_copy"] = {"fetch_reported_over_true": fetch_copy * 1024 / GiB,

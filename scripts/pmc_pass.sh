@@ -11,4 +11,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
       --no-cpu-baseline --no-kernel-timing ${BENCH_ARGS:-} > $OUT/$C.json 2> $OUT/$C.err
   echo "$C rc=$?"
 done
-cd $R && python3 scripts/parse_pmc.py $OUT ${PMC_TAG:-xlstm_16m} ${PMC_BATCH:-4096}
+cd $R && python3 scripts/parse_pmc.py $OUT ${PMC_TAG:-xlstm_16m} ${PMC_BATCH:-4096} ${PMC_MICRO:-2}
