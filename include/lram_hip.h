@@ -162,10 +162,17 @@ int32_t lram_profile_begin(lram_engine* e);
 int32_t lram_profile_end(lram_engine* e, double* total_ms, int64_t* n_launches);
 
 /* Standalone kernel entry points used by tests and micro-benchmarks. */
-/* C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) (+ residual C_in)   fp32, MFMA 32x32x2 f32 */
+/* C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) (+ residual C_in)   fp32, MFMA 32x32x2 f32 (exact k-ordered fma chain) */
 int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                       int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                       int32_t k, void* stream);
+/* Same contract through the bf16x3 kernel the engine uses for its projections (each fp32 operand split into
+ * three bf16 pieces, six bf16 MFMA products accumulated in fp32: fp32-level accuracy, not bit-identical to
+ * lram_gemm_f32).  W must be contiguous [n, k], k a multiple of 8.  Splits W into a temporary and synchronises
+ * the stream: test / micro-benchmark entry, not a hot-path call. */
+int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
+                         int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
+                         int32_t k, void* stream);
 /* STREAM-like device copy (float4), used by bench.py to measure the achievable HBM rate on the box. */
 int32_t lram_stream_copy(float* dev_dst, const float* dev_src, size_t numel, void* stream);
 

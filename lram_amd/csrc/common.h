@@ -41,8 +41,14 @@ struct GemmArgs {
   int m = 0, n = 0, k = 0;
   int nb1 = 1, nb2 = 1;
   int64_t sA1 = 0, sA2 = 0, sW1 = 0, sW2 = 0, sC1 = 0, sC2 = 0, sBias1 = 0, sBias2 = 0;
+  // optional: W pre-split into three bf16 planes (hi, mid, lo), each laid out like w, `w3_plane` elements apart
+  const uint16_t* w3 = nullptr;
+  int64_t w3_plane = 0;
 };
-void launch_gemm_f32(const GemmArgs& g, hipStream_t stream);
+void launch_gemm_f32(const GemmArgs& g, hipStream_t stream);      // exact fp32 MFMA (k-ordered fma chain)
+bool gemm_bf16x3_supported(const GemmArgs& g);
+void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t stream);   // fp32-accurate, 3 x bf16 split operands
+void launch_split_bf16x3(const float* w, uint16_t* out, size_t n, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // normalisation / elementwise

@@ -79,6 +79,13 @@ struct lram_engine {
   std::map<std::string, DevBuf> weights;
   bool finalized = false;
   std::vector<BlockWeights> bw;
+  // bf16x3 GEMM: fp32 weight pointer -> its three bf16 planes (built in finalize)
+  struct Split {
+    uint16_t* p;
+    size_t n;
+  };
+  std::map<const float*, Split> split;
+  bool use_bf16x3 = true;  // LRAM_GEMM=f32 selects the exact fp32-MFMA kernel everywhere
   // front end / head
   const float *w_state = nullptr, *b_state = nullptr, *w_rtg = nullptr, *b_rtg = nullptr, *w_rew = nullptr,
               *b_rew = nullptr, *eln_g = nullptr, *eln_b = nullptr, *w_head = nullptr, *b_head = nullptr,
@@ -119,7 +126,12 @@ struct lram_engine {
       (void)hipEventDestroy(e.second);
     }
     for (auto& kv : weights) kv.second.release();
+    drop_splits();
     release_state();
+  }
+  void drop_splits() {
+    for (auto& kv : split) (void)hipFree(kv.second.p);
+    split.clear();
   }
   void drop_graph() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -187,6 +199,8 @@ void validate_config(const lram_config& c) {
                  "bad Mamba dimensions");
   }
 }
+
+void make_split(lram_engine* e, const float* w, size_t n);
 
 void finalize(lram_engine* e) {
   const lram_config& c = e->cfg;
@@ -256,6 +270,24 @@ void finalize(lram_engine* e) {
       w.proj_down = need(e, p + "proj_down", D * inner);
     }
   }
+  // bf16 split planes of every GEMM weight (LRAM_GEMM=f32 keeps the exact fp32-MFMA kernels instead)
+  e->drop_splits();
+  if (const char* v = std::getenv("LRAM_GEMM")) e->use_bf16x3 = std::string(v) != "f32";
+  if (e->use_bf16x3) {
+    auto numel = [&](const float* p) -> size_t {
+      for (auto& kv : e->weights)
+        if (kv.second.p == p) return kv.second.n;
+      return 0;
+    };
+    std::vector<const float*> ws = {e->w_head};  // embed_state has K = state_dim (204): rows not 16-byte aligned
+    for (const BlockWeights& w : e->bw)
+      for (const float* p : {w.proj_up, w.proj_down, w.gate_w[0], w.gate_w[1], w.gate_w[2], w.gate_w[3], w.rt, w.ffn_up,
+                             w.ffn_down, w.in_proj, w.x_proj, w.dt_proj, w.out_proj})
+        ws.push_back(p);
+    for (const float* p : ws)
+      if (p != nullptr) make_split(e, p, numel(p));
+    LRAM_HIP_CHECK(hipDeviceSynchronize());
+  }
   e->finalized = true;
 }
 
@@ -323,6 +355,31 @@ void state_alloc(lram_engine* e, int B) {
 // ---------------------------------------------------------------------------------------------
 // block stack on X [B*T, D] (in place residual stream) -> HID [B*T, D]
 // ---------------------------------------------------------------------------------------------
+// GEMM dispatch: bf16x3 (fp32-accurate on the bf16 matrix cores) when the weight has split planes and the shape
+// allows 16-byte bf16 loads, else the exact fp32-MFMA kernel.
+void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
+  if (e->use_bf16x3) {
+    auto it = e->split.find(g.w);
+    if (it != e->split.end()) {
+      g.w3 = it->second.p;
+      g.w3_plane = (int64_t)it->second.n;
+      if (gemm_bf16x3_supported(g)) {
+        launch_gemm_bf16x3(g, s);
+        return;
+      }
+    }
+  }
+  launch_gemm_f32(g, s);
+}
+
+void make_split(lram_engine* e, const float* w, size_t n) {
+  if (w == nullptr || e->split.count(w)) return;
+  uint16_t* p = nullptr;
+  LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&p), 3 * n * sizeof(uint16_t)));
+  launch_split_bf16x3(w, p, n, nullptr);
+  e->split[w] = lram_engine::Split{p, n};
+}
+
 void prof_record(lram_engine* e, hipStream_t s, bool start) {
   if (!e->prof_on) return;
   if (start) {
@@ -408,7 +465,7 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   GemmArgs up;
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p + r0 * e->ucols, up.ldc = 2 * inner;
   up.m = rows, up.n = 2 * inner, up.k = D;
-  launch_gemm_f32(up, sl.s);
+  gemm(e, up, sl.s);
   MlstmPreArgs pa;
   pa.u = e->U.p + r0 * e->ucols, pa.conv_state = st.conv.p + b0 * c.conv_k * inner, pa.n_state = st.n.p + b0 * inner;
   pa.m_state = st.m.p + b0 * NH;
@@ -454,7 +511,7 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
   GemmArgs dn;
   dn.a = e->G.p + r0 * e->icols, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
   dn.m = rows, dn.n = D, dn.k = inner;
-  launch_gemm_f32(dn, sl.s);
+  gemm(e, dn, sl.s);
 }
 
 void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl) {
@@ -485,7 +542,7 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     ga.w = w.gate_w[g], ga.ldw = SDH, ga.sW1 = (int64_t)SDH * SDH;
     ga.c = gates + (int64_t)g * Hs, ga.ldc = 4 * Hs, ga.sC1 = SDH;
     ga.m = rows, ga.n = SDH, ga.k = SDH, ga.nb1 = NH;
-    launch_gemm_f32(ga, s);
+    gemm(e, ga, s);
   }
   for (int t = 0; t < T; ++t) {
     GemmArgs ra;
@@ -493,7 +550,7 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     ra.w = w.rt, ra.ldw = SDH, ra.sW1 = 4 * (int64_t)SDH * SDH, ra.sW2 = (int64_t)SDH * SDH;
     ra.c = RY, ra.ldc = 4 * Hs, ra.sC1 = SDH, ra.sC2 = Hs;
     ra.m = sl.nb, ra.n = SDH, ra.k = SDH, ra.nb1 = NH, ra.nb2 = 4;
-    launch_gemm_f32(ra, s);
+    gemm(e, ra, s);
     SlstmPointwiseArgs pw;
     pw.gates = gates, pw.ry = RY, pw.bias = w.rbias, pw.state = state, pw.yout = Y;
     pw.B = sl.nb, pw.T = T, pw.t = t, pw.H = Hs, pw.state_B = e->B;
@@ -507,12 +564,12 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   GemmArgs up;
   up.a = XN, up.lda = D, up.w = w.ffn_up, up.ldw = D, up.c = Ubuf, up.ldc = 2 * F;
   up.m = rows, up.n = 2 * F, up.k = D;
-  launch_gemm_f32(up, s);
+  gemm(e, up, s);
   launch_gelu_gate(Ubuf, Gbuf, rows, F, s);
   GemmArgs dn;
   dn.a = Gbuf, dn.lda = F, dn.w = w.ffn_down, dn.ldw = F, dn.c = X, dn.ldc = D, dn.residual = X;
   dn.m = rows, dn.n = D, dn.k = F;
-  launch_gemm_f32(dn, s);
+  gemm(e, dn, s);
 }
 
 // Block stack on X [B*T, D] (in-place residual stream) -> HID.  With more than one slice the HBM-bound cell
@@ -553,7 +610,7 @@ void run_mamba_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s)
     GemmArgs in;
     in.a = e->XN.p, in.lda = D, in.w = w.in_proj, in.ldw = D, in.c = e->U.p, in.ldc = 2 * di, in.bias = w.in_proj_b;
     in.m = BT, in.n = 2 * di, in.k = D;
-    launch_gemm_f32(in, s);
+    gemm(e, in, s);
     MambaConvArgs ca;
     ca.xz = e->U.p, ca.conv_state = st.conv.p, ca.conv_w = w.conv_w, ca.conv_b = w.conv_b, ca.xc = e->XA.p;
     ca.reset = reset, ca.B = B, ca.T = T, ca.d_inner = di, ca.K = c.d_conv;
@@ -561,11 +618,11 @@ void run_mamba_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s)
     GemmArgs xp;
     xp.a = e->XA.p, xp.lda = di, xp.w = w.x_proj, xp.ldw = di, xp.c = e->Q.p, xp.ldc = R + 2 * N;
     xp.m = BT, xp.n = R + 2 * N, xp.k = di;
-    launch_gemm_f32(xp, s);
+    gemm(e, xp, s);
     GemmArgs dp;
     dp.a = e->Q.p, dp.lda = R + 2 * N, dp.w = w.dt_proj, dp.ldw = R, dp.c = e->DTP.p, dp.ldc = di;
     dp.m = BT, dp.n = di, dp.k = R;
-    launch_gemm_f32(dp, s);
+    gemm(e, dp, s);
     MambaSsmArgs sa;
     sa.ssm_state = st.s0.p, sa.xc = e->XA.p, sa.dtp = e->DTP.p, sa.dt_bias = w.dt_bias, sa.xdb = e->Q.p;
     sa.A_log = w.A_log, sa.Dp = w.Dp, sa.xz = e->U.p, sa.y = e->H.p, sa.reset = reset;
@@ -576,7 +633,7 @@ void run_mamba_stack(lram_engine* e, int T, const uint8_t* reset, hipStream_t s)
     GemmArgs op;
     op.a = e->H.p, op.lda = di, op.w = w.out_proj, op.ldw = di, op.c = X, op.ldc = D, op.bias = w.out_proj_b;
     op.m = BT, op.n = D, op.k = di;
-    launch_gemm_f32(op, s);
+    gemm(e, op, s);
   }
   launch_add_rms_norm(X, e->RES.p, nullptr, e->HID.p, e->post_g, BT, D, c.norm_eps, s);
 }
@@ -606,7 +663,7 @@ void step_launches(lram_engine* e, const float* obs, int emb, const float* rtg, 
       GemmArgs ge;
       ge.a = obs + b0 * c.state_dim, ge.lda = c.state_dim, ge.w = e->w_state, ge.ldw = c.state_dim, ge.c = X;
       ge.ldc = (int64_t)T * D, ge.bias = e->b_state, ge.m = x.nb, ge.n = D, ge.k = c.state_dim;
-      launch_gemm_f32(ge, x.s);
+      gemm(e, ge, x.s);
     }
     launch_embed_scalars(X, rtg + b0, rew + b0, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew, x.nb, T, D, x.s);
     launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * T, D, 1e-5f, 0, x.s);
@@ -621,7 +678,7 @@ void step_launches(lram_engine* e, const float* obs, int emb, const float* rtg, 
     gh.a = e->HID.p + (r0 + c.pred_token) * D, gh.lda = (int64_t)T * D, gh.w = e->w_head, gh.ldw = D;
     gh.c = e->LOGITS.p + b0 * nlog, gh.ldc = nlog, gh.bias = e->b_head;
     gh.m = x.nb, gh.n = (int)nlog, gh.k = D;
-    launch_gemm_f32(gh, x.s);
+    gemm(e, gh, x.s);
     launch_action_argmax(e->LOGITS.p + b0 * nlog, actions + b0 * c.act_dim, tokens ? tokens + b0 * c.act_dim : nullptr,
                          x.nb, c.act_dim, c.n_vocab, c.n_discrete, c.action_channels, c.tok_min, c.tok_max, discrete,
                          x.s);
@@ -907,6 +964,30 @@ int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64
     g.residual = accumulate ? dev_c : nullptr;
     g.m = m, g.n = n, g.k = k;
     launch_gemm_f32(g, static_cast<hipStream_t>(stream));
+  });
+}
+
+int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
+                         const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(ldw == k, "lram_gemm_bf16x3: W must be contiguous [n, k]");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t numel = (size_t)n * k;
+    uint16_t* planes = nullptr;
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&planes), 3 * numel * sizeof(uint16_t)));
+    try {
+      launch_split_bf16x3(dev_w, planes, numel, s);
+      GemmArgs g;
+      g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
+      g.residual = accumulate ? dev_c : nullptr;
+      g.m = m, g.n = n, g.k = k, g.w3 = planes, g.w3_plane = (int64_t)numel;
+      launch_gemm_bf16x3(g, s);
+      LRAM_HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      (void)hipFree(planes);
+      throw;
+    }
+    (void)hipFree(planes);
   });
 }
 

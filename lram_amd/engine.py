@@ -60,6 +60,8 @@ _SYMBOLS = {
     "lram_profile_end": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "lram_gemm_f32": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
+    "lram_gemm_bf16x3": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_stream_copy": (ctypes.c_int32, [_VP, _VP, ctypes.c_size_t, _VP]),
 }
 
@@ -316,14 +318,16 @@ class Engine:
 
 
 def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
-             out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """out[M,N] = a[M,K] @ w[N,K]^T (+ bias) (+ out) through the library's fp32 MFMA kernel."""
+             out: Optional[torch.Tensor] = None, accumulate: bool = False, kernel: str = "f32") -> torch.Tensor:
+    """out[M,N] = a[M,K] @ w[N,K]^T (+ bias) (+ out) through the library's fp32-MFMA kernel (kernel="f32") or the
+    bf16x3 kernel (kernel="bf16x3") the engine uses for its projections."""
     lib = load_library()
+    fn = lib.lram_gemm_f32 if kernel == "f32" else lib.lram_gemm_bf16x3
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    _check(lib, lib.lram_gemm_f32(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), _ptr(bias),
+    _check(lib, fn(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), _ptr(bias),
                                   int(accumulate), M, N, K, _stream_ptr(a.device)))
     return out
 

@@ -39,6 +39,31 @@ def test_gemm_f32_matches_fp64(hip_lib, m, n, k):
     assert (out2.cpu().double() - ref2).abs().max().item() < 2e-6 * k ** 0.5 * 16
 
 
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (96, 2192, 512), (300, 80, 1536), (1000, 1408, 512),
+                                   (4096, 512, 1024), (5, 8, 8), (257, 129, 48)])
+def test_gemm_bf16x3_matches_fp64(hip_lib, m, n, k):
+    """The projection kernel (3 x bf16 split operands, 6 MFMA products) is fp32-accurate: its error against
+    fp64 stays within a small factor of the exact fp32-MFMA kernel's on the same data."""
+    from lram_amd.engine import gemm_f32
+    g = torch.Generator().manual_seed(m * 11 + n)
+    a = torch.randn(m, k, generator=g) * torch.exp(torch.randn(m, 1, generator=g))   # rows of varied scale
+    w = torch.randn(n, k, generator=g)
+    bias = torch.randn(n, generator=g)
+    ref = a.double() @ w.double().t() + bias.double()
+    scale = (a.double().abs() @ w.double().abs().t())                                # sum |a||w| per output
+    out3 = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="bf16x3")
+    out1 = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="f32")
+    torch.cuda.synchronize()
+    e3 = ((out3.cpu().double() - ref).abs() / scale).max().item()
+    e1 = ((out1.cpu().double() - ref).abs() / scale).max().item()
+    assert e3 < 1.5 * e1 + 1e-7, (m, n, k, e3, e1)   # e1: the exact fp32 fma-chain kernel on the same data
+    base = torch.randn(m, n, generator=g)
+    out2 = gemm_f32(a.cuda(), w.cuda(), None, out=base.clone().cuda(), accumulate=True, kernel="bf16x3")
+    torch.cuda.synchronize()
+    ref2 = base.double() + a.double() @ w.double().t()
+    assert ((out2.cpu().double() - ref2).abs() / (scale + 1)).max().item() < 1.5 * e1 + 1e-7
+
+
 def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=2e-4, state_tol=2e-4, spec=None):
     spec = preset(name) if spec is None else spec
     sd = init_state_dict(spec, seed=seed)
