@@ -44,7 +44,15 @@ struct GemmArgs {
   // optional: W pre-split into three bf16 planes (hi, mid, lo), each laid out like w, `w3_plane` elements apart
   const uint16_t* w3 = nullptr;
   int64_t w3_plane = 0;
+  // optional split-K workspace (un-batched GEMMs with few output tiles: skinny N or small M): partial [S][M][N]
+  // slabs are written by S x tiles workgroups and summed, in fixed order, by a second tiny kernel (deterministic)
+  float* splitk_ws = nullptr;
+  int64_t splitk_ws_elems = 0;
+  int split_k = 1;        // set by the launcher
+  int k_tiles_per_split = 0;
 };
+int gemm_choose_split_k(GemmArgs& g);                             // fills split_k / k_tiles_per_split, returns S
+void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream);  // C = sum_s ws[s] (+ bias) (+ residual)
 void launch_gemm_f32(const GemmArgs& g, hipStream_t stream);      // exact fp32 MFMA (k-ordered fma chain)
 bool gemm_bf16x3_supported(const GemmArgs& g);
 void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t stream);   // fp32-accurate, 3 x bf16 split operands

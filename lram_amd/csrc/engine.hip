@@ -94,6 +94,9 @@ struct lram_engine {
   int B = 0;
   std::vector<BlockState> st;
   DevBuf X, XN, TOK, HID, U, Q, K, V, XA, H, G, SCAL, RY, LOGITS, RES, DTP;
+  DevBuf SK;                         // split-K partial slabs: one slot per stream that may run a GEMM
+  static constexpr size_t kSplitKSlotElems = 6u << 20;  // 6 Mi floats (24 MiB) >= S*M*N for any GEMM the chooser splits
+  static constexpr int kSplitKSlots = 9;                 // caller's stream + up to 8 micro-batch streams
   size_t ucols = 0, icols = 0;  // allocated row pitch of U and of Q/K/V/XA/H/G (slice offsets use these)
   // graph replay
   bool graph_mode = false;
@@ -148,7 +151,7 @@ struct lram_engine {
       s.conv.release();
     }
     st.clear();
-    for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP}) b->release();
+    for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK}) b->release();
     B = 0;
   }
   int dh() const { return cfg.inner / cfg.n_heads; }
@@ -320,6 +323,7 @@ void state_alloc(lram_engine* e, int B) {
     s.m.zero();
     s.conv.zero();
   }
+  e->SK.alloc(lram_engine::kSplitKSlotElems * lram_engine::kSplitKSlots);
   e->X.alloc(BT * D);
   e->XN.alloc(BT * D);
   e->TOK.alloc(BT * D);
@@ -358,6 +362,13 @@ void state_alloc(lram_engine* e, int B) {
 // GEMM dispatch: bf16x3 (fp32-accurate on the bf16 matrix cores) when the weight has split planes and the shape
 // allows 16-byte bf16 loads, else the exact fp32-MFMA kernel.
 void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
+  if (e->SK.p != nullptr) {  // split-K slab slot of the stream this GEMM runs on
+    int slot = 0;
+    for (size_t i = 0; i < e->micro_streams.size() && i + 1 < (size_t)lram_engine::kSplitKSlots; ++i)
+      if (e->micro_streams[i] == s) slot = (int)i + 1;
+    g.splitk_ws = e->SK.p + (size_t)slot * lram_engine::kSplitKSlotElems;
+    g.splitk_ws_elems = (int64_t)lram_engine::kSplitKSlotElems;
+  }
   if (e->use_bf16x3) {
     auto it = e->split.find(g.w);
     if (it != e->split.end()) {

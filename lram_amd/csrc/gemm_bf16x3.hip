@@ -127,9 +127,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   const __bf16* a_base = As + (64 * wm + li) * PITCH + 8 * lh;
   const __bf16* b_base = Bs + (64 * wn + li) * PITCH + 8 * lh;
 
-  const int nk = (g.k + BK - 1) / BK;
-  load_tile(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  const int nk_all = (g.k + BK - 1) / BK;
+  const int kt0 = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
+  const int nk = g.split_k > 1 ? min(nk_all, kt0 + g.k_tiles_per_split) : nk_all;
+  load_tile(kt0 * BK);
+  for (int kt = kt0; kt < nk; ++kt) {
     store_tile();
     __syncthreads();
     if (kt + 1 < nk) load_tile((kt + 1) * BK);
@@ -160,6 +162,22 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   }
 
   // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+  if (g.split_k > 1) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
+    float* S = g.splitk_ws + (int64_t)blockIdx.z * g.m * g.n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + 64 * wn + 32 * j + li;
+        if (col >= g.n) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < g.m) S[(int64_t)row * g.n + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -198,11 +216,13 @@ bool gemm_bf16x3_supported(const GemmArgs& g) {
          ((g.sW1 | g.sW2) & 7) == 0 && ((g.sA1 | g.sA2) & 3) == 0 && (g.w3_plane & 7) == 0;
 }
 
-void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t stream) {
+void launch_gemm_bf16x3(const GemmArgs& g_in, hipStream_t stream) {
+  GemmArgs g = g_in;
+  const int S = gemm_choose_split_k(g);
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
   LRAM_REQUIRE(gemm_bf16x3_supported(g), "gemm bf16x3: K, ldw and W strides must be multiples of 8");
   const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
-  dim3 grid(tiles, g.nb1 * g.nb2);
+  dim3 grid(tiles, g.nb1 * g.nb2, S);
   dim3 block(256);
   const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
   if (hb && hr)
@@ -214,6 +234,7 @@ void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t stream) {
   else
     hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, block, 0, stream, g);
   LRAM_HIP_CHECK(hipGetLastError());
+  if (S > 1) launch_splitk_reduce(g, stream);
 }
 
 void launch_split_bf16x3(const float* w, uint16_t* out, size_t n, hipStream_t stream) {

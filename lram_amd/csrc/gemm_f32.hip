@@ -9,6 +9,8 @@
 // 32x32 accumulators (64 VGPR).  Both operands are K-contiguous, staged global -> registers -> LDS
 // (row pitch 36 floats: ds_read_b128 of 16 consecutive rows hits 16 distinct 4-bank slots), next
 // K-tile's global loads are issued before the MFMAs of the current one.
+#include <algorithm>
+
 #include "common.h"
 
 namespace lram {
@@ -87,9 +89,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const float* a_base = As + (64 * wm + li) * PITCH + 4 * lh;
   const float* b_base = Bs + (64 * wn + li) * PITCH + 4 * lh;
 
-  const int nk = (g.k + BK - 1) / BK;
-  load_tile(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  const int nk_all = (g.k + BK - 1) / BK;
+  const int kt0 = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
+  const int nk = g.split_k > 1 ? min(nk_all, kt0 + g.k_tiles_per_split) : nk_all;
+  load_tile(kt0 * BK);
+  for (int kt = kt0; kt < nk; ++kt) {
     store_tile();
     __syncthreads();
     if (kt + 1 < nk) load_tile((kt + 1) * BK);
@@ -116,6 +120,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  if (g.split_k > 1) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
+    float* S = g.splitk_ws + (int64_t)blockIdx.z * g.m * g.n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + 64 * wn + 32 * j + li;
+        if (col >= g.n) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < g.m) S[(int64_t)row * g.n + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -136,12 +156,54 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 }
 }  // namespace
 
-void launch_gemm_f32(const GemmArgs& g, hipStream_t stream) {
+namespace {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+  const int64_t total = (int64_t)g.m * g.n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / g.n), col = (int)(i - (int64_t)row * g.n);
+    float v = 0.f;
+    for (int s = 0; s < g.split_k; ++s) v += g.splitk_ws[(int64_t)s * total + i];
+    if (g.bias != nullptr) v += g.bias[col];
+    if (g.residual != nullptr) v += g.residual[(int64_t)row * g.ldc + col];
+    g.c[(int64_t)row * g.ldc + col] = v;
+  }
+}
+}  // namespace
+
+// Split-K when the output has too few 128x128 tiles to fill the 256 CUs and K is deep enough to split.
+int gemm_choose_split_k(GemmArgs& g) {
+  g.split_k = 1;
+  g.k_tiles_per_split = 0;
+  if (g.splitk_ws == nullptr || g.nb1 * g.nb2 != 1) return 1;
+  const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
+  const int nk = (g.k + BK - 1) / BK;
+  if (tiles >= 128 || nk < 4) return 1;
+  int S = std::min(std::min(nk / 2, 16), (256 + tiles - 1) / tiles);
+  while (S > 1 && (int64_t)S * g.m * g.n > g.splitk_ws_elems) --S;
+  if (S < 2) return 1;
+  const int per = (nk + S - 1) / S;
+  S = (nk + per - 1) / per;
+  if (S < 2) return 1;
+  g.split_k = S;
+  g.k_tiles_per_split = per;
+  return S;
+}
+
+void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream) {
+  const int64_t total = (int64_t)g.m * g.n;
+  const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_gemm_f32(const GemmArgs& g_in, hipStream_t stream) {
+  GemmArgs g = g_in;
+  const int S = gemm_choose_split_k(g);
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
   LRAM_REQUIRE((g.k & 3) == 0 && (g.lda & 3) == 0 && (g.ldw & 3) == 0, "gemm: K, lda, ldw must be multiples of 4");
   LRAM_REQUIRE(((g.sA1 | g.sA2 | g.sW1 | g.sW2) & 3) == 0, "gemm: batch strides of A/W must be multiples of 4");
   const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
-  dim3 grid(tiles, g.nb1 * g.nb2);
+  dim3 grid(tiles, g.nb1 * g.nb2, S);
   dim3 block(256);
   const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
   if (hb && hr)
@@ -153,6 +215,7 @@ void launch_gemm_f32(const GemmArgs& g, hipStream_t stream) {
   else
     hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, stream, g);
   LRAM_HIP_CHECK(hipGetLastError());
+  if (S > 1) launch_splitk_reduce(g, stream);
 }
 
 }  // namespace lram
