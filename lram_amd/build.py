@@ -7,7 +7,8 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["engine.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "xlstm_kernels.hip", "misc_kernels.hip", "mamba_kernels.hip"]
+SOURCES = ["engine.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "xlstm_kernels.hip", "misc_kernels.hip", "mamba_kernels.hip",
+           "selftest.hip"]
 HEADERS = ["common.h", "device_math.h", os.path.join("..", "..", "include", "lram_hip.h")]
 LIB = os.path.join(CSRC, "liblram_hip.so")
 
@@ -30,11 +31,21 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
+    # -packed-fp32-ops: no v_pk_*_f32 VALU instructions in device code.  On MI355X they return wrong results for a
+    # quarter wave when a co-resident wave of another dispatch issues bf16 MFMAs (csrc/selftest.hip); the flag is a
+    # device target feature, the host pass prints a harmless "not a recognized feature" note that is filtered here.
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
+           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print("[lram_amd.build]", " ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    proc = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+    noise = "'-packed-fp32-ops' is not a recognized feature for this target"
+    err = "\n".join(l for l in proc.stderr.splitlines() if noise not in l)
+    if err.strip():
+        print(err, file=sys.stderr)
+    if proc.returncode != 0:
+        raise subprocess.CalledProcessError(proc.returncode, cmd)
     return LIB
 
 
