@@ -47,7 +47,10 @@ def _worker(rank, world, port, total, q):
 def test_env_sharded_rollout_equals_single_process(total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + total
+    import socket
+    with socket.socket() as sk:   # a free port chosen by the OS (fixed ports collide when suites run side by side)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
     for p in procs:
         p.start()
