@@ -1,0 +1,119 @@
+"""GPU edge cases of the hot path: single env, ragged batches, every tokens-per-call count for both backbones,
+Mamba agent surface, cache-reset frequency, loud failures on misuse."""
+import pytest
+import torch
+
+from lram_amd import init_state_dict, preset
+from oracle import dt_ref, mamba_ref, xlstm_ref
+from tests.helpers import assert_actions_match, make_inputs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,B", [("xlstm_tiny", 1), ("xlstm_tiny", 3), ("mamba_tiny", 1), ("mamba_tiny", 7),
+                                    ("xlstm_tiny", 130)])
+def test_odd_batch_sizes(hip_lib, name, B):
+    from lram_amd.engine import Engine
+    spec = preset(name)
+    sd = init_state_dict(spec, seed=B)
+    eng = Engine(spec, sd, B, device="cuda:0")
+    ora = dt_ref.OraclePolicy(spec, sd)
+    for t, (obs, rtg, rew, mask) in enumerate(make_inputs(spec, B, 5, seed=B + 50)):
+        a, _ = eng.step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+        ref, dbg = ora.step(obs, rtg, rew, mask, return_debug=True)
+        torch.cuda.synchronize()
+        assert_actions_match(a, ref, dbg["logits"], spec, what=f"{name} B={B} step {t}")
+        assert rel_err(eng.taps()[1], dbg["hidden"]) < 2e-4
+    eng.close()
+
+
+def test_mamba_encoder_step_all_token_counts(hip_lib):
+    from lram_amd.engine import Engine
+    spec = preset("mamba_tiny")
+    sd = init_state_dict(spec, seed=3)
+    B = 4
+    eng = Engine(spec, sd, B, device="cuda:0")
+    state = None
+    g = torch.Generator().manual_seed(4)
+    for T in (1, 4, 2, 3):
+        x = torch.randn(B, T, spec.d_model, generator=g)
+        ref, state = mamba_ref.encoder_forward_cached(spec, sd, x, state)
+        out = eng.encoder_step(x.cuda())
+        torch.cuda.synchronize()
+        assert rel_err(out, ref) < 2e-4, T
+    pkv = eng.export_past_key_values()
+    assert rel_err(pkv[0][0], state[0][0]) < 2e-4 and rel_err(pkv[1][1], state[1][1]) < 2e-4
+    eng.close()
+
+
+def test_prefill_equals_sequential_steps(hip_lib):
+    """Context re-prime: feeding a stored trajectory through encoder_step in chunks of up to 4
+    tokens leaves the same state and last hidden as token-by-token stepping."""
+    from lram_amd.engine import Engine
+    spec = preset("xlstm_tiny")
+    sd = init_state_dict(spec, seed=8)
+    B, L = 3, 24
+    x = torch.randn(B, L, spec.d_model, generator=torch.Generator().manual_seed(1))
+    e1 = Engine(spec, sd, B, device="cuda:0")
+    e2 = Engine(spec, sd, B, device="cuda:0")
+    last1 = None
+    for i in range(0, L, 4):
+        last1 = e1.encoder_step(x[:, i:i + 4].contiguous().cuda())[:, -1]
+    for i in range(L):
+        last2 = e2.encoder_step(x[:, i:i + 1].contiguous().cuda())[:, -1]
+    torch.cuda.synchronize()
+    assert rel_err(last1, last2) < 1e-5
+    assert rel_err(e1.export_state_tensor(0, 0), e2.export_state_tensor(0, 0)) < 1e-5
+    ref, _ = xlstm_ref.encoder_forward_cached(spec, sd, x, None)
+    assert rel_err(last1, ref[:, -1]) < 2e-4
+    e1.close(), e2.close()
+
+
+def test_mamba_agent_surface_and_cache_reset_freq(hip_lib):
+    from lram_amd.agent import RecurrentAgent
+    import dataclasses
+    spec = dataclasses.replace(preset("mamba_tiny"), reset_inf_cache_freq=3)
+    sd = init_state_dict(spec, seed=12)
+    agent = RecurrentAgent(spec, sd, n_envs=1, device="cuda:0", target_return=90.0, reward_scale=10.0)
+    ora = dt_ref.OraclePolicy(spec, sd)
+    dev = agent.device
+    g = torch.Generator().manual_seed(2)
+    obs_hist = torch.rand(1, 9, generator=g).to(dev)
+    acts = torch.zeros((0, 2), device=dev)
+    rews = torch.zeros(0, device=dev)
+    rtg = torch.full((1, 1), agent.compute_target_return_val(), device=dev)
+    ts = torch.zeros((1, 1), dtype=torch.long, device=dev)
+    for t in range(8):
+        acts = torch.cat([acts, torch.zeros((1, 2), device=dev)])
+        rews = torch.cat([rews, torch.zeros(1, device=dev)])
+        a, _ = agent.predict(agent.policy, obs_hist, acts, rews, rtg, ts, env_act_dim=2, is_eval=True)
+        pad = torch.cat([obs_hist[-1].cpu(), torch.zeros(spec.state_dim - 9)]).view(1, -1)
+        ref = ora.step(pad, rtg[0, -1].cpu().view(1), torch.zeros(1))[0, :2]
+        assert float((a.cpu() - ref).abs().max()) <= 1e-4, t
+        if t > 0 and t % 3 == 0:      # decision_transformer_sb3.py:663-666: cache dropped after this step
+            ora.reset(1)
+        obs_hist = torch.cat([obs_hist, torch.rand(1, 9, generator=g).to(dev)])
+        rtg = torch.cat([rtg, rtg[:, -1:] - 0.1], dim=1)
+        ts = torch.cat([ts, torch.full((1, 1), t + 1, device=dev)], dim=1)
+    kv = agent.past_key_values
+    assert set(kv) == {0, 1} and kv[0][0].shape == (1, spec.d_inner, spec.d_conv)
+    agent.inference_params.reset()
+    assert float(agent.past_key_values[0][1].abs().max()) == 0.0
+    agent.engine.close()
+
+
+def test_misuse_is_loud(hip_lib):
+    from lram_amd.engine import Engine, LramError
+    spec = preset("xlstm_tiny")
+    eng = Engine(spec, init_state_dict(spec, 0), 2, device="cuda:0")
+    with pytest.raises(ValueError):
+        eng.encoder_step(torch.zeros(2, 5, spec.d_model).cuda()[:, ::1][:1])      # wrong batch
+    with pytest.raises(LramError):
+        eng.encoder_step(torch.zeros(2, 5, spec.d_model).cuda())                   # more than 4 tokens per call
+    with pytest.raises(ValueError):
+        eng.step(torch.zeros(2, spec.state_dim, dtype=torch.float64).cuda(), torch.zeros(2).cuda(), torch.zeros(2).cuda())
+    with pytest.raises(KeyError):
+        eng.export_state_tensor(1, 1)                                              # sLSTM block has no 'n' tensor
+    eng.close()
+    with pytest.raises(LramError):
+        eng.step(torch.zeros(2, spec.state_dim).cuda(), torch.zeros(2).cuda(), torch.zeros(2).cuda())  # closed
