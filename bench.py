@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--config", default="xlstm_16m", help="preset name (lram_amd.config.preset)")
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph")
     ap.add_argument("--micro", type=int, default=0, help="env slices pipelined on separate streams (0 = auto, 1 = off)")
+    ap.add_argument("--side-stream", action="store_true", help="issue the steps on a non-default HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -144,6 +145,10 @@ def main():
             a = ldist.all_gather_actions(a)
         return a
 
+    if args.side_stream:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(side)
     for t in range(W):
         one_step(t)
     timing = not args.no_kernel_timing and not args.graph

@@ -369,7 +369,7 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
     g.splitk_ws = e->SK.p + (size_t)slot * lram_engine::kSplitKSlotElems;
     g.splitk_ws_elems = (int64_t)lram_engine::kSplitKSlotElems;
   }
-  if (e->use_bf16x3) {
+  if (e->use_bf16x3 && !gemm_small_m(g)) {
     auto it = e->split.find(g.w);
     if (it != e->split.end()) {
       g.w3 = it->second.p;

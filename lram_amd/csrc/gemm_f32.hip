@@ -157,6 +157,68 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 }  // namespace
 
 namespace {
+// Small-M path (M <= 8: one or two envs x 3 tokens, the reference's own operating point): a tile GEMM would
+// spend a whole 128x128 MFMA tile and a serial K loop on 3 rows.  Here every wave owns two output columns, its
+// lanes stride over K with 16-byte loads of the weight rows (read exactly once, coalesced), the few activation
+// rows come from L1/L2, and a wave reduction finishes the dot products: exact fp32 fma arithmetic, ~2 dependent
+// memory round trips per launch.
+constexpr int kGemvMaxM = 8;
+constexpr int kGemvCols = 2;  // columns per wave
+
+__global__ __launch_bounds__(256) void gemv_small_m_kernel(GemmArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int z = blockIdx.y;
+  const int z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const float* A = g.a + z1 * g.sA1 + z2 * g.sA2;
+  const float* W = g.w + z1 * g.sW1 + z2 * g.sW2;
+  float* C = g.c + z1 * g.sC1 + z2 * g.sC2;
+  const float* R = g.residual ? g.residual + z1 * g.sC1 + z2 * g.sC2 : nullptr;
+  const float* bias = g.bias ? g.bias + z1 * g.sBias1 + z2 * g.sBias2 : nullptr;
+  const int n0 = (blockIdx.x * 4 + wave) * kGemvCols;
+  if (n0 >= g.n) return;
+  float acc[kGemvMaxM][kGemvCols];
+#pragma unroll
+  for (int m = 0; m < kGemvMaxM; ++m)
+#pragma unroll
+    for (int c = 0; c < kGemvCols; ++c) acc[m][c] = 0.f;
+  for (int k = lane * 4; k < g.k; k += 256) {
+    float4 w[kGemvCols];
+#pragma unroll
+    for (int c = 0; c < kGemvCols; ++c)
+      w[c] = (n0 + c < g.n) ? *reinterpret_cast<const float4*>(W + (int64_t)(n0 + c) * g.ldw + k)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < kGemvMaxM; ++m) {
+      if (m < g.m) {
+        const float4 a = *reinterpret_cast<const float4*>(A + (int64_t)m * g.lda + k);
+#pragma unroll
+        for (int c = 0; c < kGemvCols; ++c) {
+          acc[m][c] = fmaf(a.x, w[c].x, acc[m][c]);
+          acc[m][c] = fmaf(a.y, w[c].y, acc[m][c]);
+          acc[m][c] = fmaf(a.z, w[c].z, acc[m][c]);
+          acc[m][c] = fmaf(a.w, w[c].w, acc[m][c]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < kGemvMaxM; ++m) {
+    if (m < g.m) {
+#pragma unroll
+      for (int c = 0; c < kGemvCols; ++c) {
+        float v = acc[m][c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && n0 + c < g.n) {
+          if (bias) v += bias[n0 + c];
+          if (R) v += R[(int64_t)m * g.ldc + n0 + c];
+          C[(int64_t)m * g.ldc + n0 + c] = v;
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   const int64_t total = (int64_t)g.m * g.n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -196,10 +258,20 @@ void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream) {
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
+bool gemm_small_m(const GemmArgs& g) { return g.m <= kGemvMaxM; }
+
 void launch_gemm_f32(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
-  const int S = gemm_choose_split_k(g);
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
+  if (gemm_small_m(g)) {
+    LRAM_REQUIRE((g.k & 3) == 0 && (g.lda & 3) == 0 && (g.ldw & 3) == 0, "gemm: K, lda, ldw must be multiples of 4");
+    LRAM_REQUIRE(((g.sA1 | g.sA2 | g.sW1 | g.sW2) & 3) == 0, "gemm: batch strides of A/W must be multiples of 4");
+    dim3 grid((g.n + 4 * kGemvCols - 1) / (4 * kGemvCols), g.nb1 * g.nb2);
+    hipLaunchKernelGGL(gemv_small_m_kernel, grid, dim3(256), 0, stream, g);
+    LRAM_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  const int S = gemm_choose_split_k(g);
   LRAM_REQUIRE((g.k & 3) == 0 && (g.lda & 3) == 0 && (g.ldw & 3) == 0, "gemm: K, lda, ldw must be multiples of 4");
   LRAM_REQUIRE(((g.sA1 | g.sA2 | g.sW1 | g.sW2) & 3) == 0, "gemm: batch strides of A/W must be multiples of 4");
   const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);

@@ -539,9 +539,12 @@ static void launch_cell_tl(const MlstmCellArgs& a, hipStream_t s) {
 
 template <int T>
 static void launch_cell_t(const MlstmCellArgs& a, hipStream_t s) {
-  if (a.DH % 256 == 0)
+  // Few (env, head) pairs: cut the head's columns into narrower slices so that at least ~256 workgroups exist
+  // (a single env at DH = 256 gets 16 workgroups of 64 columns instead of 4 of 256).
+  const long pairs = (long)a.B * a.NH;
+  if (a.DH % 256 == 0 && pairs * (a.DH / 256) >= 256)
     launch_cell_tl<T, 64>(a, s);
-  else if (a.DH % 128 == 0)
+  else if (a.DH % 128 == 0 && pairs * (a.DH / 128) >= 256)
     launch_cell_tl<T, 32>(a, s);
   else if (a.DH % 64 == 0)
     launch_cell_tl<T, 16>(a, s);

@@ -18,7 +18,8 @@ def _engine(spec, sd, B):
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (96, 2192, 512), (300, 80, 1536), (1000, 1408, 512),
-                                   (37, 204, 204), (4096, 512, 1024), (5, 8, 4)])
+                                   (37, 204, 204), (4096, 512, 1024), (5, 8, 4), (3, 2048, 512), (6, 513, 1024),
+                                   (8, 80, 1536), (9, 80, 1536)])
 def test_gemm_f32_matches_fp64(hip_lib, m, n, k):
     from lram_amd.engine import gemm_f32
     g = torch.Generator().manual_seed(m * 7 + n)
@@ -143,9 +144,11 @@ def test_graph_replay_matches(hip_lib):
     assert _run_parity("xlstm_tiny", B=8, steps=10, seed=5, graph=True) == 0
 
 
-def test_micro_batch_pipeline_is_bit_identical(hip_lib):
-    """Env slices on separate streams (cell kernels serialised on their own stream) == one slice, bit for bit,
-    eager and under hipGraph capture, including a ragged split."""
+def test_micro_batch_pipeline_matches_single_slice(hip_lib):
+    """Env slices on separate streams (cell kernels serialised on their own stream) == one slice, eager and under
+    hipGraph capture, including ragged splits.  At this tiny batch the per-slice kernel choices (GEMV vs tile GEMM,
+    split-K, cell column slicing) differ with the slice size, so equality is to fp32 rounding; at 4096 envs it is
+    bit for bit (tests/test_gpu_fullsize.py)."""
     from lram_amd.engine import Engine
     spec = preset("xlstm_tiny")
     sd = init_state_dict(spec, seed=13)
@@ -171,8 +174,9 @@ def test_micro_batch_pipeline_is_bit_identical(hip_lib):
         outs[n] = (torch.stack(acts), torch.stack(hids), enc.clone(), eng.export_state_tensor(0, 0))
         eng.close()
     for n in (2, 3, 4):
-        for a, b in zip(outs[1], outs[n]):
-            assert torch.equal(a, b), n
+        assert torch.equal(outs[1][0], outs[n][0]), n                 # actions (argmax'ed) identical
+        for a, b in zip(outs[1][1:], outs[n][1:]):
+            assert rel_err(a, b) < 1e-4, n
 
 
 def test_rms_norm_and_ln_bias_variants(hip_lib):
