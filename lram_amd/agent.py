@@ -48,7 +48,7 @@ class RecurrentAgent:
     def __init__(self, spec: ModelSpec, state_dict: Dict[str, torch.Tensor], n_envs: int = 1, device=None,
                  discrete: bool = False, state_mean: Optional[torch.Tensor] = None,
                  state_std: Optional[torch.Tensor] = None, target_return: float = 0.0, reward_scale: float = 1.0,
-                 graph: bool = False):
+                 graph: bool = False, reprime_context: bool = False):
         self.spec = spec
         self.engine = Engine(spec, state_dict, n_envs, device)
         self.device = self.engine.device
@@ -64,6 +64,9 @@ class RecurrentAgent:
         self.eval_context_len = spec.max_length
         self.use_inference_cache = True
         self.reset_inf_cache_freq = spec.reset_inf_cache_freq
+        # reference behaviour (False): the context is dropped when the cache is reset;
+        # True: the last eval_context_len stored timesteps are fed back through Engine.prefill
+        self.reprime_context = bool(reprime_context)
         self.persist_context = False
         self.compile = False
         self.target_return_type = "predefined"
@@ -150,6 +153,14 @@ class RecurrentAgent:
             current_step = int(timesteps[0, -1])
             if current_step > 0 and current_step % self.reset_inf_cache_freq == 0:
                 self.past_key_values = None  # context is dropped, not re-primed
+                if self.reprime_context and observation.dim() == 2:
+                    n = min(int(self.eval_context_len), states.shape[1])
+                    obs_seq, _ = self._prepare_obs(states[0, -n:])
+                    rew_seq = torch.zeros(1, n, device=self.device) if rewards is None else \
+                        rewards[:, -n:, 0].to(self.device, torch.float32)
+                    self.engine.prefill(obs_seq.view(1, n, -1).contiguous(),
+                                        returns_to_go[:, -n:, 0].to(self.device, torch.float32).contiguous(),
+                                        rew_seq.contiguous(), want_action=False)
         return a1, a2
 
     @torch.no_grad()

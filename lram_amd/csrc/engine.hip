@@ -418,12 +418,15 @@ struct Slice {
 // stream capture, where it becomes a graph edge).
 void stream_after(lram_engine* e, hipStream_t dst, hipStream_t src) {
   if (dst == src) return;
-  if (e->sync_used == e->sync_events.size()) {
-    hipEvent_t ev;
-    LRAM_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    e->sync_events.push_back(ev);
+  // ring of events: a wait captures the record that precedes it at call time, so re-recording an event later
+  // (next timestep / next call) cannot disturb waits that are already enqueued
+  constexpr size_t kRing = 512;
+  if (e->sync_events.size() < kRing && e->sync_used >= e->sync_events.size()) {
+    hipEvent_t nev;
+    LRAM_HIP_CHECK(hipEventCreateWithFlags(&nev, hipEventDisableTiming));
+    e->sync_events.push_back(nev);
   }
-  hipEvent_t ev = e->sync_events[e->sync_used++];
+  hipEvent_t ev = e->sync_events[e->sync_used++ % e->sync_events.size()];
   LRAM_HIP_CHECK(hipEventRecord(ev, src));
   LRAM_HIP_CHECK(hipStreamWaitEvent(dst, ev, 0));
 }
@@ -656,45 +659,61 @@ void run_stack(lram_engine* e, int T, const uint8_t* reset, const std::vector<Sl
     run_xlstm_stack(e, T, reset, sl, hbm);
 }
 
-void step_launches(lram_engine* e, const float* obs, int emb, const float* rtg, const float* rew,
-                   const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s) {
+// L consecutive timesteps for every env slot (L = 1: one env-step).  Inputs are [B, L, .] / [B, L] row-major; the
+// reset mask applies before the first timestep; the action head runs on the last timestep only (and only if an
+// output buffer is given).  One fork / join of the slice streams brackets the whole call.
+void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* rtg, const float* rew, int L,
+                        const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s) {
   const lram_config& c = e->cfg;
   const int D = c.d_model, T = c.tokens_per_step;
+  const int64_t obs_w = emb ? D : c.state_dim;
   e->sync_used = 0;
   hipStream_t hbm;
   const std::vector<Slice> sl = make_slices(e, s, &hbm);
   const bool multi = sl.size() > 1;
   if (multi) fork_slices(e, sl, hbm, s);
-  for (const Slice& x : sl) {
-    const size_t r0 = (size_t)x.b0 * T, b0 = x.b0;
-    float* X = e->X.p + r0 * D;
-    if (emb) {
-      launch_scatter_token0(X, obs + b0 * D, x.nb, T, D, x.s);
-    } else {
-      GemmArgs ge;
-      ge.a = obs + b0 * c.state_dim, ge.lda = c.state_dim, ge.w = e->w_state, ge.ldw = c.state_dim, ge.c = X;
-      ge.ldc = (int64_t)T * D, ge.bias = e->b_state, ge.m = x.nb, ge.n = D, ge.k = c.state_dim;
-      gemm(e, ge, x.s);
+  for (int l = 0; l < L; ++l) {
+    for (const Slice& x : sl) {
+      const size_t r0 = (size_t)x.b0 * T, b0 = x.b0;
+      float* X = e->X.p + r0 * D;
+      const float* o = obs + (b0 * L + l) * obs_w;
+      if (emb) {
+        launch_scatter_token0(X, o, (int64_t)L * D, x.nb, T, D, x.s);
+      } else {
+        GemmArgs ge;
+        ge.a = o, ge.lda = (int64_t)L * c.state_dim, ge.w = e->w_state, ge.ldw = c.state_dim, ge.c = X;
+        ge.ldc = (int64_t)T * D, ge.bias = e->b_state, ge.m = x.nb, ge.n = D, ge.k = c.state_dim;
+        gemm(e, ge, x.s);
+      }
+      launch_embed_scalars(X, rtg + b0 * L + l, rew + b0 * L + l, L, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew, x.nb, T, D,
+                           x.s);
+      launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * T, D, 1e-5f, 0, x.s);
+      if (l == L - 1)
+        LRAM_HIP_CHECK(hipMemcpyAsync(e->TOK.p + r0 * D, X, sizeof(float) * (size_t)x.nb * T * D,
+                                      hipMemcpyDeviceToDevice, x.s));
     }
-    launch_embed_scalars(X, rtg + b0, rew + b0, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew, x.nb, T, D, x.s);
-    launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * T, D, 1e-5f, 0, x.s);
-    LRAM_HIP_CHECK(hipMemcpyAsync(e->TOK.p + r0 * D, X, sizeof(float) * (size_t)x.nb * T * D, hipMemcpyDeviceToDevice,
-                                  x.s));
+    run_stack(e, T, l == 0 ? reset : nullptr, sl, hbm);
   }
-  run_stack(e, T, reset, sl, hbm);
-  const int64_t nlog = (int64_t)c.act_dim * c.n_vocab;
-  for (const Slice& x : sl) {
-    const size_t r0 = (size_t)x.b0 * T, b0 = x.b0;
-    GemmArgs gh;
-    gh.a = e->HID.p + (r0 + c.pred_token) * D, gh.lda = (int64_t)T * D, gh.w = e->w_head, gh.ldw = D;
-    gh.c = e->LOGITS.p + b0 * nlog, gh.ldc = nlog, gh.bias = e->b_head;
-    gh.m = x.nb, gh.n = (int)nlog, gh.k = D;
-    gemm(e, gh, x.s);
-    launch_action_argmax(e->LOGITS.p + b0 * nlog, actions + b0 * c.act_dim, tokens ? tokens + b0 * c.act_dim : nullptr,
-                         x.nb, c.act_dim, c.n_vocab, c.n_discrete, c.action_channels, c.tok_min, c.tok_max, discrete,
-                         x.s);
+  if (actions != nullptr) {
+    const int64_t nlog = (int64_t)c.act_dim * c.n_vocab;
+    for (const Slice& x : sl) {
+      const size_t r0 = (size_t)x.b0 * T, b0 = x.b0;
+      GemmArgs gh;
+      gh.a = e->HID.p + (r0 + c.pred_token) * D, gh.lda = (int64_t)T * D, gh.w = e->w_head, gh.ldw = D;
+      gh.c = e->LOGITS.p + b0 * nlog, gh.ldc = nlog, gh.bias = e->b_head;
+      gh.m = x.nb, gh.n = (int)nlog, gh.k = D;
+      gemm(e, gh, x.s);
+      launch_action_argmax(e->LOGITS.p + b0 * nlog, actions + b0 * c.act_dim,
+                           tokens ? tokens + b0 * c.act_dim : nullptr, x.nb, c.act_dim, c.n_vocab, c.n_discrete,
+                           c.action_channels, c.tok_min, c.tok_max, discrete, x.s);
+    }
   }
   if (multi) join_slices(e, sl, hbm, s);
+}
+
+void step_launches(lram_engine* e, const float* obs, int emb, const float* rtg, const float* rew,
+                   const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s) {
+  timesteps_launches(e, obs, emb, rtg, rew, 1, reset, discrete, actions, tokens, s);
 }
 
 struct StateView {
@@ -866,6 +885,20 @@ int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding
       step_launches(e, dev_obs, obs_is_embedding, dev_rtg, dev_reward, dev_reset_mask, discrete, dev_actions,
                     dev_tokens, s);
     }
+  });
+}
+
+int32_t lram_prefill(lram_engine* e, const float* dev_obs_seq, int32_t obs_is_embedding, const float* dev_rtg_seq,
+                     const float* dev_reward_seq, int32_t timesteps, const uint8_t* dev_reset_mask, int32_t discrete,
+                     float* dev_actions, int32_t* dev_tokens, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0, "lram_prefill: state not allocated (call lram_state_alloc)");
+    LRAM_REQUIRE(dev_obs_seq && dev_rtg_seq && dev_reward_seq, "lram_prefill: null device pointer");
+    LRAM_REQUIRE(timesteps >= 1, "lram_prefill: timesteps must be >= 1");
+    LRAM_REQUIRE(e->cfg.tokens_per_step == 3, "lram_prefill: the (state, rtg, reward) front end needs tokens_per_step == 3");
+    LRAM_HIP_CHECK(hipSetDevice(e->device));
+    timesteps_launches(e, dev_obs_seq, obs_is_embedding, dev_rtg_seq, dev_reward_seq, timesteps, dev_reset_mask, discrete,
+                       dev_actions, dev_tokens, static_cast<hipStream_t>(stream));
   });
 }
 

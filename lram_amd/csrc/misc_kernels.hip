@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, 
 }
 
 __global__ __launch_bounds__(256) void embed_scalars_kernel(float* x, const float* rtg, const float* rew,
-                                                            const float* w_rtg, const float* b_rtg,
+                                                            int64_t in_stride, const float* w_rtg, const float* b_rtg,
                                                             const float* w_rew, const float* b_rew, int B, int T,
                                                             int D) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,16 +120,17 @@ __global__ __launch_bounds__(256) void embed_scalars_kernel(float* x, const floa
   const int b = (int)(gid / D);
   const int d = (int)(gid - (int64_t)b * D);
   float* row = x + (int64_t)b * T * D;
-  row[D + d] = rtg[b] * w_rtg[d] + b_rtg[d];
-  row[2 * D + d] = rew[b] * w_rew[d] + b_rew[d];
+  row[D + d] = rtg[b * in_stride] * w_rtg[d] + b_rtg[d];
+  row[2 * D + d] = rew[b * in_stride] * w_rew[d] + b_rew[d];
 }
 
-__global__ __launch_bounds__(256) void scatter_token0_kernel(float* x, const float* emb, int B, int T, int D) {
+__global__ __launch_bounds__(256) void scatter_token0_kernel(float* x, const float* emb, int64_t emb_stride, int B,
+                                                             int T, int D) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (int64_t)B * D) return;
   const int b = (int)(gid / D);
   const int d = (int)(gid - (int64_t)b * D);
-  x[(int64_t)b * T * D + d] = emb[gid];
+  x[(int64_t)b * T * D + d] = emb[(int64_t)b * emb_stride + d];
 }
 
 // One wave per (env, action dim): first index of the maximum (torch.argmax tie rule), then
@@ -219,19 +220,20 @@ void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_ou
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
-void launch_embed_scalars(float* x, const float* rtg, const float* rew, const float* w_rtg, const float* b_rtg,
-                          const float* w_rew, const float* b_rew, int B, int T, int D, hipStream_t stream) {
+void launch_embed_scalars(float* x, const float* rtg, const float* rew, int64_t in_stride, const float* w_rtg,
+                          const float* b_rtg, const float* w_rew, const float* b_rew, int B, int T, int D,
+                          hipStream_t stream) {
   LRAM_REQUIRE(T >= 3, "embed: tokens_per_step must be >= 3 (state, rtg, reward)");
   const int64_t n = (int64_t)B * D;
   hipLaunchKernelGGL(embed_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, rtg, rew,
-                     w_rtg, b_rtg, w_rew, b_rew, B, T, D);
+                     in_stride, w_rtg, b_rtg, w_rew, b_rew, B, T, D);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
-void launch_scatter_token0(float* x, const float* emb, int B, int T, int D, hipStream_t stream) {
+void launch_scatter_token0(float* x, const float* emb, int64_t emb_stride, int B, int T, int D, hipStream_t stream) {
   const int64_t n = (int64_t)B * D;
-  hipLaunchKernelGGL(scatter_token0_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, emb, B, T,
-                     D);
+  hipLaunchKernelGGL(scatter_token0_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, emb,
+                     emb_stride, B, T, D);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

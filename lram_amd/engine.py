@@ -49,6 +49,8 @@ _SYMBOLS = {
     "lram_state_bytes_per_env": (ctypes.c_int64, [_VP]),
     "lram_reset": (ctypes.c_int32, [_VP, _VP, _VP]),
     "lram_step": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, _VP, _VP, _VP, ctypes.c_int32, _VP, _VP, _VP]),
+    "lram_prefill": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, _VP, _VP, ctypes.c_int32, _VP, ctypes.c_int32, _VP, _VP,
+                                      _VP]),
     "lram_encoder_step": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, _VP, _VP, _VP]),
     "lram_get_taps": (ctypes.c_int32, [_VP, _VP, _VP, _VP, _VP]),
     "lram_state_numel": (ctypes.c_int64, [_VP, ctypes.c_int32, ctypes.c_int32]),
@@ -219,6 +221,26 @@ class Engine:
                                             _ptr(reset_mask), int(discrete), _ptr(actions), _ptr(tokens),
                                             _stream_ptr(self.device)))
         return actions, tokens
+
+    def prefill(self, obs_seq: torch.Tensor, rtg_seq: torch.Tensor, reward_seq: torch.Tensor,
+                reset_mask: Optional[torch.Tensor] = None, discrete: bool = False, obs_is_embedding: bool = False,
+                want_action: bool = True):
+        """L stored timesteps in one call ([B, L, state_dim], [B, L], [B, L]); == L sequential step() calls.
+        Returns (actions, tokens) of the last timestep (None when want_action is False)."""
+        B, spec = self.batch, self.spec
+        L = obs_seq.shape[1]
+        _chk_dev(obs_seq, torch.float32, (B, L, spec.d_model if obs_is_embedding else spec.state_dim), self.device,
+                 "obs_seq")
+        _chk_dev(rtg_seq, torch.float32, (B, L), self.device, "rtg_seq")
+        _chk_dev(reward_seq, torch.float32, (B, L), self.device, "reward_seq")
+        if reset_mask is not None:
+            _chk_dev(reset_mask, torch.uint8, (B,), self.device, "reset_mask")
+        act = self._actions if want_action else None
+        tok = self._tokens if want_action else None
+        _check(self.lib, self.lib.lram_prefill(self._h, _ptr(obs_seq), int(obs_is_embedding), _ptr(rtg_seq),
+                                               _ptr(reward_seq), int(L), _ptr(reset_mask), int(discrete), _ptr(act),
+                                               _ptr(tok), _stream_ptr(self.device)))
+        return (act, tok) if want_action else (None, None)
 
     def encoder_step(self, inputs_embeds: torch.Tensor, reset_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`self.encoder(inputs_embeds=[B,T,D], use_cache=True)` plug point (decision_xlstm.py:138-169)."""

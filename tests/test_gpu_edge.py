@@ -117,3 +117,30 @@ def test_misuse_is_loud(hip_lib):
     eng.close()
     with pytest.raises(LramError):
         eng.step(torch.zeros(2, spec.state_dim).cuda(), torch.zeros(2).cuda(), torch.zeros(2).cuda())  # closed
+
+
+@pytest.mark.parametrize("name", ["xlstm_tiny", "mamba_tiny"])
+def test_prefill_api_equals_sequential_steps(hip_lib, name):
+    """lram_prefill(L timesteps) == L lram_step calls: same final state (bit for bit) and same last action."""
+    from lram_amd.engine import Engine
+    spec = preset(name)
+    sd = init_state_dict(spec, seed=17)
+    B, L = 5, 9
+    seq = make_inputs(spec, B, L, seed=3, reset_prob=0.0)
+    obs_seq = torch.stack([x[0] for x in seq], 1).contiguous().cuda()
+    rtg_seq = torch.stack([x[1] for x in seq], 1).contiguous().cuda()
+    rew_seq = torch.stack([x[2] for x in seq], 1).contiguous().cuda()
+    e1 = Engine(spec, sd, B, device="cuda:0")
+    e2 = Engine(spec, sd, B, device="cuda:0")
+    for obs, rtg, rew, _ in seq:
+        a_seq, _ = e1.step(obs.cuda(), rtg.cuda(), rew.cuda(), None)
+    a_pre, _ = e2.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=torch.ones(B, dtype=torch.uint8).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(a_seq, a_pre)
+    for which in (0, 3):
+        assert torch.equal(e1.export_state_tensor(0, which), e2.export_state_tensor(0, which))
+    ora = dt_ref.OraclePolicy(spec, sd)
+    for obs, rtg, rew, _ in seq:
+        ref = ora.step(obs, rtg, rew)
+    assert float((a_pre.cpu() - ref).abs().max()) <= 1e-4
+    e1.close(), e2.close()
