@@ -185,6 +185,14 @@ int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64
 int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                          int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                          int32_t k, void* stream);
+/* Observation front end on the device: native obs [batch, n_native] -> model input [batch, state_dim].
+ * dev_inv_index == NULL: zero-pad (DecisionXLSTM.pad_inputs, src/algos/decision_xlstm.py:16-19); otherwise
+ * int32[state_dim] giving, per output dim, the native column it is filled from or -1 (DMControl full-space
+ * mapping, src/envs/dmcontrol_utils.py:35-59; Mimicgen, mimicgen_utils.py:190-197).  Optional fused
+ * normalisation (x - mean) / std over the padded vector (src/algos/decision_transformer_sb3.py:650-651). */
+int32_t lram_pad_obs(const float* dev_native, int32_t n_native, const int32_t* dev_inv_index, const float* dev_mean,
+                     const float* dev_std, float* dev_out, int32_t batch, int32_t state_dim, void* stream);
+
 /* Diagnostic: runs the mLSTM front-end kernel beside a bf16x3 GEMM on a second stream `iters` times and counts
  * output elements that differ from a solo run (must be 0; see lram_amd/csrc/selftest.hip for the gfx950
  * packed-fp32 / bf16-MFMA co-execution hazard this guards against). */

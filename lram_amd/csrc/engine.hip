@@ -1035,6 +1035,17 @@ int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, in
   });
 }
 
+int32_t lram_pad_obs(const float* dev_native, int32_t n_native, const int32_t* dev_inv_index, const float* dev_mean,
+                     const float* dev_std, float* dev_out, int32_t batch, int32_t state_dim, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(dev_native && dev_out && batch > 0 && state_dim > 0 && n_native > 0, "lram_pad_obs: bad argument");
+    LRAM_REQUIRE(dev_inv_index != nullptr || n_native <= state_dim, "lram_pad_obs: observation wider than state_dim");
+    LRAM_REQUIRE((dev_mean == nullptr) == (dev_std == nullptr), "lram_pad_obs: mean and std go together");
+    launch_pad_obs(dev_native, n_native, dev_inv_index, dev_mean, dev_std, dev_out, batch, state_dim,
+                   static_cast<hipStream_t>(stream));
+  });
+}
+
 int32_t lram_stream_copy(float* dev_dst, const float* dev_src, size_t numel, void* stream) {
   return guarded([&] { launch_stream_copy(dev_dst, dev_src, numel, static_cast<hipStream_t>(stream)); });
 }

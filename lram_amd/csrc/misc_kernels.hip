@@ -179,6 +179,27 @@ __global__ __launch_bounds__(256) void action_argmax_kernel(const float* logits,
   }
 }
 
+// Observation front end: native obs [B, n_native] -> model input [B, state_dim]: scatter by an index table
+// (identity = zero-pad, decision_xlstm.py:16-19; DMControl dict obs -> 204-dim full space,
+// src/envs/dmcontrol_utils.py:35-59), then optional (x - mean) / std (decision_transformer_sb3.py:650-651).
+__global__ __launch_bounds__(256) void pad_obs_kernel(const float* native, int n_native, const int32_t* index,
+                                                      const float* mean, const float* stdv, float* out, int B,
+                                                      int state_dim) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * state_dim) return;
+  const int b = (int)(gid / state_dim);
+  const int d = (int)(gid - (int64_t)b * state_dim);
+  float v = 0.f;
+  if (index == nullptr) {
+    if (d < n_native) v = native[(int64_t)b * n_native + d];
+  } else {
+    const int src = index[d];  // inverse table: source column of output dim d, or -1
+    if (src >= 0) v = native[(int64_t)b * n_native + src];
+  }
+  if (mean != nullptr) v = (v - mean[d]) / stdv[d];
+  out[gid] = v;
+}
+
 __global__ __launch_bounds__(256) void stream_copy_kernel(float4* dst, const float4* src, size_t n4) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -243,6 +264,14 @@ void launch_action_argmax(const float* logits, float* actions, int32_t* tokens, 
   const int items = B * (discrete ? 1 : act_dim);
   hipLaunchKernelGGL(action_argmax_kernel, dim3((items + 3) / 4), dim3(256), 0, stream, logits, actions, tokens, B,
                      act_dim, n_vocab, n_discrete, action_channels, tok_min, tok_max, discrete);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_pad_obs(const float* native, int n_native, const int32_t* inv_index, const float* mean, const float* stdv,
+                    float* out, int B, int state_dim, hipStream_t stream) {
+  const int64_t n = (int64_t)B * state_dim;
+  hipLaunchKernelGGL(pad_obs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, native, n_native,
+                     inv_index, mean, stdv, out, B, state_dim);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

@@ -64,6 +64,7 @@ _SYMBOLS = {
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_bf16x3": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
+    "lram_pad_obs": (ctypes.c_int32, [_VP, ctypes.c_int32, _VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_selftest_concurrent": (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]),
     "lram_stream_copy": (ctypes.c_int32, [_VP, _VP, ctypes.c_size_t, _VP]),
 }
@@ -352,6 +353,19 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     _check(lib, fn(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), _ptr(bias),
                                   int(accumulate), M, N, K, _stream_ptr(a.device)))
+    return out
+
+
+def pad_obs(native: torch.Tensor, state_dim: int, inv_index: Optional[torch.Tensor] = None,
+            mean: Optional[torch.Tensor] = None, std: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Device-side observation front end (lram_pad_obs): scatter / zero-pad to `state_dim` (+ normalise)."""
+    lib = load_library()
+    B, n = native.shape
+    if out is None:
+        out = torch.empty(B, state_dim, dtype=torch.float32, device=native.device)
+    _check(lib, lib.lram_pad_obs(_ptr(native), n, _ptr(inv_index), _ptr(mean), _ptr(std), _ptr(out), B, state_dim,
+                                 _stream_ptr(native.device)))
     return out
 
 

@@ -124,3 +124,15 @@ def test_engine_refuses_to_run_without_gpu():
     spec = preset("xlstm_tiny")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Engine(spec, init_state_dict(spec, 0), 2)
+
+
+def test_dmc_index_tables():
+    from lram_amd import obs
+    from lram_amd.rollout import CHEETAH_RUN_OBS_INDEX
+    assert obs.DMC_FULL_OBS_DIM == 204
+    st = obs.dmc_start_index()
+    assert st["velocity"] == 14 and st["position"] == 41 and st["height"] == 203   # dmcontrol_utils.py:44-49
+    inv = obs.dmc_inverse_index(obs.CHEETAH_RUN_SPEC)
+    filled = (inv >= 0).nonzero().flatten().tolist()
+    assert sorted(filled) == sorted(CHEETAH_RUN_OBS_INDEX)
+    assert inv[41].item() == 0 and inv[14].item() == 8 and inv[22].item() == 16

@@ -144,3 +144,22 @@ def test_prefill_api_equals_sequential_steps(hip_lib, name):
         ref = ora.step(obs, rtg, rew)
     assert float((a_pre.cpu() - ref).abs().max()) <= 1e-4
     e1.close(), e2.close()
+
+
+def test_device_obs_front_end(hip_lib):
+    from lram_amd import obs as lobs
+    from lram_amd.engine import pad_obs
+    g = torch.Generator().manual_seed(0)
+    native = torch.rand(37, 17, generator=g) * 2 - 1
+    inv = lobs.dmc_inverse_index(lobs.CHEETAH_RUN_SPEC)
+    mean, std = torch.randn(204, generator=g), torch.rand(204, generator=g) + 0.5
+    ref = torch.zeros(37, 204)
+    ref[:, 41:49] = native[:, :8]
+    ref[:, 14:23] = native[:, 8:]
+    out = pad_obs(native.cuda(), 204, inv.cuda(), mean.cuda(), std.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), (ref - mean) / std)
+    mw = torch.rand(5, 39, generator=g)
+    out2 = pad_obs(mw.cuda(), 204)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.cpu(), torch.cat([mw, torch.zeros(5, 165)], 1))
