@@ -25,7 +25,8 @@ struct Error : std::runtime_error {
     if (!(cond)) throw ::lram::Error(std::string("lram: ") + msg); \
   } while (0)
 
-constexpr int kMaxTokens = 4;  // tokens per env-step handled by the fused recurrent kernels
+constexpr int kMaxTokens = 12;  // tokens per launch of the fused recurrent kernels: 3 per env-step, up to 4
+                                // timesteps (12 tokens) per state pass when a stored context is prefilled
 
 // ---------------------------------------------------------------------------------------------
 // GEMM  C[M,N] = A[M,K] * W[N,K]^T  (fp32 in, fp32 MFMA accumulate), optional bias / residual.

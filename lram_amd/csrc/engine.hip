@@ -182,7 +182,7 @@ void validate_config(const lram_config& c) {
   LRAM_REQUIRE(c.backbone == LRAM_BACKBONE_XLSTM || c.backbone == LRAM_BACKBONE_MAMBA, "unknown backbone");
   LRAM_REQUIRE(c.d_model > 0 && c.d_model % 4 == 0 && c.d_model <= 2048, "d_model must be a multiple of 4, <= 2048");
   LRAM_REQUIRE(c.n_blocks > 0 && c.n_blocks <= LRAM_MAX_BLOCKS, "n_blocks out of range");
-  LRAM_REQUIRE(c.tokens_per_step >= 1 && c.tokens_per_step <= kMaxTokens, "tokens_per_step must be in 1..4");
+  LRAM_REQUIRE(c.tokens_per_step >= 1 && c.tokens_per_step <= 4, "tokens_per_step must be in 1..4");
   LRAM_REQUIRE(c.pred_token >= 0 && c.pred_token < c.tokens_per_step, "pred_token out of range");
   LRAM_REQUIRE(c.state_dim > 0 && c.state_dim % 4 == 0, "state_dim must be a positive multiple of 4");
   LRAM_REQUIRE(c.act_dim > 0 && c.n_vocab > 0 && c.n_discrete >= 0 && c.n_discrete <= c.n_vocab &&
@@ -672,34 +672,45 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   const std::vector<Slice> sl = make_slices(e, s, &hbm);
   const bool multi = sl.size() > 1;
   if (multi) fork_slices(e, sl, hbm, s);
-  for (int l = 0; l < L; ++l) {
+  // Stored context is consumed in chunks of up to 4 timesteps (12 tokens): every block then reads and writes
+  // its recurrent state once per chunk instead of once per timestep.
+  constexpr int kChunk = kMaxTokens / 3;
+  int Tc = T, last_steps = 1;
+  for (int l = 0; l < L; l += kChunk) {
+    const int Lc = std::min(kChunk, L - l);
+    Tc = T * Lc;
+    last_steps = Lc;
     for (const Slice& x : sl) {
-      const size_t r0 = (size_t)x.b0 * T, b0 = x.b0;
+      const size_t r0 = (size_t)x.b0 * Tc, b0 = x.b0;
       float* X = e->X.p + r0 * D;
-      const float* o = obs + (b0 * L + l) * obs_w;
-      if (emb) {
-        launch_scatter_token0(X, o, (int64_t)L * D, x.nb, T, D, x.s);
-      } else {
-        GemmArgs ge;
-        ge.a = o, ge.lda = (int64_t)L * c.state_dim, ge.w = e->w_state, ge.ldw = c.state_dim, ge.c = X;
-        ge.ldc = (int64_t)T * D, ge.bias = e->b_state, ge.m = x.nb, ge.n = D, ge.k = c.state_dim;
-        gemm(e, ge, x.s);
+      for (int j = 0; j < Lc; ++j) {
+        const float* o = obs + (b0 * L + l + j) * obs_w;
+        float* Xj = X + (size_t)(T * j) * D;  // token slots 3j .. 3j+2 of every env row group
+        if (emb) {
+          launch_scatter_token0(Xj, o, (int64_t)L * D, x.nb, Tc, D, x.s);
+        } else {
+          GemmArgs ge;
+          ge.a = o, ge.lda = (int64_t)L * c.state_dim, ge.w = e->w_state, ge.ldw = c.state_dim, ge.c = Xj;
+          ge.ldc = (int64_t)Tc * D, ge.bias = e->b_state, ge.m = x.nb, ge.n = D, ge.k = c.state_dim;
+          gemm(e, ge, x.s);
+        }
+        launch_embed_scalars(Xj, rtg + b0 * L + l + j, rew + b0 * L + l + j, L, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew,
+                             x.nb, Tc, D, x.s);
       }
-      launch_embed_scalars(X, rtg + b0 * L + l, rew + b0 * L + l, L, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew, x.nb, T, D,
-                           x.s);
-      launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * T, D, 1e-5f, 0, x.s);
-      if (l == L - 1)
-        LRAM_HIP_CHECK(hipMemcpyAsync(e->TOK.p + r0 * D, X, sizeof(float) * (size_t)x.nb * T * D,
+      launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s);
+      if (L == 1)  // taps (lram_get_taps) are defined for single env-steps
+        LRAM_HIP_CHECK(hipMemcpyAsync(e->TOK.p + r0 * D, X, sizeof(float) * (size_t)x.nb * Tc * D,
                                       hipMemcpyDeviceToDevice, x.s));
     }
-    run_stack(e, T, l == 0 ? reset : nullptr, sl, hbm);
+    run_stack(e, Tc, l == 0 ? reset : nullptr, sl, hbm);
   }
   if (actions != nullptr) {
     const int64_t nlog = (int64_t)c.act_dim * c.n_vocab;
+    const int pred = T * (last_steps - 1) + c.pred_token;  // rtg token of the last timestep in the last chunk
     for (const Slice& x : sl) {
-      const size_t r0 = (size_t)x.b0 * T, b0 = x.b0;
+      const size_t r0 = (size_t)x.b0 * Tc, b0 = x.b0;
       GemmArgs gh;
-      gh.a = e->HID.p + (r0 + c.pred_token) * D, gh.lda = (int64_t)T * D, gh.w = e->w_head, gh.ldw = D;
+      gh.a = e->HID.p + (r0 + pred) * D, gh.lda = (int64_t)Tc * D, gh.w = e->w_head, gh.ldw = D;
       gh.c = e->LOGITS.p + b0 * nlog, gh.ldc = nlog, gh.bias = e->b_head;
       gh.m = x.nb, gh.n = (int)nlog, gh.k = D;
       gemm(e, gh, x.s);
@@ -907,7 +918,8 @@ int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_
   return guarded([&] {
     LRAM_REQUIRE(e && e->B > 0, "lram_encoder_step: state not allocated");
     LRAM_REQUIRE(dev_inputs_embeds && dev_hidden_out, "lram_encoder_step: null device pointer");
-    LRAM_REQUIRE(tokens >= 1 && tokens <= kMaxTokens, "lram_encoder_step: tokens must be in 1..4");
+    LRAM_REQUIRE((tokens >= 1 && tokens <= 4) || tokens == 6 || tokens == 9 || tokens == 12,
+                 "lram_encoder_step: tokens must be 1..4, 6, 9 or 12");
     LRAM_HIP_CHECK(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = sizeof(float) * (size_t)e->B * tokens * e->cfg.d_model;

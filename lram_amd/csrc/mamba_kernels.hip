@@ -40,13 +40,37 @@ __global__ __launch_bounds__(256) void mamba_conv_kernel(MambaConvArgs a) {
 // owning 4 of the N = 16 states (16 B per lane, consecutive lanes consecutive addresses).  The env's B_t, C_t
 // vectors (shared by all its channels) are staged once in LDS and read back as broadcasts.
 //   dt = softplus(dt_proj(dt_raw) + dt_bias);  s = s * exp(dt * A) + x * (dt * B);  y = s . C + D x;  y *= silu(z)
-constexpr int kSsmEnvs = 4;  // envs per workgroup: amortises A = -exp(A_log) and keeps 4 state loads in flight per lane
+// same, runtime T (prefill chunks)
+__global__ __launch_bounds__(256) void mamba_conv_rt_kernel(MambaConvArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int di = a.d_inner;
+  if (gid >= (int64_t)a.B * di) return;
+  const int b = (int)(gid / di);
+  const int d = (int)(gid - (int64_t)b * di);
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+  float4 win = rs ? f4_zero() : *reinterpret_cast<const float4*>(a.conv_state + gid * 4);
+  const float4 w = *reinterpret_cast<const float4*>(a.conv_w + (int64_t)d * 4);
+  const float bias = a.conv_b != nullptr ? a.conv_b[d] : 0.f;
+  for (int t = 0; t < a.T; ++t) {
+    const int64_t row = (int64_t)b * a.T + t;
+    const float x = a.xz[row * 2 * di + d];
+    win.x = win.y;
+    win.y = win.z;
+    win.z = win.w;
+    win.w = x;
+    a.xc[row * di + d] = silu_f(win.x * w.x + win.y * w.y + win.z * w.z + win.w * w.w + bias);
+  }
+  *reinterpret_cast<float4*>(a.conv_state + gid * 4) = win;
+}
+
+// kSsmEnvs envs per workgroup (4 for an env-step: amortises A = -exp(A_log) and keeps 4 state loads in flight
+// per lane; 1 for the long prefill chunks, whose LDS staging grows with T)
 
 // One workgroup = kSsmEnvs envs x 256/Q channels (64 for N = 16).  Per-(env, token, channel) scalars x, dt =
 // softplus(.), silu(z) and the per-(env, token) vectors B, C are staged in LDS with coalesced loads (dt and the
 // gate are evaluated once per channel there, not once per lane); outputs go back through LDS so the global
 // stores are full 256-byte rows.
-template <int T>
+template <int T, int kSsmEnvs>
 __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
   __shared__ __attribute__((aligned(16))) float bc[kSsmEnvs][T][2][64];   // [env][token][B|C][n], N <= 64
   __shared__ float sc[kSsmEnvs][T][3][64];                                // x | dt | silu(z) per channel
@@ -132,7 +156,9 @@ void launch_mamba_conv(const MambaConvArgs& a, hipStream_t stream) {
     case 2: hipLaunchKernelGGL(mamba_conv_kernel<2>, grid, block, 0, stream, a); break;
     case 3: hipLaunchKernelGGL(mamba_conv_kernel<3>, grid, block, 0, stream, a); break;
     case 4: hipLaunchKernelGGL(mamba_conv_kernel<4>, grid, block, 0, stream, a); break;
-    default: throw Error("lram: tokens per step must be in 1..4");
+    default:
+      LRAM_REQUIRE(a.T >= 1 && a.T <= kMaxTokens, "tokens per launch out of range");
+      hipLaunchKernelGGL(mamba_conv_rt_kernel, grid, block, 0, stream, a);
   }
   LRAM_HIP_CHECK(hipGetLastError());
 }
@@ -141,13 +167,18 @@ void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream) {
   const int Q = a.N >> 2;
   LRAM_REQUIRE(a.N % 4 == 0 && Q >= 1 && Q <= 16 && (Q & (Q - 1)) == 0, "Mamba d_state must be 4 * 2^k, <= 64");
   const int cpb = 256 / Q;
-  dim3 grid((unsigned)((a.d_inner + cpb - 1) / cpb), (unsigned)((a.B + kSsmEnvs - 1) / kSsmEnvs)), block(256);
+  const unsigned gx = (unsigned)((a.d_inner + cpb - 1) / cpb);
+  dim3 block(256);
+  dim3 g4(gx, (unsigned)((a.B + 3) / 4)), g1(gx, (unsigned)a.B);
   switch (a.T) {
-    case 1: hipLaunchKernelGGL(mamba_ssm_kernel<1>, grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(mamba_ssm_kernel<2>, grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(mamba_ssm_kernel<3>, grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(mamba_ssm_kernel<4>, grid, block, 0, stream, a); break;
-    default: throw Error("lram: tokens per step must be in 1..4");
+    case 1: hipLaunchKernelGGL((mamba_ssm_kernel<1, 4>), g4, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((mamba_ssm_kernel<2, 4>), g4, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((mamba_ssm_kernel<3, 4>), g4, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((mamba_ssm_kernel<4, 4>), g4, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((mamba_ssm_kernel<6, 1>), g1, block, 0, stream, a); break;
+    case 9: hipLaunchKernelGGL((mamba_ssm_kernel<9, 1>), g1, block, 0, stream, a); break;
+    case 12: hipLaunchKernelGGL((mamba_ssm_kernel<12, 1>), g1, block, 0, stream, a); break;
+    default: throw Error("lram: tokens per launch must be 1..4, 6, 9 or 12");
   }
   LRAM_HIP_CHECK(hipGetLastError());
 }

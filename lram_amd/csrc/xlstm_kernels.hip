@@ -213,6 +213,156 @@ __global__ __launch_bounds__(kPreThreads) void mlstm_pre_kernel(MlstmPreArgs a) 
   }
 }
 
+// Large-T variant of the front end (context prefill: T = 3 x timesteps-per-chunk, up to kMaxTokens): the same
+// arithmetic token by token with a block reduction per token, so the register footprint does not grow with T.
+template <int NH>
+__global__ __launch_bounds__(kPreThreads) void mlstm_pre_seq_kernel(MlstmPreArgs a) {
+  __shared__ float red[4][2 * NH];
+  __shared__ float s_gi[NH], s_gf[NH], s_f[NH], s_i[NH], s_m[NH];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int inner = a.inner, T = a.T, DH = inner / NH, ngroups = inner >> 2;
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+  const float sqrt_dh = sqrtf((float)DH);
+  float4 win[kMaxGroups][4], nst[kMaxGroups];
+#pragma unroll
+  for (int g = 0; g < kMaxGroups; ++g) {
+    const int cg = tid + g * kPreThreads;
+    const int c0 = cg << 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      win[g][k] = (rs || cg >= ngroups) ? f4_zero()
+                                        : *reinterpret_cast<const float4*>(a.conv_state + ((int64_t)b * 4 + k) * inner + c0);
+    nst[g] = (rs || cg >= ngroups) ? f4_zero() : *reinterpret_cast<const float4*>(a.n_state + (int64_t)b * inner + c0);
+  }
+  if (tid < NH) s_m[tid] = rs ? 0.f : a.m_state[(int64_t)b * NH + tid];
+  auto dot = [](const float4& x, const float4& y) { return x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; };
+  for (int t = 0; t < T; ++t) {
+    const int64_t row = (int64_t)b * T + t;
+    float pi[NH], pf[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) pi[h] = pf[h] = 0.f;
+    float4 qg[kMaxGroups], kg[kMaxGroups];
+#pragma unroll
+    for (int g = 0; g < kMaxGroups; ++g) {
+      const int cg = tid + g * kPreThreads;
+      qg[g] = kg[g] = f4_zero();
+      if (cg < ngroups) {
+        const int c0 = cg << 2;
+        const float4 xm = *reinterpret_cast<const float4*>(a.u + row * 2 * inner + c0);
+        win[g][0] = win[g][1];
+        win[g][1] = win[g][2];
+        win[g][2] = win[g][3];
+        win[g][3] = xm;
+        float4 cw[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cw[c] = *reinterpret_cast<const float4*>(a.conv_w + (int64_t)(c0 + c) * 4);
+        const float4 cb = *reinterpret_cast<const float4*>(a.conv_b + c0);
+        float4 y;
+        y.x = win[g][0].x * cw[0].x + win[g][1].x * cw[0].y + win[g][2].x * cw[0].z + win[g][3].x * cw[0].w + cb.x;
+        y.y = win[g][0].y * cw[1].x + win[g][1].y * cw[1].y + win[g][2].y * cw[1].z + win[g][3].y * cw[1].w + cb.y;
+        y.z = win[g][0].z * cw[2].x + win[g][1].z * cw[2].y + win[g][2].z * cw[2].z + win[g][3].z * cw[2].w + cb.z;
+        y.w = win[g][0].w * cw[3].x + win[g][1].w * cw[3].y + win[g][2].w * cw[3].z + win[g][3].w * cw[3].w + cb.w;
+        const float4 xa = make_float4(silu_f(y.x), silu_f(y.y), silu_f(y.z), silu_f(y.w));
+        float4 q, k, v;
+        {
+          const float4* wq = reinterpret_cast<const float4*>(a.wq + (int64_t)cg * 16);
+          const float4* wk = reinterpret_cast<const float4*>(a.wk + (int64_t)cg * 16);
+          const float4* wv = reinterpret_cast<const float4*>(a.wv + (int64_t)cg * 16);
+          q = make_float4(dot(wq[0], xa), dot(wq[1], xa), dot(wq[2], xa), dot(wq[3], xa));
+          k = make_float4(dot(wk[0], xa), dot(wk[1], xa), dot(wk[2], xa), dot(wk[3], xa));
+          v = make_float4(dot(wv[0], xm), dot(wv[1], xm), dot(wv[2], xm), dot(wv[3], xm));
+        }
+        *reinterpret_cast<float4*>(a.q + row * inner + c0) = q;
+        *reinterpret_cast<float4*>(a.k + row * inner + c0) = k;
+        *reinterpret_cast<float4*>(a.v + row * inner + c0) = v;
+        *reinterpret_cast<float4*>(a.xa + row * inner + c0) = xa;
+        qg[g] = q;
+        kg[g] = k;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          const float* wi = a.wi + (int64_t)h * 3 * inner + c0;
+          const float* wf = a.wf + (int64_t)h * 3 * inner + c0;
+          pi[h] += dot(*reinterpret_cast<const float4*>(wi), q) + dot(*reinterpret_cast<const float4*>(wi + inner), k) +
+                   dot(*reinterpret_cast<const float4*>(wi + 2 * inner), v);
+          pf[h] += dot(*reinterpret_cast<const float4*>(wf), q) + dot(*reinterpret_cast<const float4*>(wf + inner), k) +
+                   dot(*reinterpret_cast<const float4*>(wf + 2 * inner), v);
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float si = wave_sum(pi[h]), sf = wave_sum(pf[h]);
+      if (lane == 0) {
+        red[wave][2 * h] = si;
+        red[wave][2 * h + 1] = sf;
+      }
+    }
+    __syncthreads();
+    if (tid < NH) {
+      const int h = tid;
+      const float gi = red[0][2 * h] + red[1][2 * h] + red[2][2 * h] + red[3][2 * h] + a.bi[h];
+      const float gf = red[0][2 * h + 1] + red[1][2 * h + 1] + red[2][2 * h + 1] + red[3][2 * h + 1] + a.bf[h];
+      const float m = s_m[h];
+      const float lf = log_sigmoid(gf);
+      const float mn = fmaxf(lf + m, gi);
+      s_f[h] = expf(lf + m - mn);
+      s_i[h] = expf(gi - mn);
+      s_m[h] = mn;
+    }
+    __syncthreads();
+    float pq[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) pq[h] = 0.f;
+#pragma unroll
+    for (int g = 0; g < kMaxGroups; ++g) {
+      const int cg = tid + g * kPreThreads;
+      if (cg < ngroups) {
+        const int hh = (cg << 2) / DH;
+        float f = 0.f, i = 0.f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          if (h == hh) {
+            f = s_f[h];
+            i = s_i[h];
+          }
+        float4& n = nst[g];
+        n.x = f * n.x + i * (kg[g].x / sqrt_dh);
+        n.y = f * n.y + i * (kg[g].y / sqrt_dh);
+        n.z = f * n.z + i * (kg[g].z / sqrt_dh);
+        n.w = f * n.w + i * (kg[g].w / sqrt_dh);
+        const float d = dot(qg[g], n);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) pq[h] += (h == hh) ? d : 0.f;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float sq = wave_sum(pq[h]);
+      if (lane == 0) red[wave][h] = sq;   // slots [0, NH) of red are free again: gates were consumed above
+    }
+    __syncthreads();
+    if (tid < NH) {
+      const int h = tid;
+      const float qn = red[0][h] + red[1][h] + red[2][h] + red[3][h];
+      const float denom = fmaxf(fabsf(qn), expf(-s_m[h])) + 1e-6f;
+      *reinterpret_cast<float4*>(a.scal + (row * NH + h) * 4) = make_float4(s_f[h], s_i[h], denom, s_m[h]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int g = 0; g < kMaxGroups; ++g) {
+    const int cg = tid + g * kPreThreads;
+    if (cg < ngroups) {
+      const int c0 = cg << 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<float4*>(a.conv_state + ((int64_t)b * 4 + k) * inner + c0) = win[g][k];
+      *reinterpret_cast<float4*>(a.n_state + (int64_t)b * inner + c0) = nst[g];
+    }
+  }
+  if (tid < NH) a.m_state[(int64_t)b * NH + tid] = s_m[tid];
+}
+
 // =============================================================================================
 // mLSTM cell: C_t = f_t C_{t-1} + i_t (k_t/sqrt(DH)) v_t^T ;  h_t = (q_t^T C_t) / denom_t   for t = 1..T
 // One workgroup per (env, head, column slice of CW = 4*LPR columns).  Each lane owns 4 adjacent columns
@@ -427,6 +577,46 @@ __global__ __launch_bounds__(256) void slstm_conv_kernel(SlstmConvArgs a) {
   }
 }
 
+// same, runtime T (prefill chunks)
+__global__ __launch_bounds__(256) void slstm_conv_rt_kernel(SlstmConvArgs a) {
+  const int ngroups = a.D >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)a.B * ngroups) return;
+  const int b = (int)(gid / ngroups);
+  const int c0 = (int)(gid - (int64_t)b * ngroups) << 2;
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+  const int D = a.D;
+  float4 win[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    win[k] = rs ? f4_zero() : *reinterpret_cast<const float4*>(a.conv_state + ((int64_t)b * 4 + k) * D + c0);
+  float4 cw[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) cw[c] = *reinterpret_cast<const float4*>(a.conv_w + (int64_t)(c0 + c) * 4);
+  const float4 cb = *reinterpret_cast<const float4*>(a.conv_b + c0);
+  for (int t = 0; t < a.T; ++t) {
+    const int64_t row = (int64_t)b * a.T + t;
+    const float4 x = *reinterpret_cast<const float4*>(a.xn + row * D + c0);
+    win[0] = win[1];
+    win[1] = win[2];
+    win[2] = win[3];
+    win[3] = x;
+    float4 y;
+    y.x = win[0].x * cw[0].x + win[1].x * cw[0].y + win[2].x * cw[0].z + win[3].x * cw[0].w + cb.x;
+    y.y = win[0].y * cw[1].x + win[1].y * cw[1].y + win[2].y * cw[1].z + win[3].y * cw[1].w + cb.y;
+    y.z = win[0].z * cw[2].x + win[1].z * cw[2].y + win[2].z * cw[2].z + win[3].z * cw[2].w + cb.z;
+    y.w = win[0].w * cw[3].x + win[1].w * cw[3].y + win[2].w * cw[3].z + win[3].w * cw[3].w + cb.w;
+    *reinterpret_cast<float4*>(a.xc + row * D + c0) = make_float4(silu_f(y.x), silu_f(y.y), silu_f(y.z), silu_f(y.w));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(a.conv_state + ((int64_t)b * 4 + k) * D + c0) = win[k];
+  if (rs) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      *reinterpret_cast<float4*>(a.slstm_state + ((int64_t)s * a.state_B + b) * D + c0) = f4_zero();
+  }
+}
+
 // sLSTM pointwise cell update for token t ([3P] slstm_pointwise: per-element n == 0 first-step rule).
 __global__ __launch_bounds__(256) void slstm_pointwise_kernel(SlstmPointwiseArgs a) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -502,7 +692,17 @@ void launch_mlstm_pre(const MlstmPreArgs& a, hipStream_t stream) {
     case 2: launch_pre_t<2>(a, stream); break;
     case 3: launch_pre_t<3>(a, stream); break;
     case 4: launch_pre_t<4>(a, stream); break;
-    default: throw Error("lram: tokens per step must be in 1..4");
+    default: {
+      LRAM_REQUIRE(a.T >= 1 && a.T <= kMaxTokens, "tokens per launch out of range");
+      dim3 grid(a.B), block(kPreThreads);
+      switch (a.NH) {
+        case 1: hipLaunchKernelGGL(mlstm_pre_seq_kernel<1>, grid, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(mlstm_pre_seq_kernel<2>, grid, block, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(mlstm_pre_seq_kernel<4>, grid, block, 0, stream, a); break;
+        case 8: hipLaunchKernelGGL(mlstm_pre_seq_kernel<8>, grid, block, 0, stream, a); break;
+        default: throw Error("lram: mLSTM num_heads must be 1, 2, 4 or 8");
+      }
+    }
   }
   LRAM_HIP_CHECK(hipGetLastError());
 }
@@ -558,7 +758,10 @@ void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream) {
     case 2: launch_cell_t<2>(a, stream); break;
     case 3: launch_cell_t<3>(a, stream); break;
     case 4: launch_cell_t<4>(a, stream); break;
-    default: throw Error("lram: tokens per step must be in 1..4");
+    case 6: launch_cell_t<6>(a, stream); break;
+    case 9: launch_cell_t<9>(a, stream); break;
+    case 12: launch_cell_t<12>(a, stream); break;
+    default: throw Error("lram: tokens per launch must be 1..4, 6, 9 or 12");
   }
   LRAM_HIP_CHECK(hipGetLastError());
 }
@@ -578,7 +781,9 @@ void launch_slstm_conv(const SlstmConvArgs& a, hipStream_t stream) {
     case 2: hipLaunchKernelGGL(slstm_conv_kernel<2>, grid, block, 0, stream, a); break;
     case 3: hipLaunchKernelGGL(slstm_conv_kernel<3>, grid, block, 0, stream, a); break;
     case 4: hipLaunchKernelGGL(slstm_conv_kernel<4>, grid, block, 0, stream, a); break;
-    default: throw Error("lram: tokens per step must be in 1..4");
+    default:
+      LRAM_REQUIRE(a.T >= 1 && a.T <= kMaxTokens, "tokens per launch out of range");
+      hipLaunchKernelGGL(slstm_conv_rt_kernel, grid, block, 0, stream, a);
   }
   LRAM_HIP_CHECK(hipGetLastError());
 }
