@@ -27,6 +27,7 @@ struct Error : std::runtime_error {
 
 constexpr int kMaxTokens = 12;  // tokens per launch of the fused recurrent kernels: 3 per env-step, up to 4
                                 // timesteps (12 tokens) per state pass when a stored context is prefilled
+constexpr int kChunkMaxTokens = 64;  // tokens per state pass of the chunkwise (matrix-core) mLSTM prefill kernels
 
 // ---------------------------------------------------------------------------------------------
 // GEMM  C[M,N] = A[M,K] * W[N,K]^T  (fp32 in, fp32 MFMA accumulate), optional bias / residual.
@@ -109,8 +110,15 @@ struct MlstmPreArgs {
   float* scal;           // [B*T, NH, 4] out  (f_t, i_t, denom_t, m_t)
   const uint8_t* reset;  // [B] or null
   int B, T, inner, NH, K;
+  // chunkwise prefill (T > kMaxTokens) only, see mlstm_chunk.hip
+  float* gates = nullptr;  // [B*T, NH, 2] out  raw (i~, f~) gate pre-activations
+  float* amat = nullptr;   // [B, NH, 64, 64] out  intra-chunk weights A[t][s]
+  float* vec = nullptr;    // [B, NH, 3, 64] out   fcum_t | w_s | denom_t
 };
 void launch_mlstm_pre(const MlstmPreArgs& a, hipStream_t stream);
+// chunkwise path: front end + gate scan / A matrix (two launches), then the cell contraction
+bool mlstm_chunk_supported(int inner, int NH, int K);
+void launch_mlstm_chunk_pre(const MlstmPreArgs& a, hipStream_t stream);
 
 struct MlstmCellArgs {
   float* C;            // [B, NH, DH, DH] in/out
@@ -123,8 +131,11 @@ struct MlstmCellArgs {
   int B, T, NH, DH;
   int unroll = 8;         // rows in flight per thread (8 or 16)
   int min_lds_bytes = 0;  // > 0: request at least this much LDS per workgroup (occupancy cap, see launcher)
+  const float* amat = nullptr;  // chunkwise prefill only (written by launch_mlstm_chunk_pre)
+  const float* vec = nullptr;
 };
 void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream);
+void launch_mlstm_chunk_cell(const MlstmCellArgs& a, hipStream_t stream);
 
 // mode 0 (mLSTM): out[r, hd] = (GN(h)[r,hd] * gamma + skip*xa) * silu(z)      z = u[r, inner + hd]
 // mode 1 (sLSTM): x[r, hd] += GN(h)[r,hd] * gamma

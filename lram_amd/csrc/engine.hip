@@ -94,6 +94,9 @@ struct lram_engine {
   int B = 0;
   std::vector<BlockState> st;
   DevBuf X, XN, TOK, HID, U, Q, K, V, XA, H, G, SCAL, RY, LOGITS, RES, DTP;
+  DevBuf GATES, AMAT, VEC;           // chunkwise mLSTM prefill work buffers (allocated with the first long chunk)
+  int tok_cap = 0;                   // tokens per env the activation workspace holds (kMaxTokens until a prefill grows it)
+  bool chunk_prefill = true;         // LRAM_PREFILL_CHUNK=0: keep the token-sequential kernels for prefill
   DevBuf SK;                         // split-K partial slabs: one slot per stream that may run a GEMM
   static constexpr size_t kSplitKSlotElems = 6u << 20;  // 6 Mi floats (24 MiB) >= S*M*N for any GEMM the chooser splits
   static constexpr int kSplitKSlots = 9;                 // caller's stream + up to 8 micro-batch streams
@@ -151,8 +154,11 @@ struct lram_engine {
       s.conv.release();
     }
     st.clear();
-    for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK}) b->release();
+    for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
+                      &AMAT, &VEC})
+      b->release();
     B = 0;
+    tok_cap = 0;
   }
   int dh() const { return cfg.inner / cfg.n_heads; }
   int sdh() const { return cfg.d_model / cfg.n_heads; }
@@ -294,41 +300,25 @@ void finalize(lram_engine* e) {
   e->finalized = true;
 }
 
-void state_alloc(lram_engine* e, int B) {
-  LRAM_REQUIRE(e->finalized, "lram_finalize must be called before lram_state_alloc");
-  LRAM_REQUIRE(B > 0 && B <= 65535, "batch must be in 1..65535");
-  LRAM_HIP_CHECK(hipSetDevice(e->device));
-  e->drop_graph();
-  e->release_state();
+// Activation workspace for `tokens` tokens per env slot (rows b * T + t of every buffer).
+size_t workspace_floats_per_token(const lram_config& c) {
+  const size_t D = c.d_model;
+  if (c.backbone == LRAM_BACKBONE_MAMBA) return 5 * D + 4 * (size_t)c.d_inner + c.dt_rank + 2 * c.d_state + (size_t)c.d_inner;
+  const size_t inner = c.inner;
+  const size_t ucols = std::max<size_t>(std::max<size_t>(2 * inner, 4 * D), 2 * (size_t)c.ffn_dim);
+  const size_t icols = std::max<size_t>(std::max<size_t>(inner, D), (size_t)c.ffn_dim);
+  return 4 * D + ucols + 6 * icols + 6 * (size_t)c.n_heads;
+}
+
+void alloc_workspace(lram_engine* e, int tokens) {
   const lram_config& c = e->cfg;
-  const size_t D = c.d_model, BT = (size_t)B * kMaxTokens;
-  e->st.resize(c.n_blocks);
-  for (int i = 0; i < c.n_blocks; ++i) {
-    BlockState& s = e->st[i];
-    if (c.backbone == LRAM_BACKBONE_MAMBA) {
-      s.s0.alloc((size_t)B * c.d_inner * c.d_state);
-      s.conv.alloc((size_t)B * c.d_inner * c.d_conv);
-    } else if (c.block_is_slstm[i]) {
-      s.s0.alloc(4 * (size_t)B * D);
-      s.conv.alloc((size_t)B * c.conv_k * D);
-    } else {
-      const size_t DH = e->dh();
-      s.s0.alloc((size_t)B * c.n_heads * DH * DH);
-      s.n.alloc((size_t)B * c.inner);
-      s.m.alloc((size_t)B * c.n_heads);
-      s.conv.alloc((size_t)B * c.conv_k * c.inner);
-    }
-    s.s0.zero();
-    s.n.zero();
-    s.m.zero();
-    s.conv.zero();
-  }
+  const size_t B = e->B, D = c.d_model, BT = B * (size_t)tokens;
   e->SK.alloc(lram_engine::kSplitKSlotElems * lram_engine::kSplitKSlots);
   e->X.alloc(BT * D);
   e->XN.alloc(BT * D);
   e->TOK.alloc(BT * D);
   e->HID.alloc(BT * D);
-  e->LOGITS.alloc((size_t)B * c.act_dim * c.n_vocab);
+  e->LOGITS.alloc(B * c.act_dim * c.n_vocab);
   if (c.backbone == LRAM_BACKBONE_MAMBA) {
     const size_t di = c.d_inner;
     e->RES.alloc(BT * D);
@@ -350,10 +340,76 @@ void state_alloc(lram_engine* e, int B) {
     e->H.alloc(BT * icols);
     e->G.alloc(BT * icols);
     e->SCAL.alloc(BT * c.n_heads * 4);
-    e->RY.alloc((size_t)B * 4 * D);
+    e->RY.alloc(B * 4 * D);
+    if (tokens > kMaxTokens) {
+      e->GATES.alloc(BT * c.n_heads * 2);
+      e->AMAT.alloc(B * c.n_heads * kChunkMaxTokens * kChunkMaxTokens);
+      e->VEC.alloc(B * c.n_heads * 3 * kChunkMaxTokens);
+    }
   }
-  LRAM_HIP_CHECK(hipDeviceSynchronize());
+  e->tok_cap = tokens;
+}
+
+// Timesteps per state pass for a stored context of L timesteps.  xLSTM geometries the chunkwise kernels cover
+// take up to 21 timesteps (63 tokens) per pass, in equal chunks; everything else 4 (the token-sequential kernels).
+// Grows the activation workspace on first use when the device has room for it.
+int prefill_chunk_steps(lram_engine* e, int L) {
+  const lram_config& c = e->cfg;
+  const int T = c.tokens_per_step;
+  const int seq = kMaxTokens / T;
+  if (!e->chunk_prefill || c.backbone != LRAM_BACKBONE_XLSTM || L <= seq || e->graph_mode ||
+      !mlstm_chunk_supported(c.inner, c.n_heads, c.conv_k))
+    return seq;
+  const int max_steps = kChunkMaxTokens / T;
+  const int n_chunks = (L + max_steps - 1) / max_steps;
+  const int steps = (L + n_chunks - 1) / n_chunks;
+  if (steps * T <= kMaxTokens) return seq;
+  if (steps * T > e->tok_cap) {
+    LRAM_HIP_CHECK(hipDeviceSynchronize());
+    size_t free_b = 0, total_b = 0;
+    LRAM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    const size_t have = workspace_floats_per_token(c) * 4 * (size_t)e->B * e->tok_cap;
+    const size_t want = workspace_floats_per_token(c) * 4 * (size_t)e->B * kChunkMaxTokens +
+                        (size_t)e->B * c.n_heads * (kChunkMaxTokens + 3) * kChunkMaxTokens * 4;
+    if (want > have + free_b - std::min<size_t>(free_b, (size_t)2 << 30)) return seq;  // keep 2 GiB of headroom
+    alloc_workspace(e, kChunkMaxTokens);
+    LRAM_HIP_CHECK(hipDeviceSynchronize());
+  }
+  return steps;
+}
+
+void state_alloc(lram_engine* e, int B) {
+  LRAM_REQUIRE(e->finalized, "lram_finalize must be called before lram_state_alloc");
+  LRAM_REQUIRE(B > 0 && B <= 65535, "batch must be in 1..65535");
+  LRAM_HIP_CHECK(hipSetDevice(e->device));
+  e->drop_graph();
+  e->release_state();
+  const lram_config& c = e->cfg;
+  const size_t D = c.d_model;
+  e->st.resize(c.n_blocks);
+  for (int i = 0; i < c.n_blocks; ++i) {
+    BlockState& s = e->st[i];
+    if (c.backbone == LRAM_BACKBONE_MAMBA) {
+      s.s0.alloc((size_t)B * c.d_inner * c.d_state);
+      s.conv.alloc((size_t)B * c.d_inner * c.d_conv);
+    } else if (c.block_is_slstm[i]) {
+      s.s0.alloc(4 * (size_t)B * D);
+      s.conv.alloc((size_t)B * c.conv_k * D);
+    } else {
+      const size_t DH = e->dh();
+      s.s0.alloc((size_t)B * c.n_heads * DH * DH);
+      s.n.alloc((size_t)B * c.inner);
+      s.m.alloc((size_t)B * c.n_heads);
+      s.conv.alloc((size_t)B * c.conv_k * c.inner);
+    }
+    s.s0.zero();
+    s.n.zero();
+    s.m.zero();
+    s.conv.zero();
+  }
   e->B = B;
+  alloc_workspace(e, kMaxTokens);
+  LRAM_HIP_CHECK(hipDeviceSynchronize());
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -489,6 +545,12 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   pa.xa = e->XA.p + r0 * e->icols;
   pa.scal = e->SCAL.p + r0 * NH * 4, pa.reset = reset ? reset + b0 : nullptr;
   pa.B = sl.nb, pa.T = T, pa.inner = inner, pa.NH = NH, pa.K = c.conv_k;
+  if (T > kMaxTokens) {
+    LRAM_REQUIRE(T <= e->tok_cap && e->AMAT.p != nullptr, "chunkwise prefill workspace not allocated");
+    pa.gates = e->GATES.p + r0 * NH * 2;
+    pa.amat = e->AMAT.p + b0 * NH * kChunkMaxTokens * kChunkMaxTokens;
+    pa.vec = e->VEC.p + b0 * NH * 3 * kChunkMaxTokens;
+  }
   launch_mlstm_pre(pa, sl.s);
 }
 
@@ -506,6 +568,10 @@ void mlstm_cell(lram_engine* e, int i, int T, const uint8_t* reset, const Slice&
   const long wgs = (long)sl.nb * NH * ((DH % 256 == 0) ? DH / 256 : (DH % 128 == 0) ? DH / 128 : DH / 64);
   ca.min_lds_bytes = e->cell_lds_pad >= 0 ? e->cell_lds_pad : (wgs >= 1024 ? 84 * 1024 : 0);
   ca.unroll = e->cell_unroll;
+  if (T > kMaxTokens) {
+    ca.amat = e->AMAT.p + b0 * NH * kChunkMaxTokens * kChunkMaxTokens;
+    ca.vec = e->VEC.p + b0 * NH * 3 * kChunkMaxTokens;
+  }
   prof_record(e, s, true);
   launch_mlstm_cell(ca, s);
   prof_record(e, s, false);
@@ -668,13 +734,14 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   const int D = c.d_model, T = c.tokens_per_step;
   const int64_t obs_w = emb ? D : c.state_dim;
   e->sync_used = 0;
+  // Stored context is consumed in chunks: every block then reads and writes its recurrent state once per chunk
+  // instead of once per timestep.  Up to 4 timesteps (12 tokens) per chunk through the token-sequential kernels,
+  // up to 21 (63 tokens) through the chunkwise matrix-core kernels (mlstm_chunk.hip).
+  const int kChunk = L > 1 ? prefill_chunk_steps(e, L) : 1;
   hipStream_t hbm;
   const std::vector<Slice> sl = make_slices(e, s, &hbm);
   const bool multi = sl.size() > 1;
   if (multi) fork_slices(e, sl, hbm, s);
-  // Stored context is consumed in chunks of up to 4 timesteps (12 tokens): every block then reads and writes
-  // its recurrent state once per chunk instead of once per timestep.
-  constexpr int kChunk = kMaxTokens / 3;
   int Tc = T, last_steps = 1;
   for (int l = 0; l < L; l += kChunk) {
     const int Lc = std::min(kChunk, L - l);
@@ -783,6 +850,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     e->device = device;
     if (const char* v = std::getenv("LRAM_CELL_LDS_PAD_KB")) e->cell_lds_pad = std::atoi(v) * 1024;
     if (const char* v = std::getenv("LRAM_CELL_UNROLL")) e->cell_unroll = std::atoi(v);
+    if (const char* v = std::getenv("LRAM_PREFILL_CHUNK")) e->chunk_prefill = std::atoi(v) != 0;
     *out = e.release();
   });
 }
@@ -918,9 +986,18 @@ int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_
   return guarded([&] {
     LRAM_REQUIRE(e && e->B > 0, "lram_encoder_step: state not allocated");
     LRAM_REQUIRE(dev_inputs_embeds && dev_hidden_out, "lram_encoder_step: null device pointer");
-    LRAM_REQUIRE((tokens >= 1 && tokens <= 4) || tokens == 6 || tokens == 9 || tokens == 12,
-                 "lram_encoder_step: tokens must be 1..4, 6, 9 or 12");
+    const bool chunk_ok = e->cfg.backbone == LRAM_BACKBONE_XLSTM && e->chunk_prefill && !e->graph_mode &&
+                          mlstm_chunk_supported(e->cfg.inner, e->cfg.n_heads, e->cfg.conv_k);
+    LRAM_REQUIRE((tokens >= 1 && tokens <= 4) || tokens == 6 || tokens == 9 || tokens == 12 ||
+                     (chunk_ok && tokens > kMaxTokens && tokens <= kChunkMaxTokens),
+                 "lram_encoder_step: tokens must be 1..4, 6, 9 or 12 (13..64 too on xLSTM geometries with a head dim "
+                 "that is a multiple of 128)");
     LRAM_HIP_CHECK(hipSetDevice(e->device));
+    if (tokens > e->tok_cap) {
+      LRAM_HIP_CHECK(hipDeviceSynchronize());
+      alloc_workspace(e, kChunkMaxTokens);
+      LRAM_HIP_CHECK(hipDeviceSynchronize());
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = sizeof(float) * (size_t)e->B * tokens * e->cfg.d_model;
     LRAM_HIP_CHECK(hipMemcpyAsync(e->X.p, dev_inputs_embeds, bytes, hipMemcpyDeviceToDevice, s));

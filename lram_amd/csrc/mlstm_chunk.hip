@@ -1,0 +1,519 @@
+// Chunkwise mLSTM for context prefill on gfx950: L <= 64 tokens of one env per state pass, on the fp32 matrix
+// cores.
+//
+// The recurrence the step kernels apply token by token ([3P] recurrent_step_stabilized_simple, SURVEY.md 3.4;
+// reference call site src/algos/models/decision_xlstm.py:138-169 with `chunkwise_step`, :110,158-159)
+//     C_t = f_t C_{t-1} + i_t khat_t v_t^T ,   h_t = q_t^T C_t / den_t ,   khat = k / sqrt(DH)
+// with the stabilised per-token factors f_t = exp(logsig(f~_t) + m_{t-1} - m_t) <= 1, i_t = exp(i~_t - m_t) <= 1
+// unrolls over a chunk of T tokens into three dense contractions (all factors are products of numbers <= 1, so
+// nothing can overflow and no extra stabiliser is needed):
+//     A[t][s] = (f_{s+1} ... f_t) i_s (q_t . khat_s)          s <= t          intra-chunk weights
+//     H       = diag(fcum) Q C_0 + A V                          fcum_t = f_0 ... f_t
+//     C_T     = fcum_{T-1} C_0 + (diag(w) Khat)^T V             w_s = (f_{s+1} ... f_{T-1}) i_s
+//     q_t.n_t = fcum_t (q_t . n_0) + sum_s A[t][s]              (the normaliser is the v == 1 column of C)
+// The matrix memory is read and written once per chunk of up to 21 timesteps instead of once per 4 (the
+// token-sequential kernels of xlstm_kernels.hip), and the work is `v_mfma_f32_32x32x2_f32` (exact fp32 products,
+// fp32 accumulation) instead of VALU fma chains.  Same inputs, same state layout, results equal to the
+// token-by-token kernels up to fp32 summation order (tests/test_gpu_parity.py::test_chunkwise_prefill_*).
+//
+// Three launches per block and chunk:
+//   mlstm_pre_tok_kernel    (env, token)       conv / q,k,v / gate pre-activations, token-parallel
+//   mlstm_chunk_scan_kernel (env, head)        gate scan, A (MFMA), denominators, n / m / conv state
+//   mlstm_cell_chunk_kernel (env, head, 128 columns of C)   the three contractions above; HBM: C once in, once out
+#include <algorithm>
+
+#include "common.h"
+#include "device_math.h"
+
+namespace lram {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kLp = kChunkMaxTokens;  // 64: padded chunk length (two 32-row MFMA tiles)
+constexpr int kThreads = 256;
+constexpr int kPreMaxGroups = 3;      // channel groups of 4 per thread: inner <= 3072
+
+__device__ __forceinline__ float dot4(const float4& x, const float4& y) {
+  return x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+}
+
+// row of the 32x32 MFMA accumulator held in register r by a lane of half lh
+__device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// =============================================================================================
+// Front end, token-parallel: one workgroup per (env, token).  Same arithmetic (and the same summation order)
+// as mlstm_pre_seq_kernel; the conv window of the first three tokens reaches back into conv_state.
+// Writes q, k, v, xa rows and the raw gate pre-activations gates[row][head] = (i~, f~).
+// =============================================================================================
+template <int NH>
+__global__ __launch_bounds__(kThreads) void mlstm_pre_tok_kernel(MlstmPreArgs a) {
+  __shared__ float red[4][2 * NH];
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int inner = a.inner, T = a.T, ngroups = inner >> 2;
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+  const int64_t row = (int64_t)b * T + t;
+  float pi[NH], pf[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) pi[h] = pf[h] = 0.f;
+#pragma unroll
+  for (int g = 0; g < kPreMaxGroups; ++g) {
+    const int cg = tid + g * kThreads;
+    if (cg >= ngroups) continue;
+    const int c0 = cg << 2;
+    float4 win[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int tt = t - 3 + k;  // token that supplies tap k
+      if (tt >= 0)
+        win[k] = *reinterpret_cast<const float4*>(a.u + ((int64_t)b * T + tt) * 2 * inner + c0);
+      else
+        win[k] = rs ? f4_zero() : *reinterpret_cast<const float4*>(a.conv_state + ((int64_t)b * 4 + 4 + tt) * inner + c0);
+    }
+    const float4 xm = win[3];
+    float4 cw[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cw[c] = *reinterpret_cast<const float4*>(a.conv_w + (int64_t)(c0 + c) * 4);
+    const float4 cb = *reinterpret_cast<const float4*>(a.conv_b + c0);
+    float4 y;
+    y.x = win[0].x * cw[0].x + win[1].x * cw[0].y + win[2].x * cw[0].z + win[3].x * cw[0].w + cb.x;
+    y.y = win[0].y * cw[1].x + win[1].y * cw[1].y + win[2].y * cw[1].z + win[3].y * cw[1].w + cb.y;
+    y.z = win[0].z * cw[2].x + win[1].z * cw[2].y + win[2].z * cw[2].z + win[3].z * cw[2].w + cb.z;
+    y.w = win[0].w * cw[3].x + win[1].w * cw[3].y + win[2].w * cw[3].z + win[3].w * cw[3].w + cb.w;
+    const float4 xa = make_float4(silu_f(y.x), silu_f(y.y), silu_f(y.z), silu_f(y.w));
+    const float4* wq = reinterpret_cast<const float4*>(a.wq + (int64_t)cg * 16);
+    const float4* wk = reinterpret_cast<const float4*>(a.wk + (int64_t)cg * 16);
+    const float4* wv = reinterpret_cast<const float4*>(a.wv + (int64_t)cg * 16);
+    const float4 q = make_float4(dot4(wq[0], xa), dot4(wq[1], xa), dot4(wq[2], xa), dot4(wq[3], xa));
+    const float4 k = make_float4(dot4(wk[0], xa), dot4(wk[1], xa), dot4(wk[2], xa), dot4(wk[3], xa));
+    const float4 v = make_float4(dot4(wv[0], xm), dot4(wv[1], xm), dot4(wv[2], xm), dot4(wv[3], xm));
+    *reinterpret_cast<float4*>(a.q + row * inner + c0) = q;
+    *reinterpret_cast<float4*>(a.k + row * inner + c0) = k;
+    *reinterpret_cast<float4*>(a.v + row * inner + c0) = v;
+    *reinterpret_cast<float4*>(a.xa + row * inner + c0) = xa;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float* wi = a.wi + (int64_t)h * 3 * inner + c0;
+      const float* wf = a.wf + (int64_t)h * 3 * inner + c0;
+      pi[h] += dot4(*reinterpret_cast<const float4*>(wi), q) + dot4(*reinterpret_cast<const float4*>(wi + inner), k) +
+               dot4(*reinterpret_cast<const float4*>(wi + 2 * inner), v);
+      pf[h] += dot4(*reinterpret_cast<const float4*>(wf), q) + dot4(*reinterpret_cast<const float4*>(wf + inner), k) +
+               dot4(*reinterpret_cast<const float4*>(wf + 2 * inner), v);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const float si = wave_sum(pi[h]), sf = wave_sum(pf[h]);
+    if (lane == 0) {
+      red[wave][2 * h] = si;
+      red[wave][2 * h + 1] = sf;
+    }
+  }
+  __syncthreads();
+  if (tid < NH) {
+    const int h = tid;
+    const float gi = red[0][2 * h] + red[1][2 * h] + red[2][2 * h] + red[3][2 * h] + a.bi[h];
+    const float gf = red[0][2 * h + 1] + red[1][2 * h + 1] + red[2][2 * h + 1] + red[3][2 * h + 1] + a.bf[h];
+    *reinterpret_cast<float2*>(a.gates + (row * NH + h) * 2) = make_float2(gi, gf);
+  }
+}
+
+// =============================================================================================
+// Per (env, head): gate scan, intra-chunk weight matrix A (Q Khat^T on the matrix cores, masked and decayed),
+// denominators, and the small states (n, m; conv for head 0).
+// =============================================================================================
+constexpr int kSP = 36;  // LDS row pitch of the 32-wide K tiles (floats): conflict-free ds_read_b128
+constexpr int kDP = 65;  // LDS row pitch of the 64 x 64 decay / A matrix
+
+__global__ __launch_bounds__(kThreads) void mlstm_chunk_scan_kernel(MlstmPreArgs a) {
+  __shared__ __attribute__((aligned(16))) float Qs[kLp * kSP];
+  __shared__ __attribute__((aligned(16))) float Ks[kLp * kSP];
+  __shared__ float Dm[kLp * kDP];
+  __shared__ float s_gi[kLp], s_lf[kLp], s_fa[kLp], s_f[kLp], s_i[kLp], s_m[kLp], s_fc[kLp], s_w[kLp], s_qn[kLp];
+
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int inner = a.inner, T = a.T, NH = a.NH, DH = inner / NH;
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+  const float sqrt_dh = sqrtf((float)DH);
+  const float* qb = a.q + (int64_t)b * T * inner + (int64_t)h * DH;  // row t at + t * inner
+  const float* kb = a.k + (int64_t)b * T * inner + (int64_t)h * DH;
+
+  // ---- 1. stabilised gate factors: transcendental parts in parallel, the max chain by one lane ----
+  if (tid < kLp) {
+    float gi = 0.f, lf = 0.f;
+    if (tid < T) {
+      const float2 g = *reinterpret_cast<const float2*>(a.gates + (((int64_t)b * T + tid) * NH + h) * 2);
+      gi = g.x;
+      lf = log_sigmoid(g.y);
+    }
+    s_gi[tid] = gi;
+    s_lf[tid] = lf;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float m = rs ? 0.f : a.m_state[(int64_t)b * NH + h];
+    for (int t = 0; t < T; ++t) {
+      const float mn = fmaxf(s_lf[t] + m, s_gi[t]);
+      s_fa[t] = s_lf[t] + m - mn;
+      s_m[t] = mn;
+      m = mn;
+    }
+    a.m_state[(int64_t)b * NH + h] = m;
+  }
+  __syncthreads();
+  if (tid < kLp) {
+    const bool valid = tid < T;
+    s_f[tid] = valid ? expf(s_fa[tid]) : 1.f;
+    s_i[tid] = valid ? expf(s_gi[tid] - s_m[tid]) : 0.f;
+  }
+  __syncthreads();
+  // ---- 2. decay columns D[t][s] = i_s f_{s+1} .. f_t (lane s walks down its column), fcum, w ----
+  if (tid < kLp) {
+    const int s = tid;
+    float d = s_i[s];
+    for (int t = 0; t < kLp; ++t) {
+      float val = 0.f;
+      if (t >= s && t < T && s < T) {
+        if (t > s) d *= s_f[t];
+        val = d;
+      }
+      Dm[t * kDP + s] = val;
+    }
+  } else if (tid == kLp) {
+    float fc = 1.f;
+    for (int t = 0; t < kLp; ++t) {
+      if (t < T) fc *= s_f[t];
+      s_fc[t] = t < T ? fc : 0.f;
+    }
+    float g = 1.f;
+    for (int s = kLp - 1; s >= 0; --s) {
+      if (s < T) {
+        s_w[s] = g * s_i[s];
+        g *= s_f[s];
+      } else {
+        s_w[s] = 0.f;
+      }
+    }
+  }
+
+  // ---- 3. S = Q Khat^T (64 x 64, K = DH) on the matrix cores: wave (tm, tn) owns one 32 x 32 tile ----
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int lr = tid >> 3, lc = (tid & 7) << 2;  // staging: rows lr, lr + 32; k offset lc
+  float4 rq[2], rk[2];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = lr + 32 * i;
+      if (t < T) {
+        rq[i] = *reinterpret_cast<const float4*>(qb + (int64_t)t * inner + k0 + lc);
+        rk[i] = *reinterpret_cast<const float4*>(kb + (int64_t)t * inner + k0 + lc);
+      } else {
+        rq[i] = f4_zero();
+        rk[i] = f4_zero();
+      }
+    }
+  };
+  const int nk = DH / 32;
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = lr + 32 * i;
+      *reinterpret_cast<float4*>(Qs + t * kSP + lc) = rq[i];
+      *reinterpret_cast<float4*>(Ks + t * kSP + lc) =
+          make_float4(rk[i].x / sqrt_dh, rk[i].y / sqrt_dh, rk[i].z / sqrt_dh, rk[i].w / sqrt_dh);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) load_tile((kt + 1) * 32);
+    // (the tile t < 32 <= s is masked out entirely; its wave computes it anyway and drops it below)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const float4 af = *reinterpret_cast<const float4*>(Qs + (32 * wm + li) * kSP + 8 * kc + 4 * lh);
+      const float4 bf = *reinterpret_cast<const float4*>(Ks + (32 * wn + li) * kSP + 8 * kc + 4 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- 4. A = D o S, in place in LDS (the tile (0, 1) of D is zero already) ----
+  {
+    const bool live = !(wm == 0 && wn == 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = 32 * wm + acc_row(r, lh), s = 32 * wn + li;
+      const float d = Dm[t * kDP + s];
+      Dm[t * kDP + s] = live ? d * acc[r] : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- 5. A to global (row pitch 64), q_t . n_0 (one wave per row, lanes over DH) ----
+  float* Ag = a.amat + ((int64_t)b * NH + h) * kLp * kLp;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + kThreads * i;
+    const int t = idx >> 4, s4 = (idx & 15) << 2;
+    const float* src = Dm + t * kDP + s4;
+    *reinterpret_cast<float4*>(Ag + t * kLp + s4) = make_float4(src[0], src[1], src[2], src[3]);
+  }
+  const float* n0 = a.n_state + (int64_t)b * inner + (int64_t)h * DH;
+  for (int t = wave; t < kLp; t += 4) {
+    float p = 0.f;
+    if (t < T && !rs) {
+      for (int r4 = lane; r4 < (DH >> 2); r4 += 64)
+        p += dot4(*reinterpret_cast<const float4*>(qb + (int64_t)t * inner + 4 * r4),
+                  *reinterpret_cast<const float4*>(n0 + 4 * r4));
+    }
+    p = wave_sum(p);
+    if (lane == 0) s_qn[t] = p;
+  }
+  __syncthreads();
+  // ---- 6. denominators, chunk vectors; n_T = fcum_{T-1} n_0 + sum_s w_s khat_s ----
+  float* vec = a.vec + ((int64_t)b * NH + h) * 3 * kLp;
+  if (tid < kLp) {
+    const int t = tid;
+    float den = 1.f;
+    if (t < T) {
+      float rowsum = 0.f;
+      for (int s = 0; s <= t; ++s) rowsum += Dm[t * kDP + s];
+      den = fmaxf(fabsf(s_fc[t] * s_qn[t] + rowsum), expf(-s_m[t])) + 1e-6f;
+    }
+    vec[t] = s_fc[t];
+    vec[kLp + t] = s_w[t];
+    vec[2 * kLp + t] = den;
+  }
+  const float fall = s_fc[T - 1];
+  float* nst = a.n_state + (int64_t)b * inner + (int64_t)h * DH;
+  for (int r = tid; r < DH; r += kThreads) {
+    float n = rs ? 0.f : fall * nst[r];
+    for (int s = 0; s < T; ++s) n += s_w[s] * (kb[(int64_t)s * inner + r] / sqrt_dh);
+    nst[r] = n;
+  }
+  // ---- 7. conv state = the chunk's last 4 inputs (T >= 4 on this path) ----
+  if (h == 0) {
+    for (int idx = tid; idx < inner; idx += kThreads * 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        a.conv_state[((int64_t)b * 4 + k) * inner + idx] = a.u[((int64_t)b * T + T - 4 + k) * 2 * inner + idx];
+    }
+  }
+}
+
+// =============================================================================================
+// Cell: one workgroup per (env, head, 128 columns of C).  C streams through LDS in tiles of 32 rows: each tile
+// is read once (non-temporal), contributes to H = diag(fcum) Q C_0 (wave w: columns 32w..32w+31, both 32-token
+// tiles) and leaves as fcum_{T-1} C_0 + (w Khat)^T V.  A V is added from the A matrix of the scan kernel.
+// =============================================================================================
+constexpr int kCW = 128;  // columns of C per workgroup
+constexpr int kRT = 32;   // rows of C per tile
+constexpr int kPV = 136;  // LDS row pitch of the 128-wide tiles (V, C): the two lane halves hit different banks
+constexpr int kPK = 40;   // LDS row pitch of the (w Khat) tile
+constexpr int kCellChunkLds = (kLp * kPV + kRT * kPV + kLp * kSP + kLp * kPK) * 4;  // 71,680 B
+
+__global__ __launch_bounds__(kThreads) void mlstm_cell_chunk_kernel(MlstmCellArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vs = smem;                 // [64][kPV]   v_t, columns of this slice
+  float* Cs = Vs + kLp * kPV;       // [32][kPV]   C_0 row tile
+  float* Qs = Cs + kRT * kPV;       // [64][kSP]   fcum_t q_t, 32 rows of DH
+  float* Ks = Qs + kLp * kSP;       // [64][kPK]   w_t khat_t, 32 rows of DH
+  __shared__ float s_fc[kLp], s_w[kLp], s_den[kLp];
+
+  const int T = a.T, NH = a.NH, DH = a.DH, inner = NH * DH;
+  const int nslices = DH / kCW;
+  // XCD-aware order: consecutive work items (the column slices of one (env, head), which share Q, K and A) run on
+  // the same XCD back to back, so the second slice finds them in that XCD's L2
+  int wid = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wid = (wid & 7) * (nwg >> 3) + (wid >> 3);
+  const int slice = wid % nslices;
+  const int bh = wid / nslices;
+  const int h = bh % NH, b = bh / NH;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+  const bool two = T > 32;
+  const int kt8 = (T + 7) >> 3;  // 8-token groups in the contractions over tokens
+  const float sqrt_dh = sqrtf((float)DH);
+
+  const float* vec = a.vec + ((int64_t)b * NH + h) * 3 * kLp;
+  if (tid < kLp) {
+    s_fc[tid] = vec[tid];
+    s_w[tid] = vec[kLp + tid];
+    s_den[tid] = vec[2 * kLp + tid];
+  }
+  const int col0 = slice * kCW;
+  const float* qb = a.q + (int64_t)b * T * inner + (int64_t)h * DH;
+  const float* kb = a.k + (int64_t)b * T * inner + (int64_t)h * DH;
+  const float* vb = a.v + (int64_t)b * T * inner + (int64_t)h * DH + col0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int idx = tid + kThreads * i;
+    const int t = idx >> 5, c4 = (idx & 31) << 2;
+    const float4 v = t < T ? *reinterpret_cast<const float4*>(vb + (int64_t)t * inner + c4) : f4_zero();
+    *reinterpret_cast<float4*>(Vs + t * kPV + c4) = v;
+  }
+  __syncthreads();
+  const float fall = s_fc[T - 1];
+
+  f32x16 hacc0, hacc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hacc0[r] = hacc1[r] = 0.f;
+
+  // ---- H += A V  (A rows straight from global / L2; tile 0 only sees s < 32) ----
+  {
+    const float* Ag = a.amat + ((int64_t)b * NH + h) * kLp * kLp;
+    for (int j = 0; j < kt8; ++j) {
+      float vbv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vbv[i] = Vs[(8 * j + 4 * lh + i) * kPV + 32 * w + li];
+      if (j < 4) {
+        const float4 a0 = *reinterpret_cast<const float4*>(Ag + li * kLp + 8 * j + 4 * lh);
+        hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, vbv[0], hacc0, 0, 0, 0);
+        hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, vbv[1], hacc0, 0, 0, 0);
+        hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, vbv[2], hacc0, 0, 0, 0);
+        hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, vbv[3], hacc0, 0, 0, 0);
+      }
+      if (two) {
+        const float4 a1 = *reinterpret_cast<const float4*>(Ag + (32 + li) * kLp + 8 * j + 4 * lh);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, vbv[0], hacc1, 0, 0, 0);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, vbv[1], hacc1, 0, 0, 0);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, vbv[2], hacc1, 0, 0, 0);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, vbv[3], hacc1, 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- main loop over 32-row tiles of C ----
+  float* Cg = a.C + (((int64_t)b * NH + h) * DH) * DH + col0;
+  const int crow = tid >> 5, cc4 = (tid & 31) << 2;  // C tile: rows crow + 8 i, 4 columns at cc4
+  const int qrow = tid >> 3, qc4 = (tid & 7) << 2;   // Q / K tiles: tokens qrow + 32 i, 4 rows of DH at qc4
+  v4f rc[4];
+  float4 rq[2], rk[2];
+  auto load_tile = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      rc[i] = rs ? (v4f)(0.f)
+                 : __builtin_nontemporal_load(reinterpret_cast<const v4f*>(Cg + (int64_t)(r0 + crow + 8 * i) * DH + cc4));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = qrow + 32 * i;
+      if (t < T) {
+        rq[i] = *reinterpret_cast<const float4*>(qb + (int64_t)t * inner + r0 + qc4);
+        rk[i] = *reinterpret_cast<const float4*>(kb + (int64_t)t * inner + r0 + qc4);
+      } else {
+        rq[i] = f4_zero();
+        rk[i] = f4_zero();
+      }
+    }
+  };
+  const int ntiles = DH / kRT;
+  load_tile(0);
+  for (int it = 0; it < ntiles; ++it) {
+    const int r0 = it * kRT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<v4f*>(Cs + (crow + 8 * i) * kPV + cc4) = rc[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = qrow + 32 * i;
+      const float fc = s_fc[t], wt = s_w[t];
+      *reinterpret_cast<float4*>(Qs + t * kSP + qc4) = make_float4(fc * rq[i].x, fc * rq[i].y, fc * rq[i].z, fc * rq[i].w);
+      *reinterpret_cast<float4*>(Ks + t * kPK + qc4) =
+          make_float4(wt * (rk[i].x / sqrt_dh), wt * (rk[i].y / sqrt_dh), wt * (rk[i].z / sqrt_dh), wt * (rk[i].w / sqrt_dh));
+    }
+    __syncthreads();
+    if (it + 1 < ntiles) load_tile(r0 + kRT);
+    // H += (fcum Q)[:, tile] C_0[tile, cols]
+#pragma unroll
+    for (int j = 0; j < kRT / 8; ++j) {
+      float cb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cb[i] = Cs[(8 * j + 4 * lh + i) * kPV + 32 * w + li];
+      const float4 q0 = *reinterpret_cast<const float4*>(Qs + li * kSP + 8 * j + 4 * lh);
+      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.x, cb[0], hacc0, 0, 0, 0);
+      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.y, cb[1], hacc0, 0, 0, 0);
+      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.z, cb[2], hacc0, 0, 0, 0);
+      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.w, cb[3], hacc0, 0, 0, 0);
+      if (two) {
+        const float4 q1 = *reinterpret_cast<const float4*>(Qs + (32 + li) * kSP + 8 * j + 4 * lh);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.x, cb[0], hacc1, 0, 0, 0);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.y, cb[1], hacc1, 0, 0, 0);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.z, cb[2], hacc1, 0, 0, 0);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.w, cb[3], hacc1, 0, 0, 0);
+      }
+    }
+    // C_T[tile, cols] = fcum_{T-1} C_0[tile, cols] + (w Khat)[:, tile]^T V[:, cols]
+    f32x16 cacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cacc[r] = fall * Cs[acc_row(r, lh) * kPV + 32 * w + li];
+    for (int j = 0; j < kt8; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int tk = 8 * j + 4 * lh + i;
+        cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[tk * kPK + li], Vs[tk * kPV + 32 * w + li], cacc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      __builtin_nontemporal_store(cacc[r], Cg + (int64_t)(r0 + acc_row(r, lh)) * DH + 32 * w + li);
+    __syncthreads();
+  }
+
+  // ---- h_t = H[t] / den_t ----
+  float* hb = a.h + (int64_t)b * T * inner + (int64_t)h * DH + col0 + 32 * w + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t0 = acc_row(r, lh);
+    if (t0 < T) hb[(int64_t)t0 * inner] = hacc0[r] / s_den[t0];
+    if (two && 32 + t0 < T) hb[(int64_t)(32 + t0) * inner] = hacc1[r] / s_den[32 + t0];
+  }
+}
+
+}  // namespace
+
+bool mlstm_chunk_supported(int inner, int NH, int K) {
+  const int DH = NH > 0 ? inner / NH : 0;
+  return K == 4 && NH > 0 && inner % NH == 0 && DH % kCW == 0 && inner <= 4 * kThreads * kPreMaxGroups &&
+         (NH == 1 || NH == 2 || NH == 4 || NH == 8);
+}
+
+void launch_mlstm_chunk_pre(const MlstmPreArgs& a, hipStream_t stream) {
+  LRAM_REQUIRE(a.T >= 4 && a.T <= kChunkMaxTokens, "chunkwise mLSTM: 4..64 tokens per chunk");
+  LRAM_REQUIRE(mlstm_chunk_supported(a.inner, a.NH, a.K), "chunkwise mLSTM: unsupported geometry");
+  LRAM_REQUIRE(a.gates != nullptr && a.amat != nullptr && a.vec != nullptr, "chunkwise mLSTM: missing work buffers");
+  dim3 grid(a.T, a.B), block(kThreads);
+  switch (a.NH) {
+    case 1: hipLaunchKernelGGL(mlstm_pre_tok_kernel<1>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(mlstm_pre_tok_kernel<2>, grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(mlstm_pre_tok_kernel<4>, grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL(mlstm_pre_tok_kernel<8>, grid, block, 0, stream, a); break;
+  }
+  LRAM_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(mlstm_chunk_scan_kernel, dim3(a.NH, a.B), block, 0, stream, a);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_mlstm_chunk_cell(const MlstmCellArgs& a, hipStream_t stream) {
+  LRAM_REQUIRE(a.T >= 4 && a.T <= kChunkMaxTokens, "chunkwise mLSTM: 4..64 tokens per chunk");
+  LRAM_REQUIRE(a.DH % kCW == 0, "chunkwise mLSTM: head dim must be a multiple of 128");
+  LRAM_REQUIRE(a.amat != nullptr && a.vec != nullptr, "chunkwise mLSTM: missing work buffers");
+  static bool raised = false;
+  if (!raised) {
+    LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_cell_chunk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kCellChunkLds));
+    raised = true;
+  }
+  const long nwg = (long)a.B * a.NH * (a.DH / kCW);
+  hipLaunchKernelGGL(mlstm_cell_chunk_kernel, dim3((unsigned)nwg), dim3(kThreads), kCellChunkLds, stream, a);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace lram

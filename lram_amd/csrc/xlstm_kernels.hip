@@ -683,6 +683,7 @@ static void launch_pre_t(const MlstmPreArgs& a, hipStream_t s) {
 }
 
 void launch_mlstm_pre(const MlstmPreArgs& a, hipStream_t stream) {
+  if (a.T > kMaxTokens) return launch_mlstm_chunk_pre(a, stream);
   LRAM_REQUIRE(a.K >= 1 && a.K <= 4, "mLSTM conv1d_kernel_size must be in 1..4");
   LRAM_REQUIRE(a.inner % (4 * a.NH) == 0, "mLSTM inner dim must be a multiple of 4*num_heads");
   LRAM_REQUIRE(a.inner <= 4 * kPreThreads * kMaxGroups, "mLSTM inner dim too large");
@@ -753,6 +754,7 @@ static void launch_cell_t(const MlstmCellArgs& a, hipStream_t s) {
 }
 
 void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream) {
+  if (a.T > kMaxTokens) return launch_mlstm_chunk_cell(a, stream);
   switch (a.T) {
     case 1: launch_cell_t<1>(a, stream); break;
     case 2: launch_cell_t<2>(a, stream); break;
@@ -782,7 +784,7 @@ void launch_slstm_conv(const SlstmConvArgs& a, hipStream_t stream) {
     case 3: hipLaunchKernelGGL(slstm_conv_kernel<3>, grid, block, 0, stream, a); break;
     case 4: hipLaunchKernelGGL(slstm_conv_kernel<4>, grid, block, 0, stream, a); break;
     default:
-      LRAM_REQUIRE(a.T >= 1 && a.T <= kMaxTokens, "tokens per launch out of range");
+      LRAM_REQUIRE(a.T >= 1 && a.T <= kChunkMaxTokens, "tokens per launch out of range");
       hipLaunchKernelGGL(slstm_conv_rt_kernel, grid, block, 0, stream, a);
   }
   LRAM_HIP_CHECK(hipGetLastError());

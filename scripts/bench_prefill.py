@@ -1,20 +1,38 @@
-"""Prefill micro-benchmark: L stored timesteps through lram_prefill (chunks of 4 timesteps per state pass) vs the
-same L timesteps as L lram_step calls.  Prints timesteps/s per env batch."""
+"""Prefill micro-benchmark: L stored timesteps through lram_prefill -- chunkwise matrix-core kernels (up to 21
+timesteps per state pass) and token-sequential kernels (4 per pass, LRAM_PREFILL_CHUNK=0) -- vs the same L
+timesteps as L lram_step calls.  Prints env-timesteps/s per mode.
+
+    python scripts/bench_prefill.py <config> <B> <L>
+"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lram_amd import init_state_dict, preset
 from lram_amd.engine import Engine
+
 cfg, B, L = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 spec = preset(cfg); sd = init_state_dict(spec, 0)
-eng = Engine(spec, sd, B, device="cuda:0")
-obs = torch.rand(B, L, spec.state_dim, device="cuda:0") * 2 - 1
-rtg = torch.full((B, L), 4.5, device="cuda:0"); rew = torch.zeros(B, L, device="cuda:0")
-obs_t = [obs[:, l].contiguous() for l in range(L)]; rtg_t = [rtg[:, l].contiguous() for l in range(L)]; rew_t = [rew[:, l].contiguous() for l in range(L)]
-def seq():
-    for l in range(L): eng.step(obs_t[l], rtg_t[l], rew_t[l], None)
-def pre():
-    eng.prefill(obs, rtg, rew)
-for name, fn in (("sequential steps", seq), ("lram_prefill", pre), ("sequential steps", seq), ("lram_prefill", pre)):
-    fn(); torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"{cfg} B={B} L={L} {name}: {dt*1e3:.1f} ms  {B*L/dt:,.0f} env-timesteps/s", flush=True)
+dev = "cuda:0"
+eng = Engine(spec, sd, B, device=dev)
+os.environ["LRAM_PREFILL_CHUNK"] = "0"
+eng_seq = Engine(spec, sd, B, device=dev)
+del os.environ["LRAM_PREFILL_CHUNK"]
+obs = torch.rand(B, L, spec.state_dim, device=dev) * 2 - 1
+rtg = torch.full((B, L), 4.5, device=dev); rew = torch.zeros(B, L, device=dev)
+obs_t = [obs[:, l].contiguous() for l in range(L)]; rtg_t = [rtg[:, l].contiguous() for l in range(L)]
+rew_t = [rew[:, l].contiguous() for l in range(L)]
+
+
+def steps():
+    for l in range(L):
+        eng.step(obs_t[l], rtg_t[l], rew_t[l], None)
+
+
+modes = (("lram_step x L", steps), ("lram_prefill, token-sequential chunks of 4", lambda: eng_seq.prefill(obs, rtg, rew)),
+         ("lram_prefill, chunkwise", lambda: eng.prefill(obs, rtg, rew)))
+for rep in range(2):
+    for name, fn in modes:
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rep == 1:
+            print(f"{cfg} B={B} L={L} {name}: {dt*1e3:.1f} ms  {B*L/dt:,.0f} env-timesteps/s", flush=True)
