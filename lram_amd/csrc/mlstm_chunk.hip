@@ -44,80 +44,113 @@ __device__ __forceinline__ float dot4(const float4& x, const float4& y) {
 __device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
 // =============================================================================================
-// Front end, token-parallel: one workgroup per (env, token).  Same arithmetic (and the same summation order)
-// as mlstm_pre_seq_kernel; the conv window of the first three tokens reaches back into conv_state.
+// Front end, token-parallel: one workgroup per (env, group of kTB consecutive tokens).  Same arithmetic (and the
+// same summation order) as mlstm_pre_seq_kernel; the conv window of the first three tokens reaches back into
+// conv_state.  Per-channel weights are loaded once per workgroup and reused for its kTB tokens.
 // Writes q, k, v, xa rows and the raw gate pre-activations gates[row][head] = (i~, f~).
 // =============================================================================================
+constexpr int kTB = 4;
+
 template <int NH>
 __global__ __launch_bounds__(kThreads) void mlstm_pre_tok_kernel(MlstmPreArgs a) {
-  __shared__ float red[4][2 * NH];
-  const int t = blockIdx.x, b = blockIdx.y;
+  __shared__ float red[4][kTB * 2 * NH];
+  const int t0 = blockIdx.x * kTB, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int inner = a.inner, T = a.T, ngroups = inner >> 2;
   const bool rs = a.reset != nullptr && a.reset[b] != 0;
-  const int64_t row = (int64_t)b * T + t;
-  float pi[NH], pf[NH];
+  float pi[kTB][NH], pf[kTB][NH];
 #pragma unroll
-  for (int h = 0; h < NH; ++h) pi[h] = pf[h] = 0.f;
+  for (int j = 0; j < kTB; ++j)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) pi[j][h] = pf[j][h] = 0.f;
 #pragma unroll
   for (int g = 0; g < kPreMaxGroups; ++g) {
     const int cg = tid + g * kThreads;
     if (cg >= ngroups) continue;
     const int c0 = cg << 2;
+    auto input_row = [&](int tt) -> float4 {  // x_mlstm of token tt (tt < 0: the conv state's tap 4 + tt)
+      if (tt >= 0) return *reinterpret_cast<const float4*>(a.u + ((int64_t)b * T + tt) * 2 * inner + c0);
+      return rs ? f4_zero() : *reinterpret_cast<const float4*>(a.conv_state + ((int64_t)b * 4 + 4 + tt) * inner + c0);
+    };
     float4 win[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int tt = t - 3 + k;  // token that supplies tap k
-      if (tt >= 0)
-        win[k] = *reinterpret_cast<const float4*>(a.u + ((int64_t)b * T + tt) * 2 * inner + c0);
-      else
-        win[k] = rs ? f4_zero() : *reinterpret_cast<const float4*>(a.conv_state + ((int64_t)b * 4 + 4 + tt) * inner + c0);
-    }
-    const float4 xm = win[3];
+    win[1] = input_row(t0 - 3);
+    win[2] = input_row(t0 - 2);
+    win[3] = input_row(t0 - 1);
     float4 cw[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) cw[c] = *reinterpret_cast<const float4*>(a.conv_w + (int64_t)(c0 + c) * 4);
     const float4 cb = *reinterpret_cast<const float4*>(a.conv_b + c0);
-    float4 y;
-    y.x = win[0].x * cw[0].x + win[1].x * cw[0].y + win[2].x * cw[0].z + win[3].x * cw[0].w + cb.x;
-    y.y = win[0].y * cw[1].x + win[1].y * cw[1].y + win[2].y * cw[1].z + win[3].y * cw[1].w + cb.y;
-    y.z = win[0].z * cw[2].x + win[1].z * cw[2].y + win[2].z * cw[2].z + win[3].z * cw[2].w + cb.z;
-    y.w = win[0].w * cw[3].x + win[1].w * cw[3].y + win[2].w * cw[3].z + win[3].w * cw[3].w + cb.w;
-    const float4 xa = make_float4(silu_f(y.x), silu_f(y.y), silu_f(y.z), silu_f(y.w));
     const float4* wq = reinterpret_cast<const float4*>(a.wq + (int64_t)cg * 16);
     const float4* wk = reinterpret_cast<const float4*>(a.wk + (int64_t)cg * 16);
     const float4* wv = reinterpret_cast<const float4*>(a.wv + (int64_t)cg * 16);
-    const float4 q = make_float4(dot4(wq[0], xa), dot4(wq[1], xa), dot4(wq[2], xa), dot4(wq[3], xa));
-    const float4 k = make_float4(dot4(wk[0], xa), dot4(wk[1], xa), dot4(wk[2], xa), dot4(wk[3], xa));
-    const float4 v = make_float4(dot4(wv[0], xm), dot4(wv[1], xm), dot4(wv[2], xm), dot4(wv[3], xm));
-    *reinterpret_cast<float4*>(a.q + row * inner + c0) = q;
-    *reinterpret_cast<float4*>(a.k + row * inner + c0) = k;
-    *reinterpret_cast<float4*>(a.v + row * inner + c0) = v;
-    *reinterpret_cast<float4*>(a.xa + row * inner + c0) = xa;
+    const float4 wq0 = wq[0], wq1 = wq[1], wq2 = wq[2], wq3 = wq[3];
+    const float4 wk0 = wk[0], wk1 = wk[1], wk2 = wk[2], wk3 = wk[3];
+    const float4 wv0 = wv[0], wv1 = wv[1], wv2 = wv[2], wv3 = wv[3];
+    float4 qs[kTB], ks[kTB], vs[kTB];
+#pragma unroll
+    for (int j = 0; j < kTB; ++j) {
+      const int t = t0 + j;
+      qs[j] = f4_zero();
+      ks[j] = f4_zero();
+      vs[j] = f4_zero();
+      if (t >= T) continue;
+      const int64_t row = (int64_t)b * T + t;
+      const float4 xm = input_row(t);
+      win[0] = win[1];
+      win[1] = win[2];
+      win[2] = win[3];
+      win[3] = xm;
+      float4 y;
+      y.x = win[0].x * cw[0].x + win[1].x * cw[0].y + win[2].x * cw[0].z + win[3].x * cw[0].w + cb.x;
+      y.y = win[0].y * cw[1].x + win[1].y * cw[1].y + win[2].y * cw[1].z + win[3].y * cw[1].w + cb.y;
+      y.z = win[0].z * cw[2].x + win[1].z * cw[2].y + win[2].z * cw[2].z + win[3].z * cw[2].w + cb.z;
+      y.w = win[0].w * cw[3].x + win[1].w * cw[3].y + win[2].w * cw[3].z + win[3].w * cw[3].w + cb.w;
+      const float4 xa = make_float4(silu_f(y.x), silu_f(y.y), silu_f(y.z), silu_f(y.w));
+      const float4 q = make_float4(dot4(wq0, xa), dot4(wq1, xa), dot4(wq2, xa), dot4(wq3, xa));
+      const float4 k = make_float4(dot4(wk0, xa), dot4(wk1, xa), dot4(wk2, xa), dot4(wk3, xa));
+      const float4 v = make_float4(dot4(wv0, xm), dot4(wv1, xm), dot4(wv2, xm), dot4(wv3, xm));
+      *reinterpret_cast<float4*>(a.q + row * inner + c0) = q;
+      *reinterpret_cast<float4*>(a.k + row * inner + c0) = k;
+      *reinterpret_cast<float4*>(a.v + row * inner + c0) = v;
+      *reinterpret_cast<float4*>(a.xa + row * inner + c0) = xa;
+      qs[j] = q;
+      ks[j] = k;
+      vs[j] = v;
+    }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const float* wi = a.wi + (int64_t)h * 3 * inner + c0;
       const float* wf = a.wf + (int64_t)h * 3 * inner + c0;
-      pi[h] += dot4(*reinterpret_cast<const float4*>(wi), q) + dot4(*reinterpret_cast<const float4*>(wi + inner), k) +
-               dot4(*reinterpret_cast<const float4*>(wi + 2 * inner), v);
-      pf[h] += dot4(*reinterpret_cast<const float4*>(wf), q) + dot4(*reinterpret_cast<const float4*>(wf + inner), k) +
-               dot4(*reinterpret_cast<const float4*>(wf + 2 * inner), v);
+      const float4 iq = *reinterpret_cast<const float4*>(wi), ik = *reinterpret_cast<const float4*>(wi + inner),
+                   iv = *reinterpret_cast<const float4*>(wi + 2 * inner);
+      const float4 fq = *reinterpret_cast<const float4*>(wf), fk = *reinterpret_cast<const float4*>(wf + inner),
+                   fv = *reinterpret_cast<const float4*>(wf + 2 * inner);
+#pragma unroll
+      for (int j = 0; j < kTB; ++j) {
+        pi[j][h] += dot4(iq, qs[j]) + dot4(ik, ks[j]) + dot4(iv, vs[j]);
+        pf[j][h] += dot4(fq, qs[j]) + dot4(fk, ks[j]) + dot4(fv, vs[j]);
+      }
     }
   }
 #pragma unroll
-  for (int h = 0; h < NH; ++h) {
-    const float si = wave_sum(pi[h]), sf = wave_sum(pf[h]);
-    if (lane == 0) {
-      red[wave][2 * h] = si;
-      red[wave][2 * h + 1] = sf;
+  for (int j = 0; j < kTB; ++j)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const float si = wave_sum(pi[j][h]), sf = wave_sum(pf[j][h]);
+      if (lane == 0) {
+        red[wave][(j * NH + h) * 2] = si;
+        red[wave][(j * NH + h) * 2 + 1] = sf;
+      }
     }
-  }
   __syncthreads();
-  if (tid < NH) {
-    const int h = tid;
-    const float gi = red[0][2 * h] + red[1][2 * h] + red[2][2 * h] + red[3][2 * h] + a.bi[h];
-    const float gf = red[0][2 * h + 1] + red[1][2 * h + 1] + red[2][2 * h + 1] + red[3][2 * h + 1] + a.bf[h];
-    *reinterpret_cast<float2*>(a.gates + (row * NH + h) * 2) = make_float2(gi, gf);
+  if (tid < kTB * NH) {
+    const int j = tid / NH, h = tid - j * NH;
+    if (t0 + j < T) {
+      const int o = (j * NH + h) * 2;
+      const float gi = red[0][o] + red[1][o] + red[2][o] + red[3][o] + a.bi[h];
+      const float gf = red[0][o + 1] + red[1][o + 1] + red[2][o + 1] + red[3][o + 1] + a.bf[h];
+      *reinterpret_cast<float2*>(a.gates + (((int64_t)b * T + t0 + j) * NH + h) * 2) = make_float2(gi, gf);
+    }
   }
 }
 
@@ -132,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void mlstm_chunk_scan_kernel(MlstmPreArgs
   __shared__ __attribute__((aligned(16))) float Qs[kLp * kSP];
   __shared__ __attribute__((aligned(16))) float Ks[kLp * kSP];
   __shared__ float Dm[kLp * kDP];
-  __shared__ float s_gi[kLp], s_lf[kLp], s_fa[kLp], s_f[kLp], s_i[kLp], s_m[kLp], s_fc[kLp], s_w[kLp], s_qn[kLp];
+  __shared__ float s_m[kLp], s_fc[kLp], s_w[kLp], s_qn[kLp];
 
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,62 +175,49 @@ __global__ __launch_bounds__(kThreads) void mlstm_chunk_scan_kernel(MlstmPreArgs
   const float* qb = a.q + (int64_t)b * T * inner + (int64_t)h * DH;  // row t at + t * inner
   const float* kb = a.k + (int64_t)b * T * inner + (int64_t)h * DH;
 
-  // ---- 1. stabilised gate factors: transcendental parts in parallel, the max chain by one lane ----
-  if (tid < kLp) {
+  // ---- 1 + 2. wave 0: stabilised gate factors and every chain over the tokens, in registers.  Lane t owns
+  // token t; the sequential parts run unrolled over the 64 lanes with v_readlane broadcasts (no LDS round trips).
+  if (wave == 0) {
+    const int t = lane;
+    const bool valid = t < T;
     float gi = 0.f, lf = 0.f;
-    if (tid < T) {
-      const float2 g = *reinterpret_cast<const float2*>(a.gates + (((int64_t)b * T + tid) * NH + h) * 2);
+    if (valid) {
+      const float2 g = *reinterpret_cast<const float2*>(a.gates + (((int64_t)b * T + t) * NH + h) * 2);
       gi = g.x;
       lf = log_sigmoid(g.y);
     }
-    s_gi[tid] = gi;
-    s_lf[tid] = lf;
-  }
-  __syncthreads();
-  if (tid == 0) {
+    // m_t = max(lf_t + m_{t-1}, gi_t)   (all lanes run the same chain; lane t keeps its own step)
     float m = rs ? 0.f : a.m_state[(int64_t)b * NH + h];
-    for (int t = 0; t < T; ++t) {
-      const float mn = fmaxf(s_lf[t] + m, s_gi[t]);
-      s_fa[t] = s_lf[t] + m - mn;
-      s_m[t] = mn;
-      m = mn;
-    }
-    a.m_state[(int64_t)b * NH + h] = m;
-  }
-  __syncthreads();
-  if (tid < kLp) {
-    const bool valid = tid < T;
-    s_f[tid] = valid ? expf(s_fa[tid]) : 1.f;
-    s_i[tid] = valid ? expf(s_gi[tid] - s_m[tid]) : 0.f;
-  }
-  __syncthreads();
-  // ---- 2. decay columns D[t][s] = i_s f_{s+1} .. f_t (lane s walks down its column), fcum, w ----
-  if (tid < kLp) {
-    const int s = tid;
-    float d = s_i[s];
-    for (int t = 0; t < kLp; ++t) {
-      float val = 0.f;
-      if (t >= s && t < T && s < T) {
-        if (t > s) d *= s_f[t];
-        val = d;
-      }
-      Dm[t * kDP + s] = val;
-    }
-  } else if (tid == kLp) {
-    float fc = 1.f;
-    for (int t = 0; t < kLp; ++t) {
-      if (t < T) fc *= s_f[t];
-      s_fc[t] = t < T ? fc : 0.f;
-    }
-    float g = 1.f;
-    for (int s = kLp - 1; s >= 0; --s) {
-      if (s < T) {
-        s_w[s] = g * s_i[s];
-        g *= s_f[s];
-      } else {
-        s_w[s] = 0.f;
+    float fa = 0.f, mt = 0.f;
+#pragma unroll
+    for (int u = 0; u < kLp; ++u) {
+      if (u < T) {
+        const float lfu = __shfl(lf, u, 64), giu = __shfl(gi, u, 64);
+        const float mn = fmaxf(lfu + m, giu);
+        if (lane == u) {
+          fa = lfu + m - mn;
+          mt = mn;
+        }
+        m = mn;
       }
     }
+    if (lane == 0) a.m_state[(int64_t)b * NH + h] = m;
+    const float f = valid ? expf(fa) : 1.f;
+    const float ig = valid ? expf(gi - mt) : 0.f;
+    // fcum_t = f_0 .. f_t ;  w_s = i_s f_{s+1} .. f_{T-1} ;  decay column D[t][s = lane] = i_s f_{s+1} .. f_t
+    float fc = 1.f, fcum = 0.f;
+    float d = ig;
+#pragma unroll
+    for (int u = 0; u < kLp; ++u) {
+      const float fu = __shfl(f, u, 64);
+      fc *= fu;  // f == 1 beyond T
+      if (lane == u) fcum = fc;
+      if (u > lane) d *= fu;
+      Dm[u * kDP + lane] = (u >= lane && u < T && valid) ? d : 0.f;
+    }
+    s_fc[t] = valid ? fcum : 0.f;
+    s_w[t] = valid ? d : 0.f;  // after the last step d = i_s f_{s+1} .. f_63 with f == 1 beyond T
+    s_m[t] = mt;
   }
 
   // ---- 3. S = Q Khat^T (64 x 64, K = DH) on the matrix cores: wave (tm, tn) owns one 32 x 32 tile ----
@@ -283,8 +303,9 @@ __global__ __launch_bounds__(kThreads) void mlstm_chunk_scan_kernel(MlstmPreArgs
     const int t = tid;
     float den = 1.f;
     if (t < T) {
-      float rowsum = 0.f;
-      for (int s = 0; s <= t; ++s) rowsum += Dm[t * kDP + s];
+      float rowsum = 0.f;  // entries beyond the diagonal are zero
+#pragma unroll 16
+      for (int s = 0; s < kLp; ++s) rowsum += Dm[t * kDP + s];
       den = fmaxf(fabsf(s_fc[t] * s_qn[t] + rowsum), expf(-s_m[t])) + 1e-6f;
     }
     vec[t] = s_fc[t];
@@ -295,7 +316,13 @@ __global__ __launch_bounds__(kThreads) void mlstm_chunk_scan_kernel(MlstmPreArgs
   float* nst = a.n_state + (int64_t)b * inner + (int64_t)h * DH;
   for (int r = tid; r < DH; r += kThreads) {
     float n = rs ? 0.f : fall * nst[r];
-    for (int s = 0; s < T; ++s) n += s_w[s] * (kb[(int64_t)s * inner + r] / sqrt_dh);
+    for (int s0 = 0; s0 < T; s0 += 8) {
+      float kv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kv[j] = kb[(int64_t)min(s0 + j, T - 1) * inner + r];  // w == 0 beyond T
+#pragma unroll
+      for (int j = 0; j < 8; ++j) n += s_w[s0 + j] * (kv[j] / sqrt_dh);
+    }
     nst[r] = n;
   }
   // ---- 7. conv state = the chunk's last 4 inputs (T >= 4 on this path) ----
@@ -415,7 +442,19 @@ __global__ __launch_bounds__(kThreads) void mlstm_cell_chunk_kernel(MlstmCellArg
       }
     }
   };
+  // Stores of tile i are issued one iteration late, right after the barrier of tile i + 1 and before the prefetch of
+  // tile i + 2: on gfx9 loads and stores share vmcnt, so the wait for a prefetched tile also waits for every
+  // store issued before it -- this way those stores have had a whole compute phase to drain.
+  const int64_t lane_off = (int64_t)(4 * lh) * DH + 32 * w + li;
+  auto store_tile = [&](const f32x16& c, int r0) {
+    float* dst = Cg + (int64_t)r0 * DH + lane_off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(c[r], dst + (int64_t)((r & 3) + 8 * (r >> 2)) * DH);
+  };
   const int ntiles = DH / kRT;
+  f32x16 cprev;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cprev[r] = 0.f;
   load_tile(0);
   for (int it = 0; it < ntiles; ++it) {
     const int r0 = it * kRT;
@@ -430,42 +469,66 @@ __global__ __launch_bounds__(kThreads) void mlstm_cell_chunk_kernel(MlstmCellArg
           make_float4(wt * (rk[i].x / sqrt_dh), wt * (rk[i].y / sqrt_dh), wt * (rk[i].z / sqrt_dh), wt * (rk[i].w / sqrt_dh));
     }
     __syncthreads();
+    if (it > 0) store_tile(cprev, r0 - kRT);
     if (it + 1 < ntiles) load_tile(r0 + kRT);
-    // H += (fcum Q)[:, tile] C_0[tile, cols]
+    // H += (fcum Q)[:, tile] C_0[tile, cols]   (all LDS operands of the tile first, then the MFMAs)
+    float cb[16];
+    float4 q0[4], q1[4];
 #pragma unroll
     for (int j = 0; j < kRT / 8; ++j) {
-      float cb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) cb[i] = Cs[(8 * j + 4 * lh + i) * kPV + 32 * w + li];
-      const float4 q0 = *reinterpret_cast<const float4*>(Qs + li * kSP + 8 * j + 4 * lh);
-      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.x, cb[0], hacc0, 0, 0, 0);
-      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.y, cb[1], hacc0, 0, 0, 0);
-      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.z, cb[2], hacc0, 0, 0, 0);
-      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.w, cb[3], hacc0, 0, 0, 0);
-      if (two) {
-        const float4 q1 = *reinterpret_cast<const float4*>(Qs + (32 + li) * kSP + 8 * j + 4 * lh);
-        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.x, cb[0], hacc1, 0, 0, 0);
-        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.y, cb[1], hacc1, 0, 0, 0);
-        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.z, cb[2], hacc1, 0, 0, 0);
-        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.w, cb[3], hacc1, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) cb[4 * j + i] = Cs[(8 * j + 4 * lh + i) * kPV + 32 * w + li];
+      q0[j] = *reinterpret_cast<const float4*>(Qs + li * kSP + 8 * j + 4 * lh);
+      q1[j] = two ? *reinterpret_cast<const float4*>(Qs + (32 + li) * kSP + 8 * j + 4 * lh) : f4_zero();
+    }
+    // first operands of the token contraction, in flight while the MFMAs above run
+    float ka[4], va[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ka[i] = Ks[(4 * lh + i) * kPK + li];
+      va[i] = Vs[(4 * lh + i) * kPV + 32 * w + li];
+    }
+#pragma unroll
+    for (int j = 0; j < kRT / 8; ++j) {
+      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0[j].x, cb[4 * j + 0], hacc0, 0, 0, 0);
+      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0[j].y, cb[4 * j + 1], hacc0, 0, 0, 0);
+      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0[j].z, cb[4 * j + 2], hacc0, 0, 0, 0);
+      hacc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0[j].w, cb[4 * j + 3], hacc0, 0, 0, 0);
+    }
+    if (two) {
+#pragma unroll
+      for (int j = 0; j < kRT / 8; ++j) {
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1[j].x, cb[4 * j + 0], hacc1, 0, 0, 0);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1[j].y, cb[4 * j + 1], hacc1, 0, 0, 0);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1[j].z, cb[4 * j + 2], hacc1, 0, 0, 0);
+        hacc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1[j].w, cb[4 * j + 3], hacc1, 0, 0, 0);
       }
     }
     // C_T[tile, cols] = fcum_{T-1} C_0[tile, cols] + (w Khat)[:, tile]^T V[:, cols]
+    // (register r of the accumulator holds row acc_row(r, lh) = the row cb[r] was read from)
     f32x16 cacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cacc[r] = fall * Cs[acc_row(r, lh) * kPV + 32 * w + li];
+    for (int r = 0; r < 16; ++r) cacc[r] = fall * cb[r];
     for (int j = 0; j < kt8; ++j) {
+      float kn[4], vn[4];
+      const int jn = min(j + 1, kt8 - 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int tk = 8 * j + 4 * lh + i;
-        cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[tk * kPK + li], Vs[tk * kPV + 32 * w + li], cacc, 0, 0, 0);
+        kn[i] = Ks[(8 * jn + 4 * lh + i) * kPK + li];
+        vn[i] = Vs[(8 * jn + 4 * lh + i) * kPV + 32 * w + li];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[i], va[i], cacc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ka[i] = kn[i];
+        va[i] = vn[i];
       }
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      __builtin_nontemporal_store(cacc[r], Cg + (int64_t)(r0 + acc_row(r, lh)) * DH + 32 * w + li);
+    cprev = cacc;
     __syncthreads();
   }
+  store_tile(cprev, (ntiles - 1) * kRT);
 
   // ---- h_t = H[t] / den_t ----
   float* hb = a.h + (int64_t)b * T * inner + (int64_t)h * DH + col0 + 32 * w + li;
@@ -489,7 +552,7 @@ void launch_mlstm_chunk_pre(const MlstmPreArgs& a, hipStream_t stream) {
   LRAM_REQUIRE(a.T >= 4 && a.T <= kChunkMaxTokens, "chunkwise mLSTM: 4..64 tokens per chunk");
   LRAM_REQUIRE(mlstm_chunk_supported(a.inner, a.NH, a.K), "chunkwise mLSTM: unsupported geometry");
   LRAM_REQUIRE(a.gates != nullptr && a.amat != nullptr && a.vec != nullptr, "chunkwise mLSTM: missing work buffers");
-  dim3 grid(a.T, a.B), block(kThreads);
+  dim3 grid((a.T + kTB - 1) / kTB, a.B), block(kThreads);
   switch (a.NH) {
     case 1: hipLaunchKernelGGL(mlstm_pre_tok_kernel<1>, grid, block, 0, stream, a); break;
     case 2: hipLaunchKernelGGL(mlstm_pre_tok_kernel<2>, grid, block, 0, stream, a); break;

@@ -2,7 +2,7 @@
 timesteps per state pass) and token-sequential kernels (4 per pass, LRAM_PREFILL_CHUNK=0) -- vs the same L
 timesteps as L lram_step calls.  Prints env-timesteps/s per mode.
 
-    python scripts/bench_prefill.py <config> <B> <L>
+    python scripts/bench_prefill.py <config> <B> <L> [micro]
 """
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,12 +11,15 @@ from lram_amd import init_state_dict, preset
 from lram_amd.engine import Engine
 
 cfg, B, L = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+micro = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # env slices (0 = auto)
 spec = preset(cfg); sd = init_state_dict(spec, 0)
 dev = "cuda:0"
 eng = Engine(spec, sd, B, device=dev)
 os.environ["LRAM_PREFILL_CHUNK"] = "0"
 eng_seq = Engine(spec, sd, B, device=dev)
 del os.environ["LRAM_PREFILL_CHUNK"]
+for e in (eng, eng_seq):
+    e.set_micro_batches(micro)
 obs = torch.rand(B, L, spec.state_dim, device=dev) * 2 - 1
 rtg = torch.full((B, L), 4.5, device=dev); rew = torch.zeros(B, L, device=dev)
 obs_t = [obs[:, l].contiguous() for l in range(L)]; rtg_t = [rtg[:, l].contiguous() for l in range(L)]
