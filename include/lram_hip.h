@@ -127,8 +127,12 @@ int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding
  * policy.forward without a cache (src/algos/decision_transformer_sb3.py:628-640,663-666: after
  * `reset_inf_cache_freq` fires the reference re-embeds the context but keeps only the last 3 tokens, SURVEY 3.5 Q5;
  * `chunkwise_step`, decision_xlstm.py:158-159).  Equal to `timesteps` sequential lram_step calls up to
- * fp32 rounding, but processed in chunks of 4 timesteps (12 tokens): each block's recurrent state is read and
- * written once per chunk, so a stored context costs a quarter of the state traffic of stepping through it.
+ * fp32 rounding, but processed in chunks: each block's recurrent state is read and written once per chunk.
+ * xLSTM with a head dim that is a multiple of 128 (the 16M and 206M geometries): up to 21 timesteps (63 tokens) per
+ * chunk through the chunkwise matrix-core kernels (csrc/mlstm_chunk.hip: intra-chunk attention form + one rank-T
+ * update of C); otherwise, or with LRAM_PREFILL_CHUNK=0 in the environment at lram_create, 4 timesteps (12 tokens)
+ * per chunk through the token-sequential kernels.  The first long prefill grows the activation workspace to 64
+ * tokens per env slot (device-synchronising, once).
  *   dev_obs_seq    device float[batch, timesteps, state_dim] (or [batch, timesteps, d_model] embeddings)
  *   dev_rtg_seq, dev_reward_seq   device float[batch, timesteps]
  *   dev_reset_mask applied before the first timestep;  dev_actions (nullable): action at the LAST timestep. */
@@ -137,7 +141,8 @@ int32_t lram_prefill(lram_engine* e, const float* dev_obs_seq, int32_t obs_is_em
                      int32_t discrete, float* dev_actions, int32_t* dev_tokens, void* stream);
 
 /* Encoder-only operator: inputs_embeds[batch, tokens, d_model] -> last_hidden_state of the same shape
- * (after post_blocks_norm / norm_f), state advanced by `tokens` (1..4, 6, 9 or 12).  This is the exact plug point of
+ * (after post_blocks_norm / norm_f), state advanced by `tokens` (1..4, 6, 9 or 12; any count in 13..64 as well on
+ * xLSTM geometries the chunkwise kernels cover, see lram_prefill).  This is the exact plug point of
  * `self.encoder(**encoder_inputs)` (online_decision_transformer_model.py:448). */
 int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_t tokens,
                           const uint8_t* dev_reset_mask, float* dev_hidden_out, void* stream);

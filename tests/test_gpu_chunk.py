@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 SPECS = {
     "dh128": dict(backbone="xlstm", d_model=256, n_blocks=3, slstm_at=[1]),    # inner 512, 4 heads x 128
     "dh640": dict(backbone="xlstm", d_model=1280, n_blocks=2, slstm_at=[1]),   # the 206M head geometry
+    "nh8": dict(backbone="xlstm", d_model=512, n_blocks=2, slstm_at=[1], n_heads=8),  # 8 heads x 128
 }
 
 
