@@ -48,7 +48,7 @@ class RecurrentAgent:
     def __init__(self, spec: ModelSpec, state_dict: Dict[str, torch.Tensor], n_envs: int = 1, device=None,
                  discrete: bool = False, state_mean: Optional[torch.Tensor] = None,
                  state_std: Optional[torch.Tensor] = None, target_return: float = 0.0, reward_scale: float = 1.0,
-                 graph: bool = False, reprime_context: bool = False):
+                 graph: bool = False, reprime_context: bool = False, persist_context: bool = False):
         self.spec = spec
         self.engine = Engine(spec, state_dict, n_envs, device)
         self.device = self.engine.device
@@ -67,7 +67,8 @@ class RecurrentAgent:
         # reference behaviour (False): the context is dropped when the cache is reset;
         # True: the last eval_context_len stored timesteps are fed back through Engine.prefill
         self.reprime_context = bool(reprime_context)
-        self.persist_context = False
+        # evaluation.py:213-236: keep the context (here: the recurrent cache) across episode ends
+        self.persist_context = bool(persist_context)
         self.compile = False
         self.target_return_type = "predefined"
         self.target_return = float(target_return) / float(reward_scale)

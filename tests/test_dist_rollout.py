@@ -93,3 +93,58 @@ def test_rollout_bookkeeping_and_staggered_resets():
             steps_since_reset = age if t >= 4 - e % 4 else t
             assert abs(float(rtg[e]) - (4.5 - 0.01 * steps_since_reset)) < 1e-6, (t, e)
     assert stats["n_envs"] == 6 and stats["total_steps_per_second"] > 0 and "mean_ep_length" in stats
+
+
+class _FakeEvalAgent(_FakeAgent):
+    persist_context = False
+
+    def __init__(self):
+        super().__init__()
+        self.resets = 0
+        self.inference_params = self
+
+    def reset(self):
+        self.resets += 1
+
+    def compute_target_return_val(self, env=None, task_id=0):
+        return 4.5
+
+    def get_reward_scale_for_env(self, envid=None):
+        return 100.0
+
+
+def test_evaluate_policy_batched_follows_the_reference_contract():
+    """Episode shares per sub-env, return tuples, reward threshold, success buffer (evaluation.py:94-96,184-212,262-271)."""
+    from lram_amd.rollout import eval_log_record, evaluate_policy_batched
+    env = SyntheticVecEnv(4, obs_dim=5, act_dim=2, ep_len=3, stagger=False, success_every=2)
+    agent = _FakeEvalAgent()
+    succ = []
+    rewards, lengths, times = evaluate_policy_batched(agent, env, n_eval_episodes=10, env_act_dim=2,
+                                                      return_episode_rewards=True, is_success_buffer=succ)
+    # targets (10 + i) // 4 = 2, 2, 3, 3 episodes of 3 steps with reward 1
+    assert len(rewards) == 10 and rewards == [3.0] * 10 and lengths == [3] * 10 and len(times) == 10
+    assert len(agent.calls) == 9 and agent.resets == 1
+    assert torch.allclose(agent.calls[0][1], torch.full((4,), 4.5))   # compute_target_return_val is the rtg token value
+    assert succ == [0.0] * 4 + [1.0] * 4 + [0.0] * 2                             # every 2nd episode succeeds
+    env2 = SyntheticVecEnv(3, obs_dim=5, act_dim=2, ep_len=2, stagger=True)
+    mean_r, std_r, mean_t = evaluate_policy_batched(_FakeEvalAgent(), env2, n_eval_episodes=5, env_act_dim=2)
+    assert 1.0 <= mean_r <= 2.0 and std_r >= 0.0 and mean_t >= 0.0
+    with pytest.raises(AssertionError):
+        evaluate_policy_batched(_FakeEvalAgent(), SyntheticVecEnv(2, ep_len=2, stagger=False), n_eval_episodes=2,
+                                env_act_dim=1, reward_threshold=5.0)
+    rec = eval_log_record("eval", "cheetah-run", 3, rewards, lengths, times, is_success=succ, inf_batch=4,
+                          score_ref=(1.0, 5.0), score_type="dns")
+    assert rec["eval/cheetah-run_3/mean_reward"] == 3.0 and rec["eval/mean_ep_length"] == 3.0
+    assert abs(rec["eval/cheetah-run_3/dns"] - 0.5) < 1e-12 and abs(rec["eval/success_rate"] - 0.4) < 1e-12
+    assert abs(rec["eval/cheetah-run_3/total_steps_per_second"] - 4 * rec["eval/cheetah-run_3/steps_per_second"]) < 1e-6
+
+
+def test_persist_context_keeps_the_cache_across_episodes():
+    """evaluation.py:213-251: with persist_context only the target return restarts at an episode end."""
+    env = SyntheticVecEnv(2, obs_dim=3, act_dim=1, ep_len=2, stagger=False)
+    agent = _FakeAgent()
+    ro = BatchedRollout(agent, env, target_return=10.0, reward_scale=10.0, env_act_dim=1, persist_context=True)
+    ro.run(5)
+    assert bool(agent.calls[0][2].all())                                  # the very first step starts from a clean cache
+    assert all(int(c[2].sum()) == 0 for c in agent.calls[1:])             # ... and nothing resets it afterwards
+    assert abs(float(agent.calls[2][1][0]) - 1.0) < 1e-6                  # rtg restarts after the 2-step episode
