@@ -187,3 +187,36 @@ def test_encoder_step_long_chunks_xlstm(hip_lib):
         assert rel_err(pkv["block_0"]["mlstm_state"][0], state["block_0"]["mlstm_state"][0]) < 2e-4
         assert rel_err(pkv["block_1"]["slstm_state"], state["block_1"]["slstm_state"]) < 2e-4
         eng.close()
+
+
+def test_mamba_two_slice_pipeline_equals_single_stream(hip_lib):
+    """Mamba with two env slices (memory-bound kernels of one slice under the projections of the other, slice 1 one
+    stage behind slice 0) == the single-stream schedule: same actions, same states, step and prefill, over repeats."""
+    from lram_amd.engine import Engine
+    spec = preset("mamba_tiny")
+    sd = init_state_dict(spec, seed=21)
+    B, steps = 37, 6
+    seq = make_inputs(spec, B, steps, seed=11)
+    dseq = [[t.cuda() for t in x] for x in seq]
+    outs = []
+    for micro in (1, 2, 2):
+        eng = Engine(spec, sd, B, device="cuda:0")
+        eng.set_micro_batches(micro)
+        acts = []
+        for x in dseq:
+            a, _ = eng.step(*x)
+            acts.append(a.clone())
+        obs_seq = torch.stack([x[0] for x in dseq], 1).contiguous()
+        rtg_seq = torch.stack([x[1] for x in dseq], 1).contiguous()
+        rew_seq = torch.stack([x[2] for x in dseq], 1).contiguous()
+        a_pre, _ = eng.prefill(obs_seq, rtg_seq, rew_seq)
+        torch.cuda.synchronize()
+        outs.append((torch.stack(acts), a_pre.clone(), eng.export_state_tensor(0, 0), eng.export_state_tensor(1, 3)))
+        eng.close()
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+        assert rel_err(o[2], outs[0][2]) < 1e-5 and rel_err(o[3], outs[0][3]) < 1e-5
+    ora = dt_ref.OraclePolicy(spec, sd)
+    for t, (obs, rtg, rew, mask) in enumerate(seq):
+        ref = ora.step(obs, rtg, rew, mask)
+        assert float((outs[1][0][t].cpu() - ref).abs().max()) <= 1e-4, t
