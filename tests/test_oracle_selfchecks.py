@@ -129,3 +129,32 @@ def test_impala_cnn_shapes_and_image_path():
     enc = ImageEncoder.from_state_dict(sd, spec.image_shape, spec.d_model)
     ref = dt_ref.impala_cnn(sd, "embed_image.", img.float() / 255.0)
     assert rel_err(enc(img), ref) < 1e-6
+
+
+def test_mlstm_cell_matches_transformers_xlstm_native_step():
+    """Independent cross-check of the stabilised mLSTM recurrence (not a parity oracle: the xLSTM-7B variant in
+    `transformers.models.xlstm` scales q instead of k and has no conv front end): with the same q, k,
+    v and gate pre-activations its `mlstm_recurrent_step_native` gives the same h, m and -- up to the sqrt(DH)
+    that moves from k to q -- the same C and n as oracle.xlstm_ref.mlstm_recurrent_step, step after step."""
+    import math
+    hx = pytest.importorskip("transformers.models.xlstm.modeling_xlstm")
+    if not hasattr(hx, "mlstm_recurrent_step_native"):
+        pytest.skip("this transformers build routes to the external xlstm package")
+    from oracle import xlstm_ref
+    g = torch.Generator().manual_seed(5)
+    B, NH, DH, S = 3, 4, 32, 12
+    c = torch.zeros(B, NH, DH, DH)
+    n = torch.zeros(B, NH, DH, 1)
+    m = torch.zeros(B, NH, 1, 1)
+    c_h, n_h, m_h = torch.zeros(B, NH, DH, DH), torch.zeros(B, NH, DH), torch.zeros(B, NH, 1)
+    for t in range(S):
+        q, k, v = (torch.randn(B, NH, 1, DH, generator=g) for _ in range(3))
+        ig = torch.randn(B, NH, 1, 1, generator=g) * 2.0
+        fg = torch.randn(B, NH, 1, 1, generator=g) * 2.0 + 2.0
+        h, (c, n, m) = xlstm_ref.mlstm_recurrent_step(c, n, m, q, k, v, ig, fg)
+        h_h, (c_h, n_h, m_h) = hx.mlstm_recurrent_step_native(q[:, :, 0], k[:, :, 0], v[:, :, 0], ig[:, :, 0], fg[:, :, 0],
+                                                              c_h, n_h, m_h)
+        assert torch.allclose(h.squeeze(2), h_h, rtol=1e-5, atol=1e-6), t
+        assert torch.allclose(m.view(B, NH, 1), m_h, rtol=0, atol=1e-6), t
+    assert torch.allclose(c * math.sqrt(DH), c_h, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(n.squeeze(-1) * math.sqrt(DH), n_h, rtol=1e-5, atol=1e-6)
