@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=4096, help="env slots per GPU")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: total env slots, split over the ranks with lram_amd.dist.shard_bounds "
+                         "(overrides --batch; BASELINE C4: 4096 over 8 GPUs)")
     ap.add_argument("--config", default="xlstm_16m", help="preset name (lram_amd.config.preset)")
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph")
     ap.add_argument("--micro", type=int, default=0, help="env slices pipelined on separate streams (0 = auto, 1 = off)")
@@ -116,6 +119,9 @@ def main():
     spec = preset(args.config)
     sd = init_state_dict(spec, seed=0)
     B, T, K, W = args.batch, spec.tokens_per_step, args.steps, args.warmup
+    if args.global_batch > 0:
+        lo, hi = ldist.shard_bounds(args.global_batch, rank, world)
+        B = hi - lo
     eng = Engine(spec, sd, B, device=dev)
     if args.graph:
         eng.set_graph_mode(True)
@@ -140,6 +146,7 @@ def main():
     torch.cuda.synchronize()
 
     def one_step(t):
+        t = t % steps_total
         a, _ = eng.step(obs_ring[t % n_ring], rtgs[t], reward_tok, masks[t])
         if world > 1:
             a = ldist.all_gather_actions(a)
@@ -165,7 +172,7 @@ def main():
     kern_ms, kern_n = eng.profile_end() if timing else (0.0, 0)
     wall = ldist.max_over_ranks(wall, dev)
 
-    total_env_steps = B * world * K
+    total_env_steps = (args.global_batch if args.global_batch > 0 else B * world) * K
     value = total_env_steps / wall
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------
@@ -230,11 +237,11 @@ def main():
     out = {
         "metric": "env-steps/sec (action-inference)", "value": value, "unit": "env-steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong" if args.global_batch > 0 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: xLSTM[7:1] 16M rollout, {B} env slots per GPU, 3 tokens/timestep, "
                                "cheetah-run-shaped obs (17 of 204 dims), continuous 8x274 head"
                    if args.config == "xlstm_16m" else f"{args.config}, {B} env slots per GPU",
-                   "batch_per_gpu": B, "global_batch": B * world, "tokens_per_step": T,
+                   "batch_per_gpu": B, "global_batch": args.global_batch if args.global_batch > 0 else B * world, "tokens_per_step": T,
                    "state_bytes_per_env": spec.state_bytes_per_env(), "parallelism": f"env-shard x{world}",
                    "graph": bool(args.graph), "micro_batches": args.micro},
         "roofline": roofline,

@@ -33,6 +33,9 @@ def steps():
 
 modes = (("lram_step x L", steps), ("lram_prefill, token-sequential chunks of 4", lambda: eng_seq.prefill(obs, rtg, rew)),
          ("lram_prefill, chunkwise", lambda: eng.prefill(obs, rtg, rew)))
+only = os.environ.get("PREFILL_MODES")   # e.g. "chunkwise": restrict to modes whose name contains the string
+if only:
+    modes = tuple(m for m in modes if only in m[0])
 for rep in range(2):
     for name, fn in modes:
         fn(); torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()

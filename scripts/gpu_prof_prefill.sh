@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: gpu_prof_prefill.sh <config> <B> <L>  -> kernel stats of scripts/bench_prefill.py under rocprofv3
+# usage: gpu_prof_prefill.sh <config> <B> <L> [micro]  -> kernel stats of scripts/bench_prefill.py under rocprofv3
+# (PREFILL_MODES=chunkwise restricts the run to the chunkwise mode)
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/prof_prefill_$1; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/scripts/bench_prefill.py "$@" > $OUT/out.log 2> $OUT/err.log
