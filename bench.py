@@ -149,7 +149,7 @@ def main():
         t = t % steps_total
         a, _ = eng.step(obs_ring[t % n_ring], rtgs[t], reward_tok, masks[t])
         if world > 1:
-            a = ldist.all_gather_actions(a)
+            a = ldist.all_gather_actions(a, args.global_batch if args.global_batch > 0 else None)
         return a
 
     if args.side_stream:
