@@ -50,6 +50,9 @@ class RecurrentAgent:
                  state_std: Optional[torch.Tensor] = None, target_return: float = 0.0, reward_scale: float = 1.0,
                  graph: bool = False, reprime_context: bool = False, persist_context: bool = False):
         self.spec = spec
+        # host copy of the weights: lets the agent cross a process boundary (make_pickleable / reinit_cuda_kernels)
+        self._state_dict = {k: v.detach().to("cpu") for k, v in state_dict.items()}
+        self._graph = bool(graph)
         self.engine = Engine(spec, state_dict, n_envs, device)
         self.device = self.engine.device
         self.n_envs = n_envs
@@ -91,6 +94,33 @@ class RecurrentAgent:
             self.engine.reset()
         else:
             self.engine.import_past_key_values(value)
+
+    # ---- multiprocess evaluation (src/callbacks/custom_eval_callback.py:22-33, decision_xlstm.py:243-267) ----
+    def make_pickleable(self, replace_cell: bool = False):
+        """The native engine handle cannot be serialised: release it (spec and host weights stay), as the reference
+        unsets its sLSTM CUDA kernels before handing the model to loky workers."""
+        if self.engine is not None:
+            self.engine.close()
+            self.engine = None
+
+    def reinit_cuda_kernels(self, replace_cell: bool = False):
+        """Worker-side counterpart of make_pickleable: build a fresh engine (recurrent state starts empty)."""
+        if self.engine is None:
+            self.engine = Engine(self.spec, self._state_dict, self.n_envs, self.device)
+            if self._graph:
+                self.engine.set_graph_mode(True)
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["engine"] = None          # never pickled; reinit_cuda_kernels() rebuilds it
+        d["policy"] = None          # self-reference, restored below
+        d["inference_params"] = None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self.policy = self
+        self.inference_params = _InferenceParams(self)
 
     def compute_target_return_val(self, env=None, task_id=0):
         return self.target_return

@@ -286,15 +286,30 @@ __global__ __launch_bounds__(kThreads) void mlstm_chunk_scan_kernel(MlstmPreArgs
     *reinterpret_cast<float4*>(Ag + t * kLp + s4) = make_float4(src[0], src[1], src[2], src[3]);
   }
   const float* n0 = a.n_state + (int64_t)b * inner + (int64_t)h * DH;
-  for (int t = wave; t < kLp; t += 4) {
-    float p = 0.f;
-    if (t < T && !rs) {
-      for (int r4 = lane; r4 < (DH >> 2); r4 += 64)
-        p += dot4(*reinterpret_cast<const float4*>(qb + (int64_t)t * inner + 4 * r4),
-                  *reinterpret_cast<const float4*>(n0 + 4 * r4));
+  {
+    // rows t = wave, wave + 4, ...: all loads of four rows are issued before the first reduction
+    const int nq = DH >> 2;
+    for (int t0 = wave; t0 < kLp; t0 += 16) {
+      float p[4] = {0.f, 0.f, 0.f, 0.f};
+      if (!rs) {
+        for (int r4 = lane; r4 < nq; r4 += 64) {
+          const float4 nv = *reinterpret_cast<const float4*>(n0 + 4 * r4);
+          float4 qv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 4 * j;
+            qv[j] = t < T ? *reinterpret_cast<const float4*>(qb + (int64_t)t * inner + 4 * r4) : f4_zero();
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) p[j] += dot4(qv[j], nv);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sum = wave_sum(p[j]);
+        if (lane == 0) s_qn[t0 + 4 * j] = sum;
+      }
     }
-    p = wave_sum(p);
-    if (lane == 0) s_qn[t] = p;
   }
   __syncthreads();
   // ---- 6. denominators, chunk vectors; n_T = fcum_{T-1} n_0 + sum_s w_s khat_s ----

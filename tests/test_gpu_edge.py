@@ -220,3 +220,27 @@ def test_mamba_two_slice_pipeline_equals_single_stream(hip_lib):
     for t, (obs, rtg, rew, mask) in enumerate(seq):
         ref = ora.step(obs, rtg, rew, mask)
         assert float((outs[1][0][t].cpu() - ref).abs().max()) <= 1e-4, t
+
+
+def test_agent_crosses_a_process_boundary(hip_lib):
+    """make_pickleable / pickle / reinit_cuda_kernels (custom_eval_callback.py:22-33, decision_xlstm.py:243-267): the
+    rebuilt agent starts from an empty cache and reproduces the original agent's first action."""
+    import pickle
+    from lram_amd.agent import RecurrentAgent
+    spec = preset("xlstm_tiny")
+    sd = init_state_dict(spec, seed=5)
+    agent = RecurrentAgent(spec, sd, n_envs=3, device="cuda:0", target_return=90.0, reward_scale=10.0)
+    obs = torch.rand(3, 17, generator=torch.Generator().manual_seed(1)).cuda()
+    rtg = torch.full((3,), 9.0).cuda()
+    first = agent.predict_batch(obs, rtg).clone()
+    agent.predict_batch(obs, rtg)
+    agent.make_pickleable()
+    assert agent.engine is None
+    clone = pickle.loads(pickle.dumps(agent))
+    clone.policy.reinit_cuda_kernels()
+    assert clone.policy is clone and clone.engine is not None
+    again = clone.predict_batch(obs, rtg)
+    torch.cuda.synchronize()
+    assert torch.equal(first, again)
+    clone.inference_params.reset()
+    clone.engine.close()
