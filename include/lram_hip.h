@@ -192,6 +192,15 @@ int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64
 int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                          int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                          int32_t k, void* stream);
+/* Image observations: uint8 frames [batch, channels, height, width] -> state-token embeddings [batch, d_model]
+ * through the IMPALA CNN (3 x [conv3x3 -> maxpool(3,2,1) -> 2 residual blocks], 16/32/32 channels, ReLU, flatten,
+ * Linear, ReLU).  Replaces `self.embed_image(state.float() / 255)` (online_decision_transformer_model.py:523-526;
+ * module src/algos/models/image_encoders.py:10-131, built at multi_domain_discrete_dt_model.py:43-46).  Needs the
+ * `embed_image.*` tensors (reference names) uploaded before lram_finalize; the result is passed to lram_step /
+ * lram_prefill with obs_is_embedding = 1. */
+int32_t lram_embed_images(lram_engine* e, const uint8_t* dev_images, int32_t channels, int32_t height, int32_t width,
+                          float* dev_embeddings, void* stream);
+
 /* Observation front end on the device: native obs [batch, n_native] -> model input [batch, state_dim].
  * dev_inv_index == NULL: zero-pad (DecisionXLSTM.pad_inputs, src/algos/decision_xlstm.py:16-19); otherwise
  * int32[state_dim] giving, per output dim, the native column it is filled from or -1 (DMControl full-space

@@ -48,7 +48,8 @@ class RecurrentAgent:
     def __init__(self, spec: ModelSpec, state_dict: Dict[str, torch.Tensor], n_envs: int = 1, device=None,
                  discrete: bool = False, state_mean: Optional[torch.Tensor] = None,
                  state_std: Optional[torch.Tensor] = None, target_return: float = 0.0, reward_scale: float = 1.0,
-                 graph: bool = False, reprime_context: bool = False, persist_context: bool = False):
+                 graph: bool = False, reprime_context: bool = False, persist_context: bool = False,
+                 torch_image_encoder: bool = False):
         self.spec = spec
         # host copy of the weights: lets the agent cross a process boundary (make_pickleable / reinit_cuda_kernels)
         self._state_dict = {k: v.detach().to("cpu") for k, v in state_dict.items()}
@@ -60,8 +61,11 @@ class RecurrentAgent:
         self.policy = self  # `model.predict(model.policy, ...)`: the policy argument is accepted and ignored
         self.state_mean = None if state_mean is None else state_mean.to(self.device, torch.float32)
         self.state_std = None if state_std is None else state_std.to(self.device, torch.float32)
+        # image observations go through the engine's own IMPALA-CNN kernels (lram_embed_images); the PyTorch / MIOpen
+        # module (image_encoder.ImageEncoder) is only built on request, as a cross-check
+        self.has_image_encoder = any(k.startswith("embed_image.") for k in state_dict) and spec.image_shape is not None
         self.image_encoder = None
-        if any(k.startswith("embed_image.") for k in state_dict) and spec.image_shape is not None:
+        if torch_image_encoder and self.has_image_encoder:
             self.image_encoder = ImageEncoder.from_state_dict(state_dict, spec.image_shape, spec.d_model).to(self.device)
         # attributes read by the evaluation loop
         self.eval_context_len = spec.max_length
@@ -134,9 +138,11 @@ class RecurrentAgent:
         or the image encoder; returns (tensor, is_embedding)."""
         obs = obs.to(self.device)
         if obs.dim() == 4:
-            if self.image_encoder is None:
+            if not self.has_image_encoder:
                 raise RuntimeError("image observation given but the state dict has no embed_image.* weights")
-            return self.image_encoder(obs).contiguous(), True
+            if self.image_encoder is not None:
+                return self.image_encoder(obs).contiguous(), True
+            return self.engine.embed_images(obs.to(torch.uint8).contiguous()), True
         obs = obs.to(torch.float32)
         pad = self.spec.state_dim - obs.shape[-1]
         if pad < 0:

@@ -208,6 +208,22 @@ struct MambaSsmArgs {
 };
 void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// IMPALA-CNN image front end (impala_cnn.hip)
+// ---------------------------------------------------------------------------------------------
+struct Conv3x3Args {
+  const void* in;         // [B, CIN, H, W] float (or uint8 when in_u8: scaled by 1/255 while staging)
+  const float* w;         // [COUT, CIN, 3, 3]
+  const float* bias;      // [COUT]
+  const float* residual;  // optional [B, COUT, H, W], added to the output
+  float* out;             // [B, COUT, H, W]
+  int B, CIN, COUT, H, W;
+  int in_relu, out_relu, in_u8;
+};
+void launch_conv3x3(const Conv3x3Args& a, hipStream_t stream);
+void launch_maxpool3s2(const float* in, float* out, int64_t planes, int H, int W, hipStream_t stream);
+void launch_relu(float* x, int64_t n, hipStream_t stream);
+
 // misc
 void launch_pad_obs(const float* native, int n_native, const int32_t* inv_index, const float* mean, const float* stdv,
                     float* out, int B, int state_dim, hipStream_t stream);

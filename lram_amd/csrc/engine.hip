@@ -90,6 +90,16 @@ struct lram_engine {
   const float *w_state = nullptr, *b_state = nullptr, *w_rtg = nullptr, *b_rtg = nullptr, *w_rew = nullptr,
               *b_rew = nullptr, *eln_g = nullptr, *eln_b = nullptr, *w_head = nullptr, *b_head = nullptr,
               *post_g = nullptr, *post_b = nullptr;
+  // IMPALA-CNN image front end (optional: present when the embed_image.* weights were uploaded)
+  struct ImgConv {
+    const float *w = nullptr, *b = nullptr;
+    int cin = 0, cout = 0;
+  };
+  ImgConv img_conv[3][5];  // [stage][stage conv, res0.conv_0, res0.conv_1, res1.conv_0, res1.conv_1]
+  const float *img_lin_w = nullptr, *img_lin_b = nullptr;
+  int img_channels = 0, img_flat = 0;  // input channels, flattened feature count of the linear layer
+  DevBuf IMG_P, IMG_X0, IMG_X1, IMG_T;
+  size_t img_cap = 0;  // batch * input pixels the image buffers were sized for
   // state + workspace
   int B = 0;
   std::vector<BlockState> st;
@@ -155,8 +165,9 @@ struct lram_engine {
     }
     st.clear();
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
-                      &AMAT, &VEC})
+                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T})
       b->release();
+    img_cap = 0;
     B = 0;
     tok_cap = 0;
   }
@@ -279,6 +290,36 @@ void finalize(lram_engine* e) {
       w.proj_down = need(e, p + "proj_down", D * inner);
     }
   }
+  // optional image front end: embed_image.* with the reference's module names (image_encoders.py:39-56)
+  e->img_lin_w = nullptr;
+  e->img_channels = 0;
+  {
+    auto it = e->weights.find("embed_image.cnn.0.conv.weight");
+    if (it != e->weights.end()) {
+      const int chans[3] = {16, 32, 32};
+      LRAM_REQUIRE(it->second.n % (16 * 9) == 0, "embed_image.cnn.0.conv.weight has an unexpected size");
+      int cin = (int)(it->second.n / (16 * 9));
+      e->img_channels = cin;
+      for (int sidx = 0; sidx < 3; ++sidx) {
+        const int cout = chans[sidx];
+        const std::string p = "embed_image.cnn." + std::to_string(sidx) + ".";
+        const char* names[5] = {"conv", "residual_0.conv_0", "residual_0.conv_1", "residual_1.conv_0", "residual_1.conv_1"};
+        for (int k = 0; k < 5; ++k) {
+          lram_engine::ImgConv& cv = e->img_conv[sidx][k];
+          cv.cin = k == 0 ? cin : cout;
+          cv.cout = cout;
+          cv.w = need(e, p + names[k] + ".weight", (size_t)cout * cv.cin * 9);
+          cv.b = need(e, p + names[k] + ".bias", (size_t)cout);
+        }
+        cin = cout;
+      }
+      auto lw = e->weights.find("embed_image.linear.0.weight");
+      LRAM_REQUIRE(lw != e->weights.end() && lw->second.n % D == 0, "embed_image.linear.0.weight missing or mis-sized");
+      e->img_flat = (int)(lw->second.n / D);
+      e->img_lin_w = lw->second.p;
+      e->img_lin_b = need(e, "embed_image.linear.0.bias", D);
+    }
+  }
   // bf16 split planes of every GEMM weight (LRAM_GEMM=f32 keeps the exact fp32-MFMA kernels instead)
   e->drop_splits();
   if (const char* v = std::getenv("LRAM_GEMM")) e->use_bf16x3 = std::string(v) != "f32";
@@ -288,7 +329,7 @@ void finalize(lram_engine* e) {
         if (kv.second.p == p) return kv.second.n;
       return 0;
     };
-    std::vector<const float*> ws = {e->w_head};  // embed_state has K = state_dim (204): rows not 16-byte aligned
+    std::vector<const float*> ws = {e->w_head, e->img_lin_w};  // embed_state has K = state_dim (204): rows not 16-byte aligned
     for (const BlockWeights& w : e->bw)
       for (const float* p : {w.proj_up, w.proj_down, w.gate_w[0], w.gate_w[1], w.gate_w[2], w.gate_w[3], w.rt, w.ffn_up,
                              w.ffn_down, w.in_proj, w.x_proj, w.dt_proj, w.out_proj})
@@ -766,6 +807,55 @@ void run_stack(lram_engine* e, int T, const uint8_t* reset, const std::vector<Sl
     run_xlstm_stack(e, T, reset, sl, hbm);
 }
 
+// uint8 frames [B, C, H, W] -> state-token embeddings [B, d_model] (reference: embed_image(x / 255),
+// online_decision_transformer_model.py:523-526 + image_encoders.py:58-66)
+void embed_images(lram_engine* e, const uint8_t* images, int C, int H, int W, float* out, hipStream_t s) {
+  LRAM_REQUIRE(e->img_lin_w != nullptr, "lram_embed_images: no embed_image.* weights were uploaded");
+  LRAM_REQUIRE(C == e->img_channels, "lram_embed_images: channel count does not match embed_image.cnn.0.conv.weight");
+  const int B = e->B, D = e->cfg.d_model;
+  int h = H, w = W;
+  for (int k = 0; k < 3; ++k) h = (h - 1) / 2 + 1, w = (w - 1) / 2 + 1;
+  LRAM_REQUIRE(32 * h * w == e->img_flat, "lram_embed_images: image size does not match embed_image.linear.0.weight");
+  const size_t px = (size_t)B * H * W;
+  if (px > e->img_cap) {
+    LRAM_HIP_CHECK(hipDeviceSynchronize());
+    const size_t hp = (H - 1) / 2 + 1, wp = (W - 1) / 2 + 1;
+    e->IMG_P.alloc((size_t)B * 16 * H * W);       // stage-1 conv output before its pool (the largest tensor)
+    e->IMG_X0.alloc((size_t)B * 32 * hp * wp);    // pooled maps never exceed 32 channels at half resolution
+    e->IMG_X1.alloc((size_t)B * 32 * hp * wp);
+    e->IMG_T.alloc((size_t)B * 32 * hp * wp);
+    e->img_cap = px;
+  }
+  const void* in = images;
+  int in_u8 = 1;
+  h = H, w = W;
+  for (int sidx = 0; sidx < 3; ++sidx) {
+    const lram_engine::ImgConv* cv = e->img_conv[sidx];
+    auto conv = [&](const lram_engine::ImgConv& c, const void* src, int u8, int relu_in, const float* res, float* dst,
+                    int relu_out) {
+      Conv3x3Args a;
+      a.in = src, a.w = c.w, a.bias = c.b, a.residual = res, a.out = dst;
+      a.B = B, a.CIN = c.cin, a.COUT = c.cout, a.H = h, a.W = w, a.in_relu = relu_in, a.out_relu = relu_out, a.in_u8 = u8;
+      launch_conv3x3(a, s);
+    };
+    conv(cv[0], in, in_u8, 0, nullptr, e->IMG_P.p, 0);
+    launch_maxpool3s2(e->IMG_P.p, e->IMG_X0.p, (int64_t)B * cv[0].cout, h, w, s);
+    h = (h - 1) / 2 + 1, w = (w - 1) / 2 + 1;
+    conv(cv[1], e->IMG_X0.p, 0, 1, nullptr, e->IMG_T.p, 0);
+    conv(cv[2], e->IMG_T.p, 0, 1, e->IMG_X0.p, e->IMG_X1.p, 0);
+    conv(cv[3], e->IMG_X1.p, 0, 1, nullptr, e->IMG_T.p, 0);
+    conv(cv[4], e->IMG_T.p, 0, 1, e->IMG_X1.p, e->IMG_X0.p, sidx == 2 ? 1 : 0);  // act_flatten's ReLU on the last map
+    in = e->IMG_X0.p;
+    in_u8 = 0;
+  }
+  // stage s > 0 reads IMG_X0 and writes IMG_P, then pools back into IMG_X0: no aliasing within a launch
+  GemmArgs g;
+  g.a = e->IMG_X0.p, g.lda = e->img_flat, g.w = e->img_lin_w, g.ldw = e->img_flat, g.c = out, g.ldc = D;
+  g.bias = e->img_lin_b, g.m = B, g.n = D, g.k = e->img_flat;
+  gemm(e, g, s);
+  launch_relu(out, (int64_t)B * D, s);
+}
+
 // L consecutive timesteps for every env slot (L = 1: one env-step).  Inputs are [B, L, .] / [B, L] row-major; the
 // reset mask applies before the first timestep; the action head runs on the last timestep only (and only if an
 // output buffer is given).  One fork / join of the slice streams brackets the whole call.
@@ -1173,6 +1263,16 @@ int32_t lram_pad_obs(const float* dev_native, int32_t n_native, const int32_t* d
     LRAM_REQUIRE((dev_mean == nullptr) == (dev_std == nullptr), "lram_pad_obs: mean and std go together");
     launch_pad_obs(dev_native, n_native, dev_inv_index, dev_mean, dev_std, dev_out, batch, state_dim,
                    static_cast<hipStream_t>(stream));
+  });
+}
+
+int32_t lram_embed_images(lram_engine* e, const uint8_t* dev_images, int32_t channels, int32_t height, int32_t width,
+                          float* dev_embeddings, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0, "lram_embed_images: state not allocated (call lram_state_alloc)");
+    LRAM_REQUIRE(dev_images && dev_embeddings && channels > 0 && height > 0 && width > 0, "lram_embed_images: bad argument");
+    LRAM_HIP_CHECK(hipSetDevice(e->device));
+    embed_images(e, dev_images, channels, height, width, dev_embeddings, static_cast<hipStream_t>(stream));
   });
 }
 

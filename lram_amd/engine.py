@@ -64,6 +64,7 @@ _SYMBOLS = {
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_bf16x3": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
+    "lram_embed_images": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
     "lram_pad_obs": (ctypes.c_int32, [_VP, ctypes.c_int32, _VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_selftest_concurrent": (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]),
     "lram_stream_copy": (ctypes.c_int32, [_VP, _VP, ctypes.c_size_t, _VP]),
@@ -242,6 +243,21 @@ class Engine:
                                                _ptr(reward_seq), int(L), _ptr(reset_mask), int(discrete), _ptr(act),
                                                _ptr(tok), _stream_ptr(self.device)))
         return (act, tok) if want_action else (None, None)
+
+    def embed_images(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """uint8 frames [B, C, H, W] -> state-token embeddings [B, d_model] through the IMPALA CNN kernels
+        (`self.embed_image(state / 255)`, online_decision_transformer_model.py:523-526); feed the result to
+        step(..., obs_is_embedding=True).  Needs the embed_image.* weights in the state dict."""
+        B, D = self.batch, self.spec.d_model
+        if images.dim() != 4:
+            raise ValueError("images must be [B, C, H, W]")
+        _chk_dev(images, torch.uint8, (B, *images.shape[1:]), self.device, "images")
+        if out is None:
+            out = torch.empty(B, D, dtype=torch.float32, device=self.device)
+        _chk_dev(out, torch.float32, (B, D), self.device, "out")
+        _check(self.lib, self.lib.lram_embed_images(self._h, _ptr(images), int(images.shape[1]), int(images.shape[2]),
+                                                    int(images.shape[3]), _ptr(out), _stream_ptr(self.device)))
+        return out
 
     def encoder_step(self, inputs_embeds: torch.Tensor, reset_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`self.encoder(inputs_embeds=[B,T,D], use_cache=True)` plug point (decision_xlstm.py:138-169)."""

@@ -1,4 +1,7 @@
-"""IMPALA-style image observation encoder (PyTorch-ROCm / MIOpen; not a hand-kernel target).
+"""IMPALA-style image observation encoder in PyTorch-ROCm / MIOpen: a cross-check of the engine's own kernels
+(`lram_embed_images`, csrc/impala_cnn.hip), which are what `RecurrentAgent` uses; built only on request
+(`RecurrentAgent(torch_image_encoder=True)`, tests, scripts/bench_image_encoder.py).
+
 
 Front end of the hot path for image domains (Atari / Procgen / Mimicgen-vision): uint8 [B,3,64,64] ->
 x/255 -> 3 x (conv3x3 -> maxpool(3,2,1) -> 2 residual blocks) with 16/32/32 channels -> ReLU -> flatten ->

@@ -221,6 +221,10 @@ def engine_layout(spec: ModelSpec, sd: Dict[str, torch.Tensor]) -> Dict[str, tor
     }
     if "embed_ln.bias" in sd and sd["embed_ln.bias"] is not None:
         out["embed_ln.bias"] = f32(sd["embed_ln.bias"])
+    # IMPALA-CNN image front end: uploaded under the reference's own module names (csrc/impala_cnn.hip)
+    for k, v in sd.items():
+        if k.startswith("embed_image."):
+            out[k] = f32(v).reshape(-1)
     if spec.backbone == "xlstm":
         res = not spec.rms_norm
         for i in range(spec.n_blocks):

@@ -89,7 +89,8 @@ def test_agent_predict_surface_single_env(hip_lib):
 
 
 def test_batched_rollout_on_device_with_images(hip_lib):
-    """Discrete image domain end to end: uint8 frames -> ImageEncoder (MIOpen) -> engine -> argmax over 18."""
+    """Discrete image domain end to end: uint8 frames -> IMPALA-CNN kernels (lram_embed_images) -> engine -> argmax
+    over 18."""
     from lram_amd.agent import RecurrentAgent
     from lram_amd.config import ModelSpec
     from lram_amd.rollout import BatchedRollout, SyntheticVecEnv
@@ -108,6 +109,38 @@ def test_batched_rollout_on_device_with_images(hip_lib):
         assert a.dtype == torch.int64 and a.shape == (B, 1)
         lg = dbg["logits"].reshape(B, -1)[:, :18]
         gap = lg.topk(2, -1).values
-        clear = (gap[:, 0] - gap[:, 1]) > 1e-3  # MIOpen conv vs CPU conv: tolerate numerical ties only
+        clear = (gap[:, 0] - gap[:, 1]) > 1e-3  # device conv vs CPU conv: tolerate numerical ties only
         assert torch.equal(a.cpu()[clear], ref[clear]), t
     agent.engine.close()
+
+
+@pytest.mark.parametrize("d_model,B", [(128, 5), (1280, 3)])
+def test_image_encoder_kernels_match_oracle(hip_lib, d_model, B):
+    """lram_embed_images (hand-written conv3x3 / maxpool / linear) == the oracle's ImpalaCNN restatement
+    (image_encoders.py:10-131) == the PyTorch/MIOpen module, on uint8 frames; odd batch, both model widths."""
+    from lram_amd.config import ModelSpec
+    from lram_amd.engine import Engine
+    from lram_amd.image_encoder import ImageEncoder
+    from oracle.dt_ref import impala_cnn
+    spec = ModelSpec(backbone="xlstm", d_model=d_model, n_blocks=2, slstm_at=[1])
+    sd = init_state_dict(spec, seed=7, with_image_encoder=True)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (B, 3, 64, 64), generator=g, dtype=torch.uint8)
+    ref = impala_cnn(sd, "embed_image.", img.float() / 255.0)
+    eng = Engine(spec, sd, B, device="cuda:0")
+    out = eng.embed_images(img.cuda())
+    out2 = eng.embed_images(img.cuda())          # second call reuses the buffers
+    torch.cuda.synchronize()
+    assert out.shape == (B, d_model)
+    scale = float(ref.abs().max())
+    assert float((out.cpu() - ref).abs().max()) <= 2e-5 * scale
+    assert torch.equal(out, out2)
+    mi = ImageEncoder.from_state_dict(sd, (3, 64, 64), d_model).cuda()(img.cuda())
+    assert float((out - mi).abs().max()) <= 5e-5 * scale
+    with pytest.raises(Exception):
+        eng.embed_images(torch.zeros(B, 4, 64, 64, dtype=torch.uint8).cuda())     # wrong channel count
+    eng.close()
+    plain = Engine(spec, init_state_dict(spec, seed=7), B, device="cuda:0")
+    with pytest.raises(Exception):
+        plain.embed_images(img.cuda())                                            # no embed_image.* weights
+    plain.close()
