@@ -95,6 +95,9 @@ def main():
                     help="strong scaling: total env slots, split over the ranks with lram_amd.dist.shard_bounds "
                          "(overrides --batch; BASELINE C4: 4096 over 8 GPUs)")
     ap.add_argument("--config", default="xlstm_16m", help="preset name (lram_amd.config.preset)")
+    ap.add_argument("--obs", choices=("state", "image"), default="state",
+                    help="image: uint8 [3,64,64] frames through the IMPALA-CNN front end + 18-way discrete head "
+                         "(BASELINE C4, Atari-shaped)")
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph")
     ap.add_argument("--micro", type=int, default=0, help="env slices pipelined on separate streams (0 = auto, 1 = off)")
     ap.add_argument("--side-stream", action="store_true", help="issue the steps on a non-default HIP stream")
@@ -117,7 +120,7 @@ def main():
     ldist.barrier()
 
     spec = preset(args.config)
-    sd = init_state_dict(spec, seed=0)
+    sd = init_state_dict(spec, seed=0, with_image_encoder=args.obs == "image")
     B, T, K, W = args.batch, spec.tokens_per_step, args.steps, args.warmup
     if args.global_batch > 0:
         lo, hi = ldist.shard_bounds(args.global_batch, rank, world)
@@ -145,9 +148,18 @@ def main():
     reward_tok = torch.zeros(B, device=dev)                       # reward token is 0 in the reference loop (Q3)
     torch.cuda.synchronize()
 
+    img_ring = None
+    if args.obs == "image":
+        img_ring = torch.randint(0, 256, (n_ring, B, 3, 64, 64), generator=g, device=dev, dtype=torch.uint8)
+        emb = torch.empty(B, spec.d_model, device=dev)
+
     def one_step(t):
         t = t % steps_total
-        a, _ = eng.step(obs_ring[t % n_ring], rtgs[t], reward_tok, masks[t])
+        if img_ring is not None:
+            eng.embed_images(img_ring[t % n_ring], emb)
+            a, _ = eng.step(emb, rtgs[t], reward_tok, masks[t], discrete=True, obs_is_embedding=True)
+        else:
+            a, _ = eng.step(obs_ring[t % n_ring], rtgs[t], reward_tok, masks[t])
         if world > 1:
             a = ldist.all_gather_actions(a, args.global_batch if args.global_batch > 0 else None)
         return a
@@ -240,7 +252,8 @@ def main():
         "scaling": "strong" if args.global_batch > 0 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: xLSTM[7:1] 16M rollout, {B} env slots per GPU, 3 tokens/timestep, "
                                "cheetah-run-shaped obs (17 of 204 dims), continuous 8x274 head"
-                   if args.config == "xlstm_16m" else f"{args.config}, {B} env slots per GPU",
+                   if args.config == "xlstm_16m" and args.obs == "state"
+                   else f"{args.config}, {B} env slots per GPU, {args.obs} observations",
                    "batch_per_gpu": B, "global_batch": args.global_batch if args.global_batch > 0 else B * world, "tokens_per_step": T,
                    "state_bytes_per_env": spec.state_bytes_per_env(), "parallelism": f"env-shard x{world}",
                    "graph": bool(args.graph), "micro_batches": args.micro},

@@ -14,3 +14,4 @@ run --config mamba_48m --batch 2048 --steps 32 --warmup 4
 run --config mamba_48m --batch 1 --steps 100 --warmup 10 --graph
 run --config xlstm_206m --batch 512 --steps 16 --warmup 2
 run --config xlstm_206m --batch 512 --steps 16 --warmup 2 --micro 1
+run --config xlstm_206m --batch 512 --steps 16 --warmup 2 --obs image
