@@ -20,6 +20,46 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _exec_pieces(path, names):
+    """Execute only the named top-level assignments / functions of a reference file (its imports need robosuite /
+    dmc2gym, which are absent): the observation-space tables and `map_flattened_obs_to_full_space`."""
+    import ast
+    import numpy as np
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body
+            if (isinstance(n, ast.Assign) and any(getattr(t, "id", None) in names for t in n.targets))
+            or (isinstance(n, ast.FunctionDef) and n.name in names)]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def obs_full_space_vectors(g):
+    """Inputs / outputs of the reference's flattened-observation -> full-space mapping for one DMControl and one
+    Mimicgen observation spec (src/envs/dmcontrol_utils.py:35-78, src/envs/mimicgen_utils.py:58-78,199-214)."""
+    import numpy as np
+    out = {}
+    cases = {
+        "dmc_cheetah_run": ("src/envs/dmcontrol_utils.py", ["DMC_OBSTYPE_TO_DIM", "DMC_FULL_OBS_DIM", "DMC_OBSTYPE_TO_STARTIDX"],
+                            [("position", 8), ("velocity", 9)]),
+        "dmc_walker_walk": ("src/envs/dmcontrol_utils.py", ["DMC_OBSTYPE_TO_DIM", "DMC_FULL_OBS_DIM", "DMC_OBSTYPE_TO_STARTIDX"],
+                            [("orientations", 14), ("height", 1), ("velocity", 9)]),
+        "mimicgen_main_lowdim": ("src/envs/mimicgen_utils.py",
+                                 ["MIMICGEN_OBSTYPE_TO_DIM", "MIMICGEN_FULL_OBS_DIM", "MIMICGEN_OBSTYPE_TO_STARTIDX"],
+                                 [("robot0_eef_pos", 3), ("robot0_eef_quat", 4), ("robot0_gripper_qpos", 2), ("object", 23)]),
+    }
+    for name, (rel, tables, spec) in cases.items():
+        ns = _exec_pieces(os.path.join(REF, rel), tables + ["map_flattened_obs_to_full_space"])
+        n = sum(d for _, d in spec)
+        x = (torch.rand(4, n, generator=g) * 2 - 1).numpy().astype(np.float32)
+        obs_spec = {k: np.zeros(d, dtype=np.float32) for k, d in spec}   # the function reads .shape of each entry
+        full = ns["map_flattened_obs_to_full_space"](x, obs_spec)
+        dims = ns[tables[0]]
+        out[name] = {"spec": [[k, d] for k, d in spec], "x": x.tolist(), "full": np.asarray(full, dtype=np.float32).tolist(),
+                     "full_dim": int(ns[tables[1]]), "obstype_to_dim": {k: int(v) for k, v in dims.items()}}
+    return out
+
+
 def main():
     sys.path.insert(0, REF)
     from src.tokenizers_custom import make_tokenizer  # reference code, executed not copied
@@ -51,6 +91,8 @@ def main():
             y = norm(xin)
         cases.append({"eps": eps, "weight": norm.weight.tolist(), "x": xin.tolist(), "y": y.tolist()})
     out["llama_rms_norm"] = cases
+
+    out["obs_full_space"] = obs_full_space_vectors(g)
 
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as fh:
         json.dump(out, fh)

@@ -57,3 +57,23 @@ def test_oracle_reproduces_kat(name):
                           discrete=kw["discrete"], return_debug=True)
         assert np.array_equal(a.numpy().astype(np.float32), kat["actions"][t]), (name, t)
         assert rel_err(dbg["hidden"], torch.from_numpy(kat["hidden"][t])) < 1e-5
+
+
+def test_obs_full_space_tables_match_the_reference_mapping():
+    """lram_amd/obs.py's DMControl / Mimicgen slot tables and index construction reproduce the reference's own
+    `map_flattened_obs_to_full_space` (executed by make_golden_from_reference.py) on its inputs."""
+    import json
+    import os
+    from lram_amd import obs
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))["obs_full_space"]
+    tables = {"dmc": obs.DMC_OBSTYPE_TO_DIM, "mimicgen": obs.MIMICGEN_OBSTYPE_TO_DIM}
+    for name, case in vec.items():
+        table = tables[name.split("_")[0]]
+        assert table == case["obstype_to_dim"] and list(table) == list(case["obstype_to_dim"]), name  # values and order
+        assert sum(table.values()) == case["full_dim"]
+        inv = obs.inverse_index([tuple(x) for x in case["spec"]], table, 204)
+        x = torch.tensor(case["x"])
+        full = torch.tensor(case["full"])
+        got = obs.apply_inverse_index(x, inv)
+        assert got.shape == (x.shape[0], 204)
+        assert torch.equal(got[:, : case["full_dim"]], full) and not bool(got[:, case["full_dim"]:].any())
