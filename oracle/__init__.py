@@ -14,11 +14,15 @@ never imports it; the product path raises when the HIP library is missing.
 
 PARITY PINNING STATUS
 ---------------------
-* Reference-repo files on the path that can be imported in the build container
-  (``src/tokenizers_custom/minmax_tokenizer.py``, ``src/algos/models/rms_norm.py``)
-  were executed there and their input/output vectors are committed under
-  ``tests/golden/`` (``make_golden_from_reference.py`` is the generating script).
-  ``oracle.dt_ref`` is pinned against them.
+* Reference code on the path that can be executed in the build container was executed
+  there and its input/output vectors are committed under ``tests/golden/``
+  (``make_golden_from_reference.py`` is the generating script): the action tokenizer and
+  ``LlamaRMSNorm`` (importable files), and -- lifted out of modules whose imports need
+  gym / stable_baselines3 by executing only the named classes / methods -- the token front
+  end (``compute_inputs`` ... ``prepare_inputs_and_masks``), the head post-processing
+  (``prepare_action_logits`` / ``get_action_from_logits``), the ImpalaCNN block modules and
+  the DMControl / Mimicgen full-space observation mapping.  ``oracle.dt_ref`` is pinned
+  against them (tests/test_oracle_golden.py).
 * The recurrent arithmetic itself lives in third-party, un-vendored packages that
   are NOT under /root/reference and NOT installed here: ``xlstm`` (unpinned,
   reference README.md:94-97, API of 1.0.x), ``mamba_ssm==2.1.0``,

@@ -77,12 +77,13 @@ def embed_tokens(spec, sd, obs, rtg, reward, state_mean=None, state_std=None):
     return F.layer_norm(x, (x.shape[-1],), sd["embed_ln.weight"], sd.get("embed_ln.bias"), eps=1e-5)
 
 
-def action_head(spec, sd, x_a, discrete):
-    """x_a: (B, D) hidden at the rtg-token position.  Returns (action, logits).
+def actions_from_logits(spec, logits, discrete):
+    """action_net output (B, act_dim * n_vocab) -> (action, logits as the reference shapes them).
+    multi_domain_discrete_dt_model.py:83-108 (prepare_action_logits + get_action_from_logits), shared head;
+    pinned against the reference's own methods by tests/golden/reference_vectors.json `action_from_logits`.
 
     continuous: logits (B, act_dim, n_vocab) -> argmax -> inv_tokenize -> float (B, act_dim)
     discrete  : logits[:, :n_vocab][:, :n_discrete] -> argmax -> int64 (B, 1)"""
-    logits = F.linear(x_a, sd["action_net.0.weight"], sd["action_net.0.bias"])
     B = logits.shape[0]
     if discrete:
         lg = logits[:, : spec.n_vocab]
@@ -91,6 +92,11 @@ def action_head(spec, sd, x_a, discrete):
     lg = logits.view(B, spec.act_dim, spec.n_vocab)
     tok = torch.argmax(lg, dim=-1)
     return minmax_inv_tokenize(tok, spec.action_channels, spec.n_discrete), lg
+
+
+def action_head(spec, sd, x_a, discrete):
+    """x_a: (B, D) hidden at the rtg-token position.  Returns (action, logits)."""
+    return actions_from_logits(spec, F.linear(x_a, sd["action_net.0.weight"], sd["action_net.0.bias"]), discrete)
 
 
 class OraclePolicy:

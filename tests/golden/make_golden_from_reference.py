@@ -60,6 +60,114 @@ def obs_full_space_vectors(g):
     return out
 
 
+def _exec_methods(path, class_name, names):
+    """Execute only the named methods of one class of a reference file as plain functions (the module's imports
+    need gym / stable_baselines3)."""
+    import ast
+    tree = ast.parse(open(path).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == class_name)
+    keep = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def action_from_logits_vectors(g, tok):
+    """Head post-processing of the multi-domain model, executed from the reference with a stand-in `self`
+    (multi_domain_discrete_dt_model.py:83-108: prepare_action_logits + get_action_from_logits; shared action head,
+    8 x 274 logits, 18 discrete actions, min-max tokenizer with shift 18)."""
+    from types import SimpleNamespace
+    ns = _exec_methods(os.path.join(REF, "src/algos/models/multi_domain_discrete_dt_model.py"),
+                       "MultiDomainDiscreteDTModel", ["get_action_from_logits", "prepare_action_logits"])
+    me = SimpleNamespace(discrete_actions=18, tokenize_a=True, tok_a_target_only=False, shared_a_head=True,
+                         num_actions=274, action_channels=256, config=SimpleNamespace(act_dim=8),
+                         inv_tokenize_actions=lambda a: tok.inv_tokenize(a))
+    B = 6
+    raw = torch.randn(B, 1, 1, 8 * 274, generator=g)          # action_net output at the one prediction position
+    cont = ns["get_action_from_logits"](me, ns["prepare_action_logits"](me, raw.clone(), is_discrete=False), is_discrete=False)
+    disc = ns["get_action_from_logits"](me, ns["prepare_action_logits"](me, raw.clone(), is_discrete=True), is_discrete=True)
+    return {"logits": raw.reshape(B, -1).tolist(), "continuous": cont.reshape(B, 8).tolist(),
+            "discrete": disc.reshape(B).tolist()}
+
+
+def token_front_end_vectors(g):
+    """(state, return-to-go, reward) token construction with the inference cache on, executed from the reference
+    (online_decision_transformer_model.py:463-530 compute_inputs / embed_inputs, :287-311 getters, :545-612
+    construct_inputs_and_masks / prepare_inputs_and_masks) on a stand-in `self` that carries plain nn modules with
+    the multi_domain model kwargs (reward_condition, rtg_condition, no action tokens, no time embeddings)."""
+    import torch.nn as nn
+    names = ["compute_inputs", "embed_inputs", "construct_inputs_and_masks", "prepare_inputs_and_masks",
+             "get_state_embeddings", "get_return_embeddings", "get_reward_embeddings"]
+    ns = _exec_methods(os.path.join(REF, "src/algos/models/online_decision_transformer_model.py"),
+                       "OnlineDecisionTransformerModel", names)
+    D, S, B, T = 16, 204, 3, 4
+    Fake = type("Fake", (), {n: ns[n] for n in names})
+    me = Fake()
+    torch.manual_seed(11)
+    me.embed_state, me.embed_return, me.embed_rewards = nn.Linear(S, D), nn.Linear(1, D), nn.Linear(1, D)
+    me.embed_ln = nn.LayerNorm(D)
+    with torch.no_grad():
+        me.embed_ln.weight.copy_(torch.randn(D) * 0.3 + 1.0)
+        me.embed_ln.bias.copy_(torch.randn(D) * 0.1)
+    me.get_action_embeddings = lambda a, attention_mask=None: None
+    me.rtg_condition, me.reward_condition, me.action_condition = True, True, False
+    me.use_time_embds, me.symlog_transform, me.img_is_encoded, me.separate_ln = False, False, False, False
+    me.training, me.p_mask, me.p_token_drop, me.hidden_size = False, 0, 0, D
+    me.config = type("Cfg", (), {"add_cross_attention": False, "hidden_size": D})()
+    states = torch.rand(B, T, S, generator=g) * 2 - 1
+    actions = torch.zeros(B, T, 8)
+    rtg = torch.rand(B, T, 1, generator=g) * 5
+    rewards = torch.rand(B, T, 1, generator=g)
+    timesteps = torch.arange(T).repeat(B, 1)
+    mask = torch.ones(B, T, dtype=torch.long)
+    with torch.no_grad():
+        _, stacked, smask = me.compute_inputs(states, actions, rtg, rewards, timesteps, mask, use_inference_cache=True)
+    sd = {"embed_state.weight": me.embed_state.weight, "embed_state.bias": me.embed_state.bias,
+          "embed_return.weight": me.embed_return.weight, "embed_return.bias": me.embed_return.bias,
+          "embed_rewards.weight": me.embed_rewards.weight, "embed_rewards.bias": me.embed_rewards.bias,
+          "embed_ln.weight": me.embed_ln.weight, "embed_ln.bias": me.embed_ln.bias}
+    return {"state_dict": {k: v.detach().tolist() for k, v in sd.items()},
+            "states": states.tolist(), "returns_to_go": rtg.tolist(), "rewards": rewards.tolist(),
+            "stacked_inputs": stacked.tolist(), "stacked_attention_mask": smask.tolist(),
+            "tok_to_pred_pos": dict(me.tok_to_pred_pos), "tok_to_pos": dict(me.tok_to_pos)}
+
+
+def impala_cnn_vectors(g):
+    """The reference's ImpalaCNNBlock / ImpalaCNNResidual modules (src/algos/models/image_encoders.py:76-131), executed
+    as they are; chained as ImpalaCNN.__init__/forward chain them (:39-66: 16 / 32 / 32 channels, ReLU, Flatten,
+    Linear, ReLU) -- the ImpalaCNN class itself derives from stable_baselines3's BaseFeaturesExtractor, which is absent.
+    Weights, one uint8 batch and the outputs go to tests/golden/impala_cnn_reference.npz."""
+    import ast
+    import numpy as np
+    import torch.nn as nn
+    path = os.path.join(REF, "src/algos/models/image_encoders.py")
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("ImpalaCNNResidual", "ImpalaCNNBlock")]
+    ns = {"torch": torch, "nn": nn}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    torch.manual_seed(21)
+    ident = lambda p: p
+    cnn = nn.ModuleList([ns["ImpalaCNNBlock"](3, 16, norm_func=ident), ns["ImpalaCNNBlock"](16, 32, norm_func=ident),
+                         ns["ImpalaCNNBlock"](32, 32, norm_func=ident)])
+    D = 24
+    linear = nn.Sequential(nn.Linear(32 * 8 * 8, D), nn.ReLU())
+    img = torch.randint(0, 256, (2, 3, 64, 64), generator=g, dtype=torch.uint8)
+    with torch.no_grad():
+        x = img.float() / 255.0                      # online_decision_transformer_model.py:523-525
+        per_block = []
+        for block in cnn:
+            x = block(x)
+            per_block.append(x.clone())
+        out = linear(nn.Flatten()(torch.relu(x)))
+    arrays = {"images": img.numpy(), "out": out.numpy(), "block2": per_block[2].numpy()}
+    for k, v in cnn.state_dict().items():
+        arrays["embed_image.cnn." + k] = v.numpy()
+    for k, v in linear.state_dict().items():
+        arrays["embed_image.linear." + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "impala_cnn_reference.npz"), **arrays)
+    print("wrote", os.path.join(HERE, "impala_cnn_reference.npz"))
+
+
 def main():
     sys.path.insert(0, REF)
     from src.tokenizers_custom import make_tokenizer  # reference code, executed not copied
@@ -93,6 +201,9 @@ def main():
     out["llama_rms_norm"] = cases
 
     out["obs_full_space"] = obs_full_space_vectors(g)
+    out["action_from_logits"] = action_from_logits_vectors(g, tok)
+    out["token_front_end"] = token_front_end_vectors(g)
+    impala_cnn_vectors(g)
 
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as fh:
         json.dump(out, fh)

@@ -77,3 +77,52 @@ def test_obs_full_space_tables_match_the_reference_mapping():
         got = obs.apply_inverse_index(x, inv)
         assert got.shape == (x.shape[0], 204)
         assert torch.equal(got[:, : case["full_dim"]], full) and not bool(got[:, case["full_dim"]:].any())
+
+
+def test_action_head_postprocessing_matches_the_reference_methods():
+    """oracle.dt_ref.actions_from_logits == the reference's prepare_action_logits + get_action_from_logits
+    (executed by make_golden_from_reference.py with the real min-max tokenizer), continuous and discrete."""
+    import json
+    import os
+    from lram_amd import preset
+    from oracle import dt_ref
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))["action_from_logits"]
+    spec = preset("xlstm_16m")
+    logits = torch.tensor(vec["logits"])
+    cont, _ = dt_ref.actions_from_logits(spec, logits, discrete=False)
+    disc, _ = dt_ref.actions_from_logits(spec, logits, discrete=True)
+    assert torch.equal(cont, torch.tensor(vec["continuous"]))
+    assert disc.view(-1).tolist() == vec["discrete"]
+
+
+def test_token_front_end_matches_the_reference_methods():
+    """oracle.dt_ref.embed_tokens == the reference's compute_inputs(use_inference_cache=True) chain (executed by
+    make_golden_from_reference.py): last timestep only, token order (state, rtg, reward), embed_ln; and the action is
+    read at the rtg token (tok_to_pred_pos["a"] == 1 == ModelSpec.pred_token)."""
+    import json
+    import os
+    from lram_amd import preset
+    from oracle import dt_ref
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))["token_front_end"]
+    sd = {k: torch.tensor(v) for k, v in vec["state_dict"].items()}
+    states, rtg, rew = torch.tensor(vec["states"]), torch.tensor(vec["returns_to_go"]), torch.tensor(vec["rewards"])
+    spec = preset("xlstm_16m")
+    got = dt_ref.embed_tokens(spec, sd, states[:, -1], rtg[:, -1, 0], rew[:, -1, 0])
+    ref = torch.tensor(vec["stacked_inputs"])
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-6
+    assert vec["tok_to_pos"] == {"s": 0, "rtg": 1, "r": 2}
+    assert vec["tok_to_pred_pos"]["a"] == spec.pred_token == 1 and spec.tokens_per_step == 3
+
+
+def test_impala_cnn_matches_the_reference_modules():
+    """oracle.dt_ref.impala_cnn == the reference's ImpalaCNNBlock / ImpalaCNNResidual modules chained as ImpalaCNN
+    chains them (executed by make_golden_from_reference.py), from uint8 frames to the state-token embedding."""
+    import os
+    import numpy as np
+    from oracle import dt_ref
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "impala_cnn_reference.npz"))
+    sd = {k: torch.from_numpy(d[k]) for k in d.files if k.startswith("embed_image.")}
+    img = torch.from_numpy(d["images"])
+    out = dt_ref.impala_cnn(sd, "embed_image.", img.float() / 255.0)
+    ref = torch.from_numpy(d["out"])
+    assert out.shape == ref.shape and float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
