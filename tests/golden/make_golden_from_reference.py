@@ -168,6 +168,71 @@ def impala_cnn_vectors(g):
     print("wrote", os.path.join(HERE, "impala_cnn_reference.npz"))
 
 
+def agent_predict_trace(g):
+    """`agent.predict` -> `pad_inputs` -> `get_action_pred` executed from the reference over a short rollout, on a
+    stand-in `self` and with a recording stand-in for the policy network (decision_transformer_sb3.py:621-667,
+    algos/decision_xlstm.py:11-28, discrete_decision_transformer_sb3.py:13-72; the loop around it follows
+    callbacks/evaluation.py:130-177).  Stores what the policy network is handed at every step (padded, normalised
+    states; returns-to-go; reward tokens; whether the cache had been dropped) and what `predict` returns."""
+    from types import SimpleNamespace
+    fns = {}
+    fns.update(_exec_methods(os.path.join(REF, "src/algos/decision_transformer_sb3.py"), "DecisionTransformerSb3", ["predict"]))
+    fns.update(_exec_methods(os.path.join(REF, "src/algos/decision_xlstm.py"), "DecisionXLSTM", ["pad_inputs"]))
+    fns.update(_exec_methods(os.path.join(REF, "src/algos/discrete_decision_transformer_sb3.py"),
+                             "DiscreteDecisionTransformerSb3", ["get_action_pred"]))
+    obs_dim, env_act_dim, steps, freq = 39, 4, 8, 3          # Meta-World shaped: 39 -> 204, 4 of 8 action dims
+    Fake = type("Fake", (), {k: fns[k] for k in ("predict", "pad_inputs", "get_action_pred")})
+    me = Fake()
+    me.transforms, me.s_proj_dim, me.a_proj_dim, me.s_proj_raw = None, None, None, False
+    me.state_mean = torch.randn(204, generator=g) * 0.1
+    me.state_std = torch.rand(204, generator=g) + 0.5
+    me.reset_inf_cache_freq, me.past_key_values, me.use_inference_cache = freq, None, True
+    me.ddp_kwargs, me.target_return_type, me.a_sample_kwargs = {}, "predefined", None
+    me.use_amp, me.amp_dtype, me.device = False, torch.bfloat16, torch.device("cpu")
+    me.replay_buffer = SimpleNamespace(max_state_dim=204, max_act_dim=8)
+    me.policy = SimpleNamespace(tok_a_target_only=False, shared_a_head=True)
+    canned = torch.rand(steps, 8, generator=g) * 2 - 1
+    seen = []
+
+    def policy(**inputs):
+        t = len(seen)
+        seen.append({"states": inputs["states"].clone(), "returns_to_go": inputs["returns_to_go"].clone(),
+                     "rewards": inputs["rewards"].clone(), "cache_is_none": inputs["past_key_values"] is None,
+                     "use_inference_cache": bool(inputs["use_inference_cache"])})
+        T = inputs["actions"].shape[1]
+        return SimpleNamespace(action_preds=canned[t].expand(1, T, 8).clone(), past_key_values=f"kv{t}")
+
+    # the rollout bookkeeping of custom_evaluate_policy (evaluation.py:104-177), single env, no episode end
+    obs_all = torch.rand(steps + 1, obs_dim, generator=g) * 2 - 1
+    env_rewards = torch.rand(steps, generator=g)
+    reward_scale = 200.0
+    states = obs_all[:1].clone()
+    actions = torch.zeros((0, env_act_dim))
+    rewards = torch.zeros(0)
+    target_return = torch.tensor(6.5).reshape(1, 1)
+    timesteps = torch.tensor(0).reshape(1, 1)
+    returned = []
+    for t in range(steps):
+        actions = torch.cat([actions, torch.zeros((1, env_act_dim))], dim=0)
+        rewards = torch.cat([rewards, torch.zeros(1)])
+        a, _ = me.predict(policy, states, actions, rewards, target_return, timesteps, state=None, episode_start=None,
+                          deterministic=True, context_len=1, prompt=None, task_id=None, is_eval=True,
+                          env_act_dim=env_act_dim)
+        returned.append(a.clone())
+        actions[-1] = a
+        rewards[-1] = env_rewards[t] / reward_scale
+        states = torch.cat([states, obs_all[t + 1: t + 2]], dim=0)
+        target_return = torch.cat([target_return, (target_return[0, -1] - env_rewards[t] / reward_scale).reshape(1, 1)], dim=1)
+        timesteps = torch.cat([timesteps, torch.ones((1, 1), dtype=torch.long) * (t + 1)], dim=1)
+    return {"obs": obs_all.tolist(), "env_rewards": env_rewards.tolist(), "reward_scale": reward_scale,
+            "target_return0": 6.5, "env_act_dim": env_act_dim, "reset_inf_cache_freq": freq,
+            "state_mean": me.state_mean.tolist(), "state_std": me.state_std.tolist(), "canned_action_preds": canned.tolist(),
+            "policy_saw": [{"state_last": s["states"][0, -1].tolist(), "n_states": int(s["states"].shape[1]),
+                            "rtg_last": float(s["returns_to_go"][0, -1, 0]), "reward_last": float(s["rewards"][0, -1, 0]),
+                            "cache_is_none": s["cache_is_none"]} for s in seen],
+            "returned_actions": [a.tolist() for a in returned]}
+
+
 def main():
     sys.path.insert(0, REF)
     from src.tokenizers_custom import make_tokenizer  # reference code, executed not copied
@@ -204,6 +269,7 @@ def main():
     out["action_from_logits"] = action_from_logits_vectors(g, tok)
     out["token_front_end"] = token_front_end_vectors(g)
     impala_cnn_vectors(g)
+    out["agent_predict_trace"] = agent_predict_trace(g)
 
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as fh:
         json.dump(out, fh)

@@ -148,3 +148,60 @@ def test_persist_context_keeps_the_cache_across_episodes():
     assert bool(agent.calls[0][2].all())                                  # the very first step starts from a clean cache
     assert all(int(c[2].sum()) == 0 for c in agent.calls[1:])             # ... and nothing resets it afterwards
     assert abs(float(agent.calls[2][1][0]) - 1.0) < 1e-6                  # rtg restarts after the 2-step episode
+
+
+def test_agent_predict_follows_the_reference_trace():
+    """RecurrentAgent.predict / get_action_pred (host logic, engine replaced by a recorder) against the trace of the
+    reference's own predict -> pad_inputs -> get_action_pred chain (tests/golden `agent_predict_trace`, generated by
+    executing those methods): what reaches the network each step -- zero-padded, normalised last observation,
+    return-to-go, reward token -- the action slice handed back, and when the cache is dropped
+    (`reset_inf_cache_freq`)."""
+    import dataclasses
+    import json
+    from types import SimpleNamespace
+    from lram_amd.agent import RecurrentAgent, _InferenceParams
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))["agent_predict_trace"]
+    canned = torch.tensor(vec["canned_action_preds"])
+
+    class Recorder:
+        def __init__(self):
+            self.calls, self.resets, self.device = [], [], torch.device("cpu")
+
+        def step(self, obs, rtg, rew, reset_mask, discrete=False, obs_is_embedding=False):
+            self.calls.append((obs.clone(), float(rtg[0]), float(rew[0])))
+            return canned[len(self.calls) - 1].view(1, -1).clone(), None
+
+        def reset(self, mask=None):
+            self.resets.append(len(self.calls))
+
+    agent = object.__new__(RecurrentAgent)
+    agent.spec = dataclasses.replace(preset("xlstm_16m"), reset_inf_cache_freq=vec["reset_inf_cache_freq"])
+    agent.engine, agent.device, agent.n_envs, agent.is_discrete = Recorder(), torch.device("cpu"), 1, False
+    agent.policy, agent.image_encoder, agent.has_image_encoder = agent, None, False
+    agent.state_mean, agent.state_std = torch.tensor(vec["state_mean"]), torch.tensor(vec["state_std"])
+    agent.eval_context_len, agent.reset_inf_cache_freq = 1, vec["reset_inf_cache_freq"]
+    agent.reprime_context, agent._zero_reward = False, torch.zeros(1)
+    agent.inference_params = _InferenceParams(agent)
+    obs_all, env_r, scale = torch.tensor(vec["obs"]), torch.tensor(vec["env_rewards"]), vec["reward_scale"]
+    A = vec["env_act_dim"]
+    states, actions, rewards = obs_all[:1].clone(), torch.zeros((0, A)), torch.zeros(0)
+    rtg, ts = torch.tensor(vec["target_return0"]).reshape(1, 1), torch.tensor(0).reshape(1, 1)
+    for t, saw in enumerate(vec["policy_saw"]):
+        actions = torch.cat([actions, torch.zeros((1, A))])
+        rewards = torch.cat([rewards, torch.zeros(1)])
+        n_resets_before = len(agent.engine.resets)
+        a, _ = agent.predict(agent.policy, states, actions, rewards, rtg, ts, deterministic=True, context_len=1,
+                             is_eval=True, env_act_dim=A)
+        obs_seen, rtg_seen, rew_seen = agent.engine.calls[t]
+        assert torch.allclose(obs_seen[0], torch.tensor(saw["state_last"]), rtol=0, atol=1e-6), t
+        assert abs(rtg_seen - saw["rtg_last"]) < 1e-6 and rew_seen == saw["reward_last"] == 0.0, t
+        assert torch.allclose(a, torch.tensor(vec["returned_actions"][t])), t
+        # the reference drops the cache after the step: the *next* call sees past_key_values None
+        dropped_now = len(agent.engine.resets) > n_resets_before
+        if t + 1 < len(vec["policy_saw"]):
+            assert dropped_now == vec["policy_saw"][t + 1]["cache_is_none"], t
+        actions[-1] = a
+        rewards[-1] = env_r[t] / scale
+        states = torch.cat([states, obs_all[t + 1: t + 2]])
+        rtg = torch.cat([rtg, (rtg[0, -1] - env_r[t] / scale).reshape(1, 1)], dim=1)
+        ts = torch.cat([ts, torch.full((1, 1), t + 1)], dim=1)
