@@ -106,7 +106,7 @@ def main():
     args = ap.parse_args()
 
     from lram_amd import build, dist as ldist, init_state_dict, preset
-    from lram_amd.engine import Engine, stream_copy
+    from lram_amd.engine import Engine, stream_copy, stream_rmw
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the engine has no CPU fallback")
@@ -244,6 +244,14 @@ def main():
         stream_copy(dst, src)
     torch.cuda.synchronize()
     copy_gbps = 5 * 2 * n_copy * 4 / (time.perf_counter() - c0) / 1e9
+    # the same bytes as an in-place read-modify-write with the cell kernel's access pattern (no arithmetic)
+    stream_rmw(src)
+    torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(5):
+        stream_rmw(src)
+    torch.cuda.synchronize()
+    rmw_gbps = 5 * 2 * n_copy * 4 / (time.perf_counter() - c0) / 1e9
     del src, dst
 
     out = {
@@ -259,8 +267,13 @@ def main():
                    "graph": bool(args.graph), "micro_batches": args.micro},
         "roofline": roofline,
         "hbm_copy_measured_GBps": copy_gbps,
+        "hbm_rmw_measured_GBps": rmw_gbps,
         "algorithmic_bytes_per_env_step": 2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim,
     }
+    if roofline.get("achieved"):
+        roofline["frac_of_rmw_stream"] = roofline["achieved"] / rmw_gbps
+        if "standalone" in roofline:
+            roofline["standalone"]["frac_of_rmw_stream"] = roofline["standalone"]["achieved"] / rmw_gbps
     out["whole_step_algorithmic_GBps"] = out["algorithmic_bytes_per_env_step"] * value / world / 1e9
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         eng.close()

@@ -216,6 +216,11 @@ int32_t lram_selftest_concurrent(int32_t iters, int64_t* n_diff);
 /* STREAM-like device copy (float4), used by bench.py to measure the achievable HBM rate on the box. */
 int32_t lram_stream_copy(float* dev_dst, const float* dev_src, size_t numel, void* stream);
 
+/* Measurement aid: in-place read-modify-write stream (x *= 1) over `numel` floats (a multiple of 65536) with the
+ * access pattern of the mLSTM cell kernel and none of its arithmetic -- the practical ceiling for "read the state
+ * once, write it once" that bench.py reports beside the cell kernel's rate. */
+int32_t lram_stream_rmw(float* dev_buf, size_t numel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

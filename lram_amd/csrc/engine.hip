@@ -1280,4 +1280,8 @@ int32_t lram_stream_copy(float* dev_dst, const float* dev_src, size_t numel, voi
   return guarded([&] { launch_stream_copy(dev_dst, dev_src, numel, static_cast<hipStream_t>(stream)); });
 }
 
+int32_t lram_stream_rmw(float* dev_buf, size_t numel, void* stream) {
+  return guarded([&] { launch_stream_rmw(dev_buf, numel, static_cast<hipStream_t>(stream)); });
+}
+
 }  // extern "C"

@@ -206,6 +206,27 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(float4* dst, const flo
   for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// In-place read-modify-write stream with the access pattern of mlstm_cell_kernel and none of its arithmetic: one
+// workgroup per contiguous 256 KiB block (256 rows of 1 KiB), a wave reads whole rows, 16 rows (16 x 16 B per lane)
+// in flight per thread, non-temporal loads and stores, one workgroup per CU (LDS request).  Its rate is the
+// practical ceiling for "read the state once, write it once" on this part.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_rmw_kernel(float* buf, float scale) {
+  extern __shared__ float pad_lds[];
+  (void)pad_lds;
+  float* blk = buf + (size_t)blockIdx.x * 65536;  // 256 rows x 256 floats
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  for (int r0 = rg; r0 < 256; r0 += 64) {
+    v4f_t c[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      c[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(blk + (size_t)(r0 + 4 * u) * 256 + 4 * cl));
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      __builtin_nontemporal_store(c[u] * scale, reinterpret_cast<v4f_t*>(blk + (size_t)(r0 + 4 * u) * 256 + 4 * cl));
+  }
+}
+
 // buf viewed as [outer][B][row_elems] with outer stride `outer_stride`; zero row b where mask[b] != 0
 // (mask == nullptr: every row).
 __global__ __launch_bounds__(256) void zero_rows_kernel(float* buf, const uint8_t* mask, int B, int64_t row_elems,
@@ -279,6 +300,18 @@ void launch_stream_copy(float* dst, const float* src, size_t numel, hipStream_t 
   LRAM_REQUIRE(numel % 4 == 0, "stream copy: numel must be a multiple of 4");
   hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, stream, reinterpret_cast<float4*>(dst),
                      reinterpret_cast<const float4*>(src), numel / 4);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_stream_rmw(float* buf, size_t numel, hipStream_t stream) {
+  LRAM_REQUIRE(numel % 65536 == 0 && numel > 0, "stream rmw: numel must be a positive multiple of 65536");
+  static bool raised = false;
+  if (!raised) {
+    LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_rmw_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
+    raised = true;
+  }
+  hipLaunchKernelGGL(stream_rmw_kernel, dim3((unsigned)(numel / 65536)), dim3(256), 84 * 1024, stream, buf, 1.0f);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

@@ -65,6 +65,7 @@ _SYMBOLS = {
     "lram_gemm_bf16x3": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_embed_images": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
+    "lram_stream_rmw": (ctypes.c_int32, [_VP, ctypes.c_size_t, _VP]),
     "lram_pad_obs": (ctypes.c_int32, [_VP, ctypes.c_int32, _VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_selftest_concurrent": (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]),
     "lram_stream_copy": (ctypes.c_int32, [_VP, _VP, ctypes.c_size_t, _VP]),
@@ -388,3 +389,10 @@ def pad_obs(native: torch.Tensor, state_dim: int, inv_index: Optional[torch.Tens
 def stream_copy(dst: torch.Tensor, src: torch.Tensor):
     lib = load_library()
     _check(lib, lib.lram_stream_copy(_ptr(dst), _ptr(src), src.numel(), _stream_ptr(src.device)))
+
+
+def stream_rmw(buf: torch.Tensor):
+    """In-place x *= 1 stream with the cell kernel's access pattern (lram_stream_rmw): the practical HBM ceiling for
+    reading the recurrent state once and writing it once."""
+    lib = load_library()
+    _check(lib, lib.lram_stream_rmw(_ptr(buf), buf.numel(), _stream_ptr(buf.device)))
