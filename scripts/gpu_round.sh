@@ -1,5 +1,6 @@
 #!/bin/bash
-# One GPU-box pass: parity tests, bench line, rocprofv3 kernel-trace summary of the same bench command, PMC pass.
+# One GPU-box pass: parity tests, bench line, rocprofv3 kernel-trace summary of the same bench command, PMC pass,
+# and the secondary measurements quoted in DESIGN.md (Mamba, prefill, image front end, GEMM micro-benchmark).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
@@ -11,3 +12,12 @@ python bench.py --steps ${STEPS:-64} --warmup 8 > $OUT/bench.json 2> $OUT/bench.
 cut -c1-400 $OUT/bench.json; tail -2 $OUT/bench.err | cut -c1-200
 bash scripts/gpu_prof.sh headline --steps 16 --warmup 4
 bash scripts/pmc_pass.sh 2>&1 | grep -E "rc=|hbm_bytes_per_env|fetch_reported|write_reported"
+if [ "${FULL:-1}" = "1" ]; then
+  bash scripts/gpu_prof.sh mamba --config mamba_48m --batch 2048 --steps 16 --warmup 4 | head -8
+  PREFILL_MODES=chunkwise bash scripts/gpu_prof_prefill.sh xlstm_16m 512 63 1 | head -10
+  python scripts/bench_prefill.py xlstm_16m 1024 63 > $OUT/prefill_16m.txt 2>/dev/null; cat $OUT/prefill_16m.txt
+  python scripts/bench_prefill.py xlstm_206m 64 512 > $OUT/prefill_206m.txt 2>/dev/null; cat $OUT/prefill_206m.txt
+  python scripts/bench_image_encoder.py 512 1280 > $OUT/image_encoder.txt 2>/dev/null; cat $OUT/image_encoder.txt
+  bash scripts/gpu_gemm.sh bf16x3 f32 > $OUT/gemm_micro.txt 2>/dev/null; head -4 $OUT/gemm_micro.txt
+  bash scripts/gpu_sweep.sh > $OUT/sweep.txt 2>/dev/null; cat $OUT/sweep.txt
+fi
