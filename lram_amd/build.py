@@ -28,24 +28,46 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return LIB
-    # -packed-fp32-ops: no v_pk_*_f32 VALU instructions in device code.  On MI355X they return wrong results for a
-    # quarter wave when a co-resident wave of another dispatch issues bf16 MFMAs (csrc/selftest.hip); the flag is a
-    # device target feature, the host pass prints a harmless "not a recognized feature" note that is filtered here.
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
-           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+# -packed-fp32-ops: no v_pk_*_f32 VALU instructions in device code.  On MI355X they return wrong results for a
+# quarter wave when a co-resident wave of another dispatch issues bf16 MFMAs (csrc/selftest.hip); the flag is a
+# device target feature, the host pass prints a harmless "not a recognized feature" note that is filtered below.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+OBJ_DIR = os.path.join(CSRC, "_obj")
+_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target"
+
+
+def _run(cmd, verbose):
     if verbose:
         print("[lram_amd.build]", " ".join(cmd), file=sys.stderr)
     proc = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
-    noise = "'-packed-fp32-ops' is not a recognized feature for this target"
-    err = "\n".join(l for l in proc.stderr.splitlines() if noise not in l)
+    err = "\n".join(l for l in proc.stderr.splitlines() if _NOISE not in l)
     if err.strip():
         print(err, file=sys.stderr)
     if proc.returncode != 0:
         raise subprocess.CalledProcessError(proc.returncode, cmd)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """One translation unit per source, compiled in parallel (objects under csrc/_obj, re-used when neither the source
+    nor a header changed), then one link step."""
+    if not force and not needs_build():
+        return LIB
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    jobs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        src_path = os.path.join(CSRC, src)
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_time, os.path.getmtime(src_path))
+        if stale:
+            jobs.append([hipcc] + FLAGS + ["-c", src_path, "-o", obj])
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs) or 1, os.cpu_count() or 1))) as pool:
+        list(pool.map(lambda c: _run(c, verbose), jobs))
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs, verbose)
     return LIB
 
 
