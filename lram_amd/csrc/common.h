@@ -137,6 +137,43 @@ struct MlstmCellArgs {
 void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream);
 void launch_mlstm_chunk_cell(const MlstmCellArgs& a, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// Lazy matrix memory (mlstm_lazy.hip): C_t = g * C_base + sum_j coef_j khat_j v_j^T.  A step reads C_base once
+// and appends its tokens to a window; C_base is rewritten (folded) once every `period` steps per env.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLazyWindow = 48;  // window capacity in tokens
+constexpr int kLazyWT = kLazyWindow + 4;  // row pitch of the per-step attention weights: window + this step's tokens
+struct MlstmLazyArgs {
+  float* C;               // [B, NH, DH, DH] C_base (fold: in/out; cell: in)
+  float* wk;              // [B, NH, W, DH] window khat_j = k_j / sqrt(DH)
+  float* wv;              // [B, NH, W, DH] window v_j
+  const float* coef_in;   // [B, NH, W]   coefficients at the start of this step
+  float* coef_out;        // book: coefficients after this step
+  const float* g_in;      // [B, NH]      scale of C_base at the start of this step
+  float* g_out;
+  const int32_t* count_in;  // [B] tokens pending at the start of this step (bit 16: C_base logically zero)
+  int32_t* count_out;
+  const float* q;         // [B*T, inner]
+  const float* k;
+  const float* v;
+  const float* scal;      // [B*T, NH, 4] (f_t, i_t, denom_t, m_t) from mlstm_pre_kernel
+  float* h;               // [B*T, inner] out
+  float* pw;              // [B, NH, T, kLazyWT] p[t][j] = c_{t,j} (q_t . khat_j): score kernel out, cell kernel in
+  const uint8_t* reset;   // [B] or null
+  int B, T, NH, DH;
+  int phase, period;      // env b folds when (phase + b) % period == 0 (staggered), or when the window would overflow
+  int force;              // fold kernel: fold every env that has pending tokens (materialise)
+  int compact = 0;        // fold kernel: launch only over the envs whose phase comes up (no window can overflow)
+  int first = 0;          // set by the launcher
+  int min_lds_bytes = 0;
+};
+void launch_mlstm_lazy_fold(const MlstmLazyArgs& a, hipStream_t stream);
+void launch_mlstm_lazy_book(const MlstmLazyArgs& a, hipStream_t stream);
+void launch_mlstm_lazy_cell(const MlstmLazyArgs& a, hipStream_t stream);
+bool mlstm_lazy_supported(int DH, int T);
+// count[b] = 0, g[b, :] = 1 for masked envs (mask == nullptr: all), both parities handled by the caller
+void launch_mlstm_lazy_clear(int32_t* count, float* g, const uint8_t* mask, int B, int NH, hipStream_t stream);
+
 // mode 0 (mLSTM): out[r, hd] = (GN(h)[r,hd] * gamma + skip*xa) * silu(z)      z = u[r, inner + hd]
 // mode 1 (sLSTM): x[r, hd] += GN(h)[r,hd] * gamma
 struct GroupNormArgs {

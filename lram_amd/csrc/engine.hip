@@ -59,6 +59,11 @@ struct BlockState {
   DevBuf n;     // mLSTM n
   DevBuf m;     // mLSTM m
   DevBuf conv;  // conv state
+  // lazy matrix memory (mlstm_lazy.hip): window rows and ping-pong bookkeeping, allocated in lazy mode only
+  DevBuf wk, wv;    // [B, NH, W, DH] each
+  DevBuf coef;      // [2][B, NH, W]
+  DevBuf gsc;       // [2][B, NH]
+  DevBuf pw;        // [B, NH, 4, kLazyWT] window attention weights of the current step
 };
 
 struct GraphKey {
@@ -100,6 +105,14 @@ struct lram_engine {
   int img_channels = 0, img_flat = 0;  // input channels, flattened feature count of the linear layer
   DevBuf IMG_P, IMG_X0, IMG_X1, IMG_T;
   size_t img_cap = 0;  // batch * input pixels the image buffers were sized for
+  // lazy matrix memory: C_base read once per step, rewritten once per `lazy_period` steps (see mlstm_lazy.hip)
+  bool lazy = false;        // requested mode (LRAM_STATE=lazy or lram_set_state_mode)
+  bool lazy_ready = false;  // buffers allocated for the current batch
+  int lazy_period = 13;
+  int64_t lazy_step = 0;    // steps taken in lazy mode: fold phase and ping-pong parity
+  std::vector<int> lazy_bound;  // host-side upper bound of pending tokens per fold class (b % period)
+  bool lazy_compact = false;    // this step's fold launches may use the compact grid (no window can overflow)
+  DevBuf LZ_COUNT;          // [2][B] int32 pending tokens per env
   // state + workspace
   int B = 0;
   std::vector<BlockState> st;
@@ -124,6 +137,7 @@ struct lram_engine {
   int cell_lds_pad = -1;  // -1 = auto;  // bytes of LDS the cell kernel requests per workgroup while pipelined (occupancy cap)
   std::vector<hipStream_t> micro_streams;
   hipStream_t hbm_stream = nullptr;
+  hipStream_t fold_stream = nullptr;  // lazy matrix memory: folds run beside the cells of the previous block
   std::vector<hipEvent_t> sync_events;
   size_t sync_used = 0;
   // profiling of the dominant recurrent kernel
@@ -135,6 +149,7 @@ struct lram_engine {
     drop_graph();
     if (capture_stream) (void)hipStreamDestroy(capture_stream);
     if (hbm_stream) (void)hipStreamDestroy(hbm_stream);
+    if (fold_stream) (void)hipStreamDestroy(fold_stream);
     for (hipStream_t ms : micro_streams) (void)hipStreamDestroy(ms);
     for (hipEvent_t ev : sync_events) (void)hipEventDestroy(ev);
     for (auto& e : prof_events) {
@@ -162,7 +177,14 @@ struct lram_engine {
       s.n.release();
       s.m.release();
       s.conv.release();
+      s.wk.release();
+      s.wv.release();
+      s.coef.release();
+      s.gsc.release();
+      s.pw.release();
     }
+    LZ_COUNT.release();
+    lazy_ready = false;
     st.clear();
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
                       &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T})
@@ -419,6 +441,88 @@ int prefill_chunk_steps(lram_engine* e, int L) {
   return steps;
 }
 
+// ---- lazy matrix memory plumbing ------------------------------------------------------------------------
+bool lazy_geometry_ok(const lram_engine* e) {
+  return e->cfg.backbone == LRAM_BACKBONE_XLSTM && mlstm_lazy_supported(e->cfg.inner / e->cfg.n_heads, e->cfg.tokens_per_step);
+}
+
+void lazy_alloc(lram_engine* e) {
+  if (e->lazy_ready || e->B <= 0 || !lazy_geometry_ok(e)) return;
+  const lram_config& c = e->cfg;
+  const size_t B = e->B, NH = c.n_heads, DH = e->dh();
+  for (int i = 0; i < c.n_blocks; ++i) {
+    if (c.block_is_slstm[i]) continue;
+    BlockState& s = e->st[i];
+    s.wk.alloc(B * NH * kLazyWindow * DH);
+    s.wv.alloc(B * NH * kLazyWindow * DH);
+    s.coef.alloc(2 * B * NH * kLazyWindow);
+    s.gsc.alloc(2 * B * NH);
+    s.pw.alloc(B * NH * 4 * kLazyWT);
+    s.coef.zero();
+    s.pw.zero();
+  }
+  e->LZ_COUNT.alloc(2 * B);
+  e->LZ_COUNT.zero();
+  for (int i = 0; i < c.n_blocks; ++i) {
+    if (c.block_is_slstm[i]) continue;
+    BlockState& s = e->st[i];
+    for (int p = 0; p < 2; ++p)
+      launch_mlstm_lazy_clear(reinterpret_cast<int32_t*>(e->LZ_COUNT.p) + p * B, s.gsc.p + p * B * NH, nullptr, (int)B,
+                              (int)NH, nullptr);
+  }
+  LRAM_HIP_CHECK(hipDeviceSynchronize());
+  e->lazy_step = 0;
+  e->lazy_ready = true;
+}
+
+bool lazy_active(const lram_engine* e, int T) {
+  return e->lazy && e->lazy_ready && !e->graph_mode && T >= 1 && T <= 4;
+}
+
+MlstmLazyArgs lazy_args(lram_engine* e, int i, int T, const uint8_t* reset, int b0, int nb) {
+  const lram_config& c = e->cfg;
+  const size_t NH = c.n_heads, DH = e->dh(), B = e->B;
+  const int in = (int)(e->lazy_step & 1), out = 1 - in;
+  BlockState& st = e->st[i];
+  MlstmLazyArgs a{};
+  a.C = st.s0.p + (size_t)b0 * NH * DH * DH;
+  a.wk = st.wk.p + (size_t)b0 * NH * kLazyWindow * DH;
+  a.wv = st.wv.p + (size_t)b0 * NH * kLazyWindow * DH;
+  a.coef_in = st.coef.p + (in * B + b0) * NH * kLazyWindow;
+  a.coef_out = st.coef.p + (out * B + b0) * NH * kLazyWindow;
+  a.g_in = st.gsc.p + (in * B + b0) * NH;
+  a.g_out = st.gsc.p + (out * B + b0) * NH;
+  a.count_in = reinterpret_cast<const int32_t*>(e->LZ_COUNT.p) + in * B + b0;
+  a.count_out = reinterpret_cast<int32_t*>(e->LZ_COUNT.p) + out * B + b0;
+  a.pw = st.pw.p + (size_t)b0 * NH * T * kLazyWT;
+  a.reset = reset ? reset + b0 : nullptr;
+  a.B = nb, a.T = T, a.NH = (int)NH, a.DH = (int)DH;
+  // the fold phase is taken relative to the env's global index, so slices fold the same envs as the whole batch
+  a.phase = (int)((e->lazy_step + b0) % e->lazy_period), a.period = e->lazy_period, a.force = 0;
+  return a;
+}
+
+// Fold every pending window into C_base and empty the bookkeeping: afterwards the state is the materialised
+// reference layout again (export / import, prefill, long encoder calls, leaving lazy mode).
+void lazy_materialize(lram_engine* e, hipStream_t s) {
+  if (!e->lazy_ready) return;
+  const lram_config& c = e->cfg;
+  const size_t B = e->B, NH = c.n_heads;
+  for (int i = 0; i < c.n_blocks; ++i) {
+    if (c.block_is_slstm[i]) continue;
+    MlstmLazyArgs a = lazy_args(e, i, 1, nullptr, 0, e->B);
+    a.force = 1;
+    launch_mlstm_lazy_fold(a, s);
+  }
+  for (int i = 0; i < c.n_blocks; ++i) {
+    if (c.block_is_slstm[i]) continue;
+    for (int p = 0; p < 2; ++p)
+      launch_mlstm_lazy_clear(reinterpret_cast<int32_t*>(e->LZ_COUNT.p) + p * B, e->st[i].gsc.p + p * B * NH, nullptr,
+                              (int)B, (int)NH, s);
+  }
+  e->lazy_bound.assign(e->lazy_period, 0);
+}
+
 void state_alloc(lram_engine* e, int B) {
   LRAM_REQUIRE(e->finalized, "lram_finalize must be called before lram_state_alloc");
   LRAM_REQUIRE(B > 0 && B <= 65535, "batch must be in 1..65535");
@@ -450,6 +554,7 @@ void state_alloc(lram_engine* e, int B) {
   }
   e->B = B;
   alloc_workspace(e, kMaxTokens);
+  if (e->lazy) lazy_alloc(e);
   LRAM_HIP_CHECK(hipDeviceSynchronize());
 }
 
@@ -700,19 +805,85 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
 void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vector<Slice>& sl, hipStream_t hbm) {
   const lram_config& c = e->cfg;
   const int D = c.d_model;
+  const bool lazy = lazy_active(e, T);
+  if (lazy) {
+    // Upper bound of pending tokens per fold class (env index mod period), tracked on the host: while no class can
+    // overflow its window before its turn, the fold launch only covers the envs whose turn it is.
+    const int P = e->lazy_period;
+    e->lazy_compact = true;
+    if ((int)e->lazy_bound.size() != P) {
+      e->lazy_bound.assign(P, kLazyWindow);
+      e->lazy_compact = false;
+    }
+    const int c_due = (P - (int)(e->lazy_step % P)) % P;
+    for (int cls = 0; cls < P; ++cls) {
+      if (cls == c_due)
+        e->lazy_bound[cls] = 0;
+      else if (e->lazy_bound[cls] + T > kLazyWindow)
+        e->lazy_compact = false;
+      e->lazy_bound[cls] = std::min(e->lazy_bound[cls] + T, 4 * kLazyWindow);
+    }
+  }
+  // This step's folds depend on nothing this step computes (window rows, coefficients and counts are last step's).
+  // They run on their own stream, one block ahead of the cells: block i's cells wait for fold(i), and fold(i + 1) is
+  // enqueued right then, so it streams beside the cells of block i (the read-only cell pass leaves HBM headroom).
+  hipStream_t fs = hbm;
+  if (lazy && sl.size() > 1) {
+    if (!e->fold_stream) LRAM_HIP_CHECK(hipStreamCreateWithFlags(&e->fold_stream, hipStreamNonBlocking));
+    fs = e->fold_stream;
+    stream_after(e, fs, hbm);  // hbm was forked from the caller's stream: inherit that dependency
+  }
+  auto launch_folds = [&](int i) {
+    for (const Slice& x : sl) {
+      MlstmLazyArgs la = lazy_args(e, i, T, reset, x.b0, x.nb);
+      la.compact = e->lazy_compact ? 1 : 0;
+      launch_mlstm_lazy_fold(la, fs);
+    }
+  };
+  auto next_mlstm = [&](int i) {
+    for (int k = i + 1; k < c.n_blocks; ++k)
+      if (!c.block_is_slstm[k]) return k;
+    return -1;
+  };
+  if (lazy && next_mlstm(-1) >= 0) launch_folds(next_mlstm(-1));
   for (int i = 0; i < c.n_blocks; ++i) {
     if (c.block_is_slstm[i]) {
       for (const Slice& x : sl) slstm_block(e, i, T, reset, x);
       continue;
     }
+    if (lazy) {
+      stream_after(e, hbm, fs);  // fold(i) done before cell(i)
+      const int nxt = next_mlstm(i);
+      if (nxt >= 0) launch_folds(nxt);
+    }
     for (const Slice& x : sl) {
       mlstm_front(e, i, T, reset, x);
+      if (lazy) {
+        // lazy matrix memory: bookkeeping beside the front end; on the HBM stream the (mostly empty) fold launch, then
+        // the read-only pass + window attention
+        MlstmLazyArgs la = lazy_args(e, i, T, reset, x.b0, x.nb);
+        const size_t r0 = (size_t)x.b0 * T;
+        la.q = e->Q.p + r0 * e->icols, la.k = e->K.p + r0 * e->icols, la.v = e->V.p + r0 * e->icols;
+        la.scal = e->SCAL.p + r0 * c.n_heads * 4, la.h = e->H.p + r0 * e->icols;
+        // the read-only pass runs best with two workgroups per CU (one's prologue / epilogue under the other's
+        // stream; 362k vs 308k env-steps/s at B = 4096 against the single-workgroup cap the read-modify-write kernel likes)
+        la.min_lds_bytes = e->cell_lds_pad >= 0 ? e->cell_lds_pad : 0;
+        launch_mlstm_lazy_book(la, x.s);
+        stream_after(e, hbm, x.s);
+        prof_record(e, hbm, true);
+        launch_mlstm_lazy_cell(la, hbm);
+        prof_record(e, hbm, false);
+        stream_after(e, x.s, hbm);
+        continue;
+      }
       stream_after(e, hbm, x.s);
       mlstm_cell(e, i, T, reset, x, hbm);
       stream_after(e, x.s, hbm);
     }
     for (const Slice& x : sl) mlstm_back(e, i, T, x);
   }
+  if (lazy && fs != hbm) stream_after(e, hbm, fs);
+  if (lazy) ++e->lazy_step;
   for (const Slice& x : sl) {
     const size_t r0 = (size_t)x.b0 * T;
     launch_row_norm(e->X.p + r0 * D, D, e->HID.p + r0 * D, D, e->post_g, e->post_b, x.nb * T, D, c.ln_eps,
@@ -869,6 +1040,7 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   // instead of once per timestep.  Up to 4 timesteps (12 tokens) per chunk through the token-sequential kernels,
   // up to 21 (63 tokens) through the chunkwise matrix-core kernels (mlstm_chunk.hip).
   const int kChunk = L > 1 ? prefill_chunk_steps(e, L) : 1;
+  if (L > 1 || !lazy_active(e, T)) lazy_materialize(e, s);  // stored contexts go through the materialised kernels
   hipStream_t hbm;
   const std::vector<Slice> sl = make_slices(e, s, &hbm);
   const bool multi = sl.size() > 1;
@@ -982,6 +1154,8 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_CELL_LDS_PAD_KB")) e->cell_lds_pad = std::atoi(v) * 1024;
     if (const char* v = std::getenv("LRAM_CELL_UNROLL")) e->cell_unroll = std::atoi(v);
     if (const char* v = std::getenv("LRAM_PREFILL_CHUNK")) e->chunk_prefill = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_STATE")) e->lazy = std::string(v) == "lazy";
+    if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
     *out = e.release();
   });
 }
@@ -1054,6 +1228,10 @@ int32_t lram_reset(lram_engine* e, const uint8_t* dev_env_mask, void* stream) {
       if (st.n.p) launch_zero_rows(st.n.p, dev_env_mask, B, (int64_t)(st.n.n / B), 1, 0, s);
       if (st.m.p) launch_zero_rows(st.m.p, dev_env_mask, B, (int64_t)(st.m.n / B), 1, 0, s);
       launch_zero_rows(st.conv.p, dev_env_mask, B, (int64_t)(st.conv.n / B), 1, 0, s);
+      if (e->lazy_ready && st.gsc.p != nullptr)  // pending window of a reset env is dropped with its C_base
+        for (int p = 0; p < 2; ++p)
+          launch_mlstm_lazy_clear(reinterpret_cast<int32_t*>(e->LZ_COUNT.p) + (size_t)p * B,
+                                  st.gsc.p + (size_t)p * B * e->cfg.n_heads, dev_env_mask, B, e->cfg.n_heads, s);
     }
   });
 }
@@ -1131,6 +1309,7 @@ int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t bytes = sizeof(float) * (size_t)e->B * tokens * e->cfg.d_model;
+    if (!lazy_active(e, tokens)) lazy_materialize(e, s);
     LRAM_HIP_CHECK(hipMemcpyAsync(e->X.p, dev_inputs_embeds, bytes, hipMemcpyDeviceToDevice, s));
     e->sync_used = 0;
     hipStream_t hbm;
@@ -1164,6 +1343,7 @@ int32_t lram_state_export(lram_engine* e, int32_t block, int32_t which, float* d
     LRAM_REQUIRE(e && e->B > 0 && dev_dst, "lram_state_export: bad argument");
     StateView v = state_view(e, block, which);
     LRAM_REQUIRE(v.p != nullptr, "lram_state_export: no such state tensor");
+    lazy_materialize(e, static_cast<hipStream_t>(stream));
     LRAM_HIP_CHECK(hipMemcpyAsync(dev_dst, v.p, v.n * sizeof(float), hipMemcpyDeviceToDevice,
                                   static_cast<hipStream_t>(stream)));
   });
@@ -1174,6 +1354,7 @@ int32_t lram_state_import(lram_engine* e, int32_t block, int32_t which, const fl
     LRAM_REQUIRE(e && e->B > 0 && dev_src, "lram_state_import: bad argument");
     StateView v = state_view(e, block, which);
     LRAM_REQUIRE(v.p != nullptr, "lram_state_import: no such state tensor");
+    lazy_materialize(e, static_cast<hipStream_t>(stream));
     LRAM_HIP_CHECK(hipMemcpyAsync(v.p, dev_src, v.n * sizeof(float), hipMemcpyDeviceToDevice,
                                   static_cast<hipStream_t>(stream)));
   });
@@ -1182,8 +1363,33 @@ int32_t lram_state_import(lram_engine* e, int32_t block, int32_t which, const fl
 int32_t lram_set_graph_mode(lram_engine* e, int32_t enable) {
   return guarded([&] {
     LRAM_REQUIRE(e != nullptr, "lram_set_graph_mode: null engine");
+    if (enable != 0 && e->lazy_ready) {  // graph replay bakes kernel arguments: it runs on the materialised state
+      LRAM_HIP_CHECK(hipSetDevice(e->device));
+      lazy_materialize(e, nullptr);
+      LRAM_HIP_CHECK(hipDeviceSynchronize());
+    }
     e->graph_mode = enable != 0;
     if (!e->graph_mode) e->drop_graph();
+  });
+}
+
+int32_t lram_set_state_mode(lram_engine* e, int32_t lazy, int32_t fold_period) {
+  return guarded([&] {
+    LRAM_REQUIRE(e != nullptr, "lram_set_state_mode: null engine");
+    LRAM_REQUIRE(fold_period == 0 || (fold_period >= 1 && fold_period * e->cfg.tokens_per_step + 4 <= kLazyWindow),
+                 "lram_set_state_mode: fold_period out of range (the window holds 48 tokens)");
+    LRAM_HIP_CHECK(hipSetDevice(e->device));
+    if (e->lazy_ready) {  // leave the current mode with a materialised state
+      lazy_materialize(e, nullptr);
+      LRAM_HIP_CHECK(hipDeviceSynchronize());
+    }
+    e->lazy = lazy != 0;
+    if (fold_period > 0) e->lazy_period = fold_period;
+    e->lazy_bound.clear();
+    if (e->lazy && e->B > 0) {
+      LRAM_REQUIRE(lazy_geometry_ok(e), "lram_set_state_mode: lazy matrix memory needs an xLSTM head dim that is a multiple of 128");
+      lazy_alloc(e);
+    }
   });
 }
 

@@ -1,0 +1,465 @@
+// Lazy matrix memory for the mLSTM step on gfx950.
+//
+// The step kernel of xlstm_kernels.hip reads and rewrites every C element once per env-step -- the algorithmic
+// minimum while C_t is kept materialised.  It does not have to be: with the stabilised per-token factors
+// (f_t, i_t <= 1; [3P] recurrent_step_stabilized_simple)
+//     C_t = g_t C_base + sum_j c_{t,j} khat_j v_j^T ,      g_t = g_{t-1} f_t ,  c_{t,j} = c_{t-1,j} f_t ,  c_{t,t} = i_t
+//     q_t^T C_t = g_t (q_t^T C_base) + sum_j c_{t,j} (q_t . khat_j) v_j^T
+// so a step only has to READ C_base (one pass instead of two) and attend over the short window of tokens that
+// have not been folded in yet; the window's (khat_j, v_j) rows are appended, not merged.  Every `period` steps
+// (staggered over the envs so the extra pass is spread evenly) `mlstm_lazy_fold_kernel` rewrites
+// C_base <- g C_base + (c Khat)^T V on the fp32 matrix cores and empties the window.  HBM bytes per env-step and
+// block: DH^2 * 4 (read) + 2 * DH^2 * 4 / period (fold) + the window rows, e.g. 1.31 MB instead of 2.05 MB at
+// period 13 on the 16M geometry.  Same mathematics as the materialised update; the fp32 rounding differs
+// (fewer roundings: C_base is touched once per period), results stay within the parity bars.
+//
+// Bookkeeping (per env: pending token count; per (env, head): scale g and the coefficients c_j) is ping-ponged
+// between two buffers by step parity: the kernels of one step read the "in" side, `mlstm_lazy_book_kernel` writes
+// the "out" side.  Whether an env folds / restarts this step is a pure function of (count_in, reset, phase), which
+// every kernel evaluates identically -- no flags, no inter-workgroup hand-off.
+#include <algorithm>
+
+#include "common.h"
+#include "device_math.h"
+
+namespace lram {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int W = kLazyWindow;
+
+struct LazyView {
+  int n_in;   // tokens pending at the start of the step (what a fold merges)
+  int n;      // tokens pending that this step's readout attends over
+  bool fold;  // C_base is rewritten before this step
+  bool rs;    // env restarts
+  bool zero_in;  // C_base held no information at the start of the step (restarted since its last fold)
+  bool zero;     // ... for this step's readout: skip the pass over C_base
+};
+
+// count word: bits 0..15 pending tokens, bit 16 "C_base is logically zero" (an env restart drops the old memory
+// without touching HBM: the next fold simply writes the window instead of accumulating into the stale C_base)
+constexpr int kZeroBit = 1 << 16;
+
+__device__ __forceinline__ LazyView lazy_view(const MlstmLazyArgs& a, int b) {
+  LazyView v;
+  v.rs = a.reset != nullptr && a.reset[b] != 0;
+  const int word = a.count_in[b];
+  v.n_in = word & 0xFFFF;
+  v.zero_in = (word & kZeroBit) != 0;
+  v.fold = !v.rs && v.n_in > 0 && (a.force != 0 || ((a.phase + b) % a.period) == 0 || v.n_in + a.T > W);
+  v.n = (v.rs || v.fold) ? 0 : v.n_in;
+  v.zero = v.rs ? true : (v.fold ? false : v.zero_in);
+  return v;
+}
+
+__device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// =============================================================================================
+// fold: one workgroup per (env, head, 128 columns); exits at once unless the env folds or restarts this step.
+//   C[r][c] <- g C[r][c] + sum_j (coef_j khat_j[r]) v_j[c]     (j < n_in, padded to a multiple of 8 with zeros)
+// =============================================================================================
+constexpr int kFC = 128;   // columns per workgroup
+constexpr int kFPV = 136;  // LDS pitch of the V rows
+constexpr int kFPK = 40;   // LDS pitch of the scaled khat tile (32 rows of DH)
+constexpr int kFR = 64;    // rows of C per workgroup (two 32-row MFMA tiles): many short workgroups hide the
+                           // load -> MFMA -> store latency of a fold better than few long ones
+
+__global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
+  __shared__ __attribute__((aligned(16))) float Vs[W * kFPV];
+  __shared__ __attribute__((aligned(16))) float Ks[(kFR / 32) * W * kFPK];
+  const int DH = a.DH, NH = a.NH;
+  const int nsl = DH / kFC;
+  int wid = blockIdx.x;
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wid = (wid & 7) * (nwg >> 3) + (wid >> 3);
+  const int nrs = DH / kFR;
+  const int rsplit = wid % nrs;
+  wid /= nrs;
+  const int slice = wid % nsl, bh = wid / nsl, h = bh % NH;
+  // compact grid: only the envs whose fold phase comes up this step (b = first, first + period, ...)
+  const int b = a.compact ? a.first + (bh / NH) * a.period : bh / NH;
+  if (b >= a.B) return;
+  const LazyView lv = lazy_view(a, b);
+  if (!lv.fold) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int n = lv.n_in;
+  const int kt8 = (n + 7) >> 3;
+  const float g = lv.zero_in ? 0.f : a.g_in[(int64_t)b * NH + h];
+  const int row0 = rsplit * kFR;
+  float* Cg = a.C + (((int64_t)b * NH + h) * DH) * DH + slice * kFC;
+  const float* wkb = a.wk + (((int64_t)b * NH + h) * W) * DH + row0;
+  const float* wvb = a.wv + (((int64_t)b * NH + h) * W) * DH + slice * kFC;
+  const float* cfb = a.coef_in + ((int64_t)b * NH + h) * W;
+  // every global load of the workgroup is issued before the first use: one memory round trip, not one per phase
+  float* cp0 = Cg + (int64_t)(row0 + 4 * lh) * DH + 32 * w + li;
+  float cold[kFR / 32][16];
+#pragma unroll
+  for (int t = 0; t < kFR / 32; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      cold[t][r] = lv.zero_in ? 0.f : cp0[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * DH];
+  float4 rv[(W * (kFC / 4) + 255) / 256];
+#pragma unroll
+  for (int i = 0; i < (W * (kFC / 4) + 255) / 256; ++i) {
+    const int idx = tid + 256 * i;
+    const int j = idx / (kFC / 4), c4 = (idx % (kFC / 4)) << 2;
+    rv[i] = (idx < W * (kFC / 4) && j < n) ? *reinterpret_cast<const float4*>(wvb + (int64_t)j * DH + c4) : f4_zero();
+  }
+  float4 rk[(W * (kFR / 4) + 255) / 256];
+  float rc[(W * (kFR / 4) + 255) / 256];
+#pragma unroll
+  for (int i = 0; i < (W * (kFR / 4) + 255) / 256; ++i) {
+    const int idx = tid + 256 * i;
+    const int j = idx / (kFR / 4), r4 = (idx % (kFR / 4)) << 2;
+    const bool ok = idx < W * (kFR / 4) && j < n;
+    rk[i] = ok ? *reinterpret_cast<const float4*>(wkb + (int64_t)j * DH + r4) : f4_zero();
+    rc[i] = ok ? cfb[j] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < (W * (kFC / 4) + 255) / 256; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < W * (kFC / 4)) {
+      const int j = idx / (kFC / 4), c4 = (idx % (kFC / 4)) << 2;
+      *reinterpret_cast<float4*>(Vs + j * kFPV + c4) = rv[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < (W * (kFR / 4) + 255) / 256; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < W * (kFR / 4)) {
+      const int j = idx / (kFR / 4), r4 = (idx % (kFR / 4)) << 2;  // row r4 .. r4+3 of this workgroup's kFR rows
+      const float cj = rc[i];
+      // scaled khat, tile (r4 / 32): Ks[tile][j][r4 % 32]
+      *reinterpret_cast<float4*>(Ks + (r4 >> 5) * W * kFPK + j * kFPK + (r4 & 31)) =
+          make_float4(cj * rk[i].x, cj * rk[i].y, cj * rk[i].z, cj * rk[i].w);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < kFR / 32; ++t) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = g * cold[t][r];
+    const float* Kt = Ks + t * W * kFPK;
+    for (int j8 = 0; j8 < kt8; ++j8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 8 * j8 + 4 * lh + i;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[j * kFPK + li], Vs[j * kFPV + 32 * w + li], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cp0[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * DH] = acc[r];
+  }
+}
+
+// =============================================================================================
+// score: one workgroup per (env, head), on the slice's stream beside the front end (off the HBM stream):
+//   * bookkeeping after this step's T tokens (coefficients, scale, count) into the "out" side;
+//   * the window attention weights of this step, p[t][j] = c_{t,j} (q_t . khat_j), j over the pending window and
+//     this step's own tokens, written to `pw` [B, NH, T, kLazyWT] for the cell kernel.
+// =============================================================================================
+constexpr int WT = kLazyWT;  // window + this step's tokens (row pitch of pw)
+
+template <int T>
+__global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) {
+  extern __shared__ float qk[];  // qs [T][DH], ks [T][DH]
+  __shared__ float s_coef[W];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NH = a.NH, DH = a.DH, inner = NH * DH;
+  float* qs = qk;
+  float* ks = qk + T * DH;
+  const LazyView lv = lazy_view(a, b);
+  const int n = lv.n;
+  float f[T], ig[T], F[T];
+  float Fc = 1.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float4 s = *reinterpret_cast<const float4*>(a.scal + (((int64_t)b * T + t) * NH + h) * 4);
+    f[t] = s.x;
+    ig[t] = s.y;
+    Fc *= s.x;
+    F[t] = Fc;
+  }
+  const float sqrt_dh = sqrtf((float)DH);
+  for (int r = tid; r < DH; r += 256) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r;
+      qs[t * DH + r] = a.q[off];
+      ks[t * DH + r] = a.k[off] / sqrt_dh;
+    }
+  }
+  const int64_t base = ((int64_t)b * NH + h) * W;
+  if (tid < W) s_coef[tid] = tid < n ? a.coef_in[base + tid] : 0.f;
+  __syncthreads();
+  // ---- bookkeeping for the next step ----
+  if (tid < n) a.coef_out[base + tid] = s_coef[tid] * F[T - 1];
+  if (tid < T) {
+    float c = 1.f;
+#pragma unroll
+    for (int x = 0; x < T; ++x) {
+      if (x == tid) c *= ig[x];
+      if (x > tid) c *= f[x];
+    }
+    a.coef_out[base + n + tid] = c;
+  }
+  if (tid == 0) {
+    const float g = (lv.rs || lv.fold) ? 1.f : a.g_in[(int64_t)b * NH + h];
+    a.g_out[(int64_t)b * NH + h] = g * F[T - 1];
+    if (h == 0) a.count_out[b] = (n + T) | (lv.zero ? kZeroBit : 0);
+  }
+  // ---- p[t][j]: each wave takes four window rows at a time (their loads are issued together) ----
+  const float* wkb = a.wk + base * DH;
+  float* pwo = a.pw + (((int64_t)b * NH + h) * T) * WT;
+  for (int j0 = 4 * wave; j0 < n + T; j0 += 16) {
+    float p[4][T];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < T; ++t) p[i][t] = 0.f;
+    for (int r = lane; r < DH; r += 64) {
+      float kv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = j0 + i;
+        kv[i] = j < n ? wkb[(int64_t)j * DH + r] : (j < n + T ? ks[(j - n) * DH + r] : 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t) p[i][t] += qs[t * DH + r] * kv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + i;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float s = wave_sum(p[i][t]);
+        if (lane == 0 && j < n + T) {
+          float c;
+          if (j < n) {
+            c = s_coef[j] * F[t];
+          } else {
+            const int u = j - n;  // this step's token u reaches t >= u with i_u f_{u+1} .. f_t
+            c = 0.f;
+            if (u <= t) {
+              c = 1.f;
+#pragma unroll
+              for (int x = 0; x < T; ++x) {
+                if (x == u) c *= ig[x];
+                if (x > u && x <= t) c *= f[x];
+              }
+            }
+          }
+          pwo[t * WT + j] = c * s;
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// cell: read-only pass over C_base + the window terms.  One workgroup per (env, head, column slice); thread c of the
+// slice owns column c of the window's V rows, fetched into registers before the pass over C_base starts.
+//   y_t = q_t^T C_base ;   h_t = ( G_t y_t + sum_j p[t][j] v_j ) / den_t
+// and the step's T tokens are appended to the window.
+// =============================================================================================
+template <int T, int LPR, int UNR>
+__global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
+  constexpr int CW = 4 * LPR;
+  constexpr int RP = 256 / LPR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int DH = a.DH;
+  float* qs = smem;                 // [T][DH]
+  float* red = smem + T * DH;       // [RP][T][CW]
+  float* pw = red + RP * T * CW;    // [T][WT]
+
+  const int b = blockIdx.z, h = blockIdx.y, slice = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int cl = tid % LPR, rg = tid / LPR;
+  const int NH = a.NH, inner = NH * DH;
+  const LazyView lv = lazy_view(a, b);
+  const int n = lv.n;
+
+  float den[T], G[T];
+  {
+    float Fc = (lv.rs || lv.fold) ? 1.f : a.g_in[(int64_t)b * NH + h];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float4 s = *reinterpret_cast<const float4*>(a.scal + (((int64_t)b * T + t) * NH + h) * 4);
+      den[t] = s.z;
+      Fc *= s.x;
+      G[t] = Fc;  // g f_1 .. f_t
+    }
+  }
+  for (int r = tid; r < DH; r += 256) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) qs[t * DH + r] = a.q[((int64_t)b * T + t) * inner + (int64_t)h * DH + r];
+  }
+  const float* pwi = a.pw + (((int64_t)b * NH + h) * T) * WT;
+  for (int idx = tid; idx < T * WT; idx += 256) pw[idx] = pwi[idx];
+  // window V column of this thread (threads >= CW idle here): in flight during the pass over C_base
+  const float* wvb = a.wv + (((int64_t)b * NH + h) * W) * DH + slice * CW + (tid < CW ? tid : 0);
+  float vw[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) vw[j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
+  float vcur[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+    vcur[t] = tid < CW ? a.v[((int64_t)b * T + t) * inner + (int64_t)h * DH + slice * CW + tid] : 0.f;
+  __syncthreads();
+
+  const int col0 = slice * CW + 4 * cl;
+  v4f acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = (v4f)(0.f);
+  const float* Cb = a.C + (((int64_t)b * NH + h) * DH) * DH + col0;
+  if (!lv.zero) {  // (after a restart C_base holds nothing until the env's next fold)
+    for (int r0 = rg; r0 < DH; r0 += RP * UNR) {
+      v4f c[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int r = r0 + u * RP;
+        c[u] = r < DH ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(Cb + (int64_t)r * DH)) : (v4f)(0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int r = r0 + u * RP;
+        if (r < DH) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) acc[t] += qs[t * DH + r] * c[u];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) *reinterpret_cast<v4f*>(red + ((rg * T + t) * CW) + 4 * cl) = acc[t];
+  __syncthreads();
+  if (tid < CW) {
+    const int c = tid;
+    float hn[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float y = 0.f;
+#pragma unroll
+      for (int g = 0; g < RP; ++g) y += red[(g * T + t) * CW + c];
+      hn[t] = G[t] * y;
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) hn[t] += pw[t * WT + j] * vw[j];  // pw == 0 beyond the window
+    }
+#pragma unroll
+    for (int u = 0; u < T; ++u)
+#pragma unroll
+      for (int t = u; t < T; ++t) hn[t] += pw[t * WT + n + u] * vcur[u];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      a.h[((int64_t)b * T + t) * inner + (int64_t)h * DH + slice * CW + c] = hn[t] / den[t];
+    // append this step's v rows; khat rows are appended by slice 0 below
+    float* wvo = a.wv + (((int64_t)b * NH + h) * W + n) * DH + slice * CW + c;
+#pragma unroll
+    for (int t = 0; t < T; ++t) wvo[(int64_t)t * DH] = vcur[t];
+  }
+  if (slice == 0) {
+    const float sqrt_dh = sqrtf((float)DH);
+    float* wko = a.wk + (((int64_t)b * NH + h) * W + n) * DH;
+    for (int idx = tid; idx < T * DH; idx += 256) {
+      const int t = idx / DH, r = idx - t * DH;
+      wko[idx] = a.k[((int64_t)b * T + t) * inner + (int64_t)h * DH + r] / sqrt_dh;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mlstm_lazy_clear_kernel(int32_t* count, float* g, const uint8_t* mask, int B,
+                                                               int NH) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= B * NH) return;
+  const int b = gid / NH;
+  if (mask != nullptr && mask[b] == 0) return;
+  g[gid] = 1.f;
+  if (gid == b * NH) count[b] = 0;
+}
+
+template <int T, int LPR>
+void launch_cell_tl(const MlstmLazyArgs& a, hipStream_t s) {
+  constexpr int CW = 4 * LPR, RP = 256 / LPR, UNR = 16;
+  dim3 grid(a.DH / CW, a.NH, a.B), block(256);
+  size_t shmem = sizeof(float) * (T * a.DH + RP * T * CW + T * kLazyWT);
+  shmem = std::max(shmem, (size_t)a.min_lds_bytes);
+  if (shmem > 48 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR>), grid, block, shmem, s, a);
+}
+
+template <int T>
+void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
+  if (a.DH % 256 == 0)
+    launch_cell_tl<T, 64>(a, s);
+  else
+    launch_cell_tl<T, 32>(a, s);
+}
+
+}  // namespace
+
+bool mlstm_lazy_supported(int DH, int T) { return DH % 128 == 0 && T >= 1 && T <= 4; }
+
+void launch_mlstm_lazy_fold(const MlstmLazyArgs& a_in, hipStream_t stream) {
+  MlstmLazyArgs a = a_in;
+  LRAM_REQUIRE(a.DH % kFC == 0 && a.DH % kFR == 0, "lazy mLSTM: head dim must be a multiple of 128");
+  long envs = a.B;
+  if (a.compact) {
+    a.first = (a.period - a.phase % a.period) % a.period;  // smallest b with (phase + b) % period == 0
+    if (a.first >= a.B) return;
+    envs = (a.B - a.first + a.period - 1) / a.period;
+  }
+  const long nwg = envs * a.NH * (a.DH / kFC) * (a.DH / kFR);
+  hipLaunchKernelGGL(mlstm_lazy_fold_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, a);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_mlstm_lazy_book(const MlstmLazyArgs& a, hipStream_t stream) {
+  LRAM_REQUIRE(a.T >= 1 && a.T <= 4, "lazy mLSTM: 1..4 tokens per step");
+  LRAM_REQUIRE(a.pw != nullptr, "lazy mLSTM: missing score buffer");
+  dim3 grid(a.NH, a.B), block(256);
+  const size_t shmem = sizeof(float) * 2 * a.T * a.DH;
+  switch (a.T) {
+    case 1: hipLaunchKernelGGL(mlstm_lazy_score_kernel<1>, grid, block, shmem, stream, a); break;
+    case 2: hipLaunchKernelGGL(mlstm_lazy_score_kernel<2>, grid, block, shmem, stream, a); break;
+    case 3: hipLaunchKernelGGL(mlstm_lazy_score_kernel<3>, grid, block, shmem, stream, a); break;
+    default: hipLaunchKernelGGL(mlstm_lazy_score_kernel<4>, grid, block, shmem, stream, a); break;
+  }
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_mlstm_lazy_cell(const MlstmLazyArgs& a, hipStream_t stream) {
+  LRAM_REQUIRE(mlstm_lazy_supported(a.DH, a.T), "lazy mLSTM: unsupported geometry");
+  switch (a.T) {
+    case 1: launch_cell_t<1>(a, stream); break;
+    case 2: launch_cell_t<2>(a, stream); break;
+    case 3: launch_cell_t<3>(a, stream); break;
+    default: launch_cell_t<4>(a, stream); break;
+  }
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_mlstm_lazy_clear(int32_t* count, float* g, const uint8_t* mask, int B, int NH, hipStream_t stream) {
+  hipLaunchKernelGGL(mlstm_lazy_clear_kernel, dim3((unsigned)((B * NH + 255) / 256)), dim3(256), 0, stream, count, g,
+                     mask, B, NH);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace lram

@@ -1,0 +1,118 @@
+"""Lazy matrix memory (lram_set_state_mode, csrc/mlstm_lazy.hip): C_base is read once per step and rewritten once per
+fold period, the tokens in between live in a window the readout attends over.  Must be indistinguishable from the
+materialised update: oracle parity, equality with the eager engine, resets, exports in the middle of a window,
+prefill hand-over, env slices, every fold period, the 206M head geometry."""
+import pytest
+import torch
+
+from lram_amd import init_state_dict, preset
+from lram_amd.config import ModelSpec
+from oracle import dt_ref
+from tests.helpers import assert_actions_match, make_inputs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(eng, seq):
+    acts = []
+    for obs, rtg, rew, mask in seq:
+        a, _ = eng.step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+        acts.append(a.clone())
+    torch.cuda.synchronize()
+    return torch.stack(acts)
+
+
+@pytest.mark.parametrize("period", [13, 1, 5, 14])
+def test_lazy_steps_match_oracle_and_eager(hip_lib, period):
+    """45 steps with random per-env resets: several staggered folds per env; actions follow the oracle, the exported
+    state equals the eager engine's."""
+    from lram_amd.engine import Engine
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=51)
+    B, steps = 5, 45
+    seq = make_inputs(spec, B, steps, seed=21, reset_prob=0.1)
+    eager = Engine(spec, sd, B, device="cuda:0")
+    lazy = Engine(spec, sd, B, device="cuda:0")
+    lazy.set_state_mode(True, period)
+    a_e, a_l = _run(eager, seq), _run(lazy, seq)
+    ora = dt_ref.OraclePolicy(spec, sd)
+    for t, (obs, rtg, rew, mask) in enumerate(seq):
+        ref, dbg = ora.step(obs, rtg, rew, mask, return_debug=True)
+        assert_actions_match(a_l[t], ref, dbg["logits"], spec, what=f"lazy period {period} step {t}")
+    assert float((a_e - a_l).abs().max()) <= 1e-4
+    for blk in (0, 2, 7):
+        for which in (0, 1, 2, 3):
+            assert rel_err(lazy.export_state_tensor(blk, which), eager.export_state_tensor(blk, which)) < 2e-4, (blk, which)
+    eager.close(), lazy.close()
+
+
+def test_lazy_export_prefill_and_mode_switches(hip_lib):
+    """Exports in the middle of a window, a prefill in between, leaving and re-entering lazy mode: none of it changes
+    the trajectory."""
+    from lram_amd.engine import Engine
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=52)
+    B = 4
+    seq = make_inputs(spec, B, 30, seed=22, reset_prob=0.0)
+    ctx = make_inputs(spec, B, 20, seed=23, reset_prob=0.0)
+    obs_seq = torch.stack([x[0] for x in ctx], 1).contiguous().cuda()
+    rtg_seq = torch.stack([x[1] for x in ctx], 1).contiguous().cuda()
+    rew_seq = torch.stack([x[2] for x in ctx], 1).contiguous().cuda()
+    eager = Engine(spec, sd, B, device="cuda:0")
+    lazy = Engine(spec, sd, B, device="cuda:0")
+    lazy.set_state_mode(True)
+    outs = []
+    for eng in (eager, lazy):
+        acts = [_run(eng, seq[:7])]
+        c_mid = eng.export_state_tensor(3, 0).clone()          # folds the pending windows in lazy mode
+        acts.append(_run(eng, seq[7:11]))
+        a_pre, _ = eng.prefill(obs_seq, rtg_seq, rew_seq)        # chunkwise kernels on the materialised state
+        acts.append(a_pre.clone().unsqueeze(0))
+        acts.append(_run(eng, seq[11:20]))
+        if eng is lazy:
+            eng.set_state_mode(False)
+        acts.append(_run(eng, seq[20:24]))
+        if eng is lazy:
+            eng.set_state_mode(True, 4)
+        acts.append(_run(eng, seq[24:]))
+        outs.append((torch.cat(acts), c_mid, eng.export_state_tensor(0, 0).clone(), eng.export_state_tensor(7, 1).clone()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-4
+    for i in (1, 2, 3):
+        assert rel_err(outs[1][i], outs[0][i]) < 2e-4, i
+    eager.close(), lazy.close()
+
+
+def test_lazy_env_slices_and_206m_geometry(hip_lib):
+    """Two env slices fold the same envs at the same steps as one slice (bit-identical), and the 5-column-slice head
+    geometry of the 206M model (DH = 640) follows the oracle."""
+    from lram_amd.engine import Engine
+    spec = ModelSpec(backbone="xlstm", d_model=1280, n_blocks=2, slstm_at=[1])
+    sd = init_state_dict(spec, seed=53)
+    B = 6
+    seq = make_inputs(spec, B, 18, seed=24, reset_prob=0.1)
+    outs = []
+    for micro in (1, 2):
+        eng = Engine(spec, sd, B, device="cuda:0")
+        eng.set_state_mode(True, 5)
+        eng.set_micro_batches(micro)
+        outs.append((_run(eng, seq), eng.export_state_tensor(0, 0).clone()))
+        eng.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ora = dt_ref.OraclePolicy(spec, sd)
+    for t, (obs, rtg, rew, mask) in enumerate(seq):
+        ref, dbg = ora.step(obs, rtg, rew, mask, return_debug=True)
+        assert_actions_match(outs[0][0][t], ref, dbg["logits"], spec, what=f"206M geometry step {t}")
+
+
+def test_lazy_mode_is_refused_or_ignored_where_it_does_not_apply(hip_lib):
+    from lram_amd.engine import Engine, LramError
+    tiny = preset("xlstm_tiny")                                   # head dim 64
+    eng = Engine(tiny, init_state_dict(tiny, 0), 2, device="cuda:0")
+    with pytest.raises(LramError):
+        eng.set_state_mode(True)
+    eng.close()
+    mam = preset("mamba_tiny")
+    eng = Engine(mam, init_state_dict(mam, 0), 2, device="cuda:0")
+    with pytest.raises(LramError):
+        eng.set_state_mode(True)
+    eng.close()
