@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--obs", choices=("state", "image"), default="state",
                     help="image: uint8 [3,64,64] frames through the IMPALA-CNN front end + 18-way discrete head "
                          "(BASELINE C4, Atari-shaped)")
+    ap.add_argument("--state", choices=("auto", "lazy", "eager"), default="auto",
+                    help="mLSTM matrix-memory representation (lram_set_state_mode); auto = lazy where the state pass dominates")
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph")
     ap.add_argument("--micro", type=int, default=0, help="env slices pipelined on separate streams (0 = auto, 1 = off)")
     ap.add_argument("--side-stream", action="store_true", help="issue the steps on a non-default HIP stream")
@@ -126,9 +128,16 @@ def main():
         lo, hi = ldist.shard_bounds(args.global_batch, rank, world)
         B = hi - lo
     eng = Engine(spec, sd, B, device=dev)
+    if spec.backbone == "xlstm" and (args.state != "auto" or "LRAM_STATE" not in os.environ):
+        try:
+            eng.set_state_mode(args.state)
+        except Exception:
+            if args.state == "lazy":
+                raise
     if args.graph:
         eng.set_graph_mode(True)
     eng.set_micro_batches(args.micro)
+    state_mode = eng.state_mode
 
     # ---- synthetic inputs, all resident in HBM before timing (DummyEnv-style) ----------
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -139,7 +148,8 @@ def main():
     obs_ring[:, :, idx] = torch.rand(n_ring, B, idx.numel(), generator=g, device=dev) * 2 - 1
     ep_len, rtg0, scale = 1000, 451.274 / 100.0, 100.0  # cheetah-run target / reward_scale
     phase = torch.arange(B, device=dev) % ep_len
-    steps_total = K + W
+    n_prime = 16  # untimed priming steps in lazy state mode (see below); the schedule covers them either way
+    steps_total = n_prime + K + W + 16  # + the standalone kernel measurement that follows the timed region
     tt = torch.arange(steps_total, device=dev).view(-1, 1)
     age = (phase.view(1, -1) + tt) % ep_len                       # steps since that env's last reset
     masks = (age == 0).to(torch.uint8).contiguous()
@@ -153,8 +163,11 @@ def main():
         img_ring = torch.randint(0, 256, (n_ring, B, 3, 64, 64), generator=g, device=dev, dtype=torch.uint8)
         emb = torch.empty(B, spec.d_model, device=dev)
 
-    def one_step(t):
-        t = t % steps_total
+    clock = [0]  # global timestep: the episode schedule (resets, returns-to-go) runs on without repeating step 0
+
+    def one_step(_t=None):
+        t = clock[0] if clock[0] < steps_total else 1 + (clock[0] - 1) % (steps_total - 1)
+        clock[0] += 1
         if img_ring is not None:
             eng.embed_images(img_ring[t % n_ring], emb)
             a, _ = eng.step(emb, rtgs[t], reward_tok, masks[t], discrete=True, obs_is_embedding=True)
@@ -168,6 +181,12 @@ def main():
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.set_stream(side)
+    if state_mode == "lazy":
+        # Untimed priming, not part of the W warm-up steps: every env starts with an empty matrix memory, and until an
+        # env's first fold (at most one fold period, 13 steps) the read pass has nothing to read.  The timed region
+        # must see the steady state, whatever W the caller picks.
+        for t in range(16):
+            one_step(t)
     for t in range(W):
         one_step(t)
     timing = not args.no_kernel_timing and not args.graph
@@ -190,6 +209,8 @@ def main():
     # ---- roofline of the dominant kernel -----------------------------------------------------------
     if spec.backbone == "xlstm":
         kname, abytes = "mlstm_cell_kernel", cell_kernel_algorithmic_bytes(spec, B, T)
+        if state_mode == "lazy":
+            kname = "mlstm_lazy_cell_kernel (+ its share of mlstm_lazy_fold_kernel)"
     else:
         kname, abytes = "mamba_ssm_kernel", ssm_kernel_algorithmic_bytes(spec, B, T)
     roofline = {"bound": "hbm", "kernel": kname, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -206,6 +227,11 @@ def main():
         ach = abytes / (avg_ms * 1e-3) / 1e9
         roofline.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, avg_launch_ms=avg_ms, launches_timed=kern_n,
                         kernel_share_of_step=kern_ms / (wall * 1e3))
+    if state_mode == "lazy":
+        roofline["note"] = ("lazy matrix memory: `achieved` prices the materialised algorithm's bytes (state read once + "
+                            "written once per env-step, SURVEY 8d) against the measured time of one read pass plus its share "
+                            "of the fold launches; the kernels move fewer bytes than that (`traffic`): C_base is read once "
+                            "per step and rewritten once per 13 steps")
     if timing and spec.backbone == "xlstm" and args.micro != 1:
         # the same kernel with the chip to itself (no overlapping slice): 8 extra, untimed-for-`value` steps
         eng.set_micro_batches(1)
@@ -222,7 +248,7 @@ def main():
                                   "algorithmic_bytes_per_launch": full,
                                   "note": "micro-batch pipeline off: one launch per block over all env slots"}
         eng.set_micro_batches(args.micro)
-    pmc_file = os.path.join(ROOT, "profiles", "r01_cell_kernel_hbm_traffic.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01_cell_kernel_hbm_traffic%s.json" % ("_lazy" if state_mode == "lazy" else ""))
     if os.path.exists(pmc_file):  # PMC bytes per launch come from a separate rocprofv3 --pmc pass (profiles/)
         try:
             with open(pmc_file) as fh:
@@ -264,7 +290,7 @@ def main():
                    else f"{args.config}, {B} env slots per GPU, {args.obs} observations",
                    "batch_per_gpu": B, "global_batch": args.global_batch if args.global_batch > 0 else B * world, "tokens_per_step": T,
                    "state_bytes_per_env": spec.state_bytes_per_env(), "parallelism": f"env-shard x{world}",
-                   "graph": bool(args.graph), "micro_batches": args.micro},
+                   "graph": bool(args.graph), "micro_batches": args.micro, "state_mode": state_mode},
         "roofline": roofline,
         "hbm_copy_measured_GBps": copy_gbps,
         "hbm_rmw_measured_GBps": rmw_gbps,

@@ -168,15 +168,20 @@ int32_t lram_state_import(lram_engine* e, int32_t block, int32_t which, const fl
 int32_t lram_set_graph_mode(lram_engine* e, int32_t enable);
 
 /* State representation of the mLSTM matrix memory for lram_step / short lram_encoder_step calls.
- *   lazy = 0 (default): C_t is materialised -- read and rewritten once per env-step.
- *   lazy = 1: C_t = g * C_base + sum_j c_j khat_j v_j^T.  A step reads C_base once and appends its tokens to a window of
- *             up to 48 tokens; C_base is rewritten ("folded", fp32 matrix cores) once every `fold_period` steps per env
- *             (0 = keep the current period, default 13; the folds of different envs are staggered).  Same mathematics
- *             as recurrent_step_stabilized_simple, ~0.64x the HBM traffic of the materialised update.  Needs an xLSTM
- *             head dim that is a multiple of 128; lram_state_export / import, lram_prefill, hipGraph mode and calls with
- *             more than 4 tokens fold every pending window first, so they see the reference state layout.
- * Also selectable with LRAM_STATE=lazy (and LRAM_LAZY_PERIOD) in the environment at lram_create. */
-int32_t lram_set_state_mode(lram_engine* e, int32_t lazy, int32_t fold_period);
+ *   mode 0: C_t is materialised -- read and rewritten once per env-step (the reference's representation).
+ *   mode 1: lazy -- C_t = g * C_base + sum_j c_j khat_j v_j^T.  A step reads C_base once and appends its tokens to a
+ *           window of up to 48 tokens; C_base is rewritten ("folded", fp32 matrix cores) once every `fold_period` steps
+ *           per env (0 = keep the current period, default 13; the folds of different envs are staggered).  Same
+ *           mathematics as recurrent_step_stabilized_simple ([3P]), ~0.6x the HBM bytes of the
+ *           materialised update.  Needs an xLSTM head dim that is a multiple of 128.
+ *   mode 2 (default): lazy where one block's matrix memory over the batch is at least 512 MiB, else materialised.
+ * lram_state_export / import, lram_prefill, hipGraph mode and calls with more than 4 tokens fold every pending window
+ * first, so they always see the reference state layout.  LRAM_STATE=eager|lazy|auto (and LRAM_LAZY_PERIOD) in the
+ * environment at lram_create set the initial mode.  lram_profile_end in lazy mode: total_ms includes the fold launches,
+ * n_launches counts the read passes. */
+int32_t lram_set_state_mode(lram_engine* e, int32_t mode, int32_t fold_period);
+/* 1 when the lazy representation is in effect for the allocated batch, else 0. */
+int32_t lram_get_state_mode(const lram_engine* e);
 
 /* Micro-batch pipeline (xLSTM): the env slots are processed as `n` slices on engine-owned HIP streams; the
  * HBM-bound matrix-memory kernels of all slices run back to back on one stream while the other slices'

@@ -106,7 +106,8 @@ struct lram_engine {
   DevBuf IMG_P, IMG_X0, IMG_X1, IMG_T;
   size_t img_cap = 0;  // batch * input pixels the image buffers were sized for
   // lazy matrix memory: C_base read once per step, rewritten once per `lazy_period` steps (see mlstm_lazy.hip)
-  bool lazy = false;        // requested mode (LRAM_STATE=lazy or lram_set_state_mode)
+  int lazy_mode = 2;        // 0 materialised, 1 lazy, 2 auto (LRAM_STATE / lram_set_state_mode)
+  bool lazy = false;        // effective choice for the current batch (decided in state_alloc / set_state_mode)
   bool lazy_ready = false;  // buffers allocated for the current batch
   int lazy_period = 13;
   int64_t lazy_step = 0;    // steps taken in lazy mode: fold phase and ping-pong parity
@@ -143,6 +144,7 @@ struct lram_engine {
   // profiling of the dominant recurrent kernel
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  std::vector<uint8_t> prof_aux;  // 1: the pair times a fold launch (adds to the total, is not a state-pass launch)
   size_t prof_used = 0;
 
   ~lram_engine() {
@@ -475,6 +477,16 @@ void lazy_alloc(lram_engine* e) {
   e->lazy_ready = true;
 }
 
+// auto: lazy where the state pass dominates -- one mLSTM block's matrix memory of at least 512 MiB over the batch
+// (16M geometry from 512 env slots, 206M from 82); below that the two extra launches per block cost more than the
+// saved bytes (measured: 16M / 256 envs 174k lazy vs 178k materialised, 64 envs 69k vs 82k).
+bool lazy_choice(const lram_engine* e) {
+  if (e->lazy_mode == 0 || !lazy_geometry_ok(e)) return false;
+  if (e->lazy_mode == 1) return true;
+  const double dh = e->cfg.inner / e->cfg.n_heads;
+  return (double)e->B * e->cfg.n_heads * dh * dh * 4.0 >= 512.0 * 1024 * 1024;
+}
+
 bool lazy_active(const lram_engine* e, int T) {
   return e->lazy && e->lazy_ready && !e->graph_mode && T >= 1 && T <= 4;
 }
@@ -554,6 +566,7 @@ void state_alloc(lram_engine* e, int B) {
   }
   e->B = B;
   alloc_workspace(e, kMaxTokens);
+  e->lazy = lazy_choice(e);
   if (e->lazy) lazy_alloc(e);
   LRAM_HIP_CHECK(hipDeviceSynchronize());
 }
@@ -593,7 +606,7 @@ void make_split(lram_engine* e, const float* w, size_t n) {
   e->split[w] = lram_engine::Split{p, n};
 }
 
-void prof_record(lram_engine* e, hipStream_t s, bool start) {
+void prof_record(lram_engine* e, hipStream_t s, bool start, bool aux = false) {
   if (!e->prof_on) return;
   if (start) {
     if (e->prof_used == e->prof_events.size()) {
@@ -601,7 +614,9 @@ void prof_record(lram_engine* e, hipStream_t s, bool start) {
       LRAM_HIP_CHECK(hipEventCreate(&a));
       LRAM_HIP_CHECK(hipEventCreate(&b));
       e->prof_events.emplace_back(a, b);
+      e->prof_aux.push_back(0);
     }
+    e->prof_aux[e->prof_used] = aux ? 1 : 0;
     LRAM_HIP_CHECK(hipEventRecord(e->prof_events[e->prof_used].first, s));
   } else {
     LRAM_HIP_CHECK(hipEventRecord(e->prof_events[e->prof_used].second, s));
@@ -837,7 +852,9 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
     for (const Slice& x : sl) {
       MlstmLazyArgs la = lazy_args(e, i, T, reset, x.b0, x.nb);
       la.compact = e->lazy_compact ? 1 : 0;
+      prof_record(e, fs, true, true);
       launch_mlstm_lazy_fold(la, fs);
+      prof_record(e, fs, false, true);
     }
   };
   auto next_mlstm = [&](int i) {
@@ -1154,7 +1171,10 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_CELL_LDS_PAD_KB")) e->cell_lds_pad = std::atoi(v) * 1024;
     if (const char* v = std::getenv("LRAM_CELL_UNROLL")) e->cell_unroll = std::atoi(v);
     if (const char* v = std::getenv("LRAM_PREFILL_CHUNK")) e->chunk_prefill = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_STATE")) e->lazy = std::string(v) == "lazy";
+    if (const char* v = std::getenv("LRAM_STATE")) {
+      const std::string m(v);
+      e->lazy_mode = m == "lazy" ? 1 : (m == "eager" || m == "materialised" || m == "materialized") ? 0 : 2;
+    }
     if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
     *out = e.release();
   });
@@ -1373,25 +1393,28 @@ int32_t lram_set_graph_mode(lram_engine* e, int32_t enable) {
   });
 }
 
-int32_t lram_set_state_mode(lram_engine* e, int32_t lazy, int32_t fold_period) {
+int32_t lram_set_state_mode(lram_engine* e, int32_t mode, int32_t fold_period) {
   return guarded([&] {
     LRAM_REQUIRE(e != nullptr, "lram_set_state_mode: null engine");
+    LRAM_REQUIRE(mode >= 0 && mode <= 2, "lram_set_state_mode: mode must be 0 (materialised), 1 (lazy) or 2 (auto)");
     LRAM_REQUIRE(fold_period == 0 || (fold_period >= 1 && fold_period * e->cfg.tokens_per_step + 4 <= kLazyWindow),
                  "lram_set_state_mode: fold_period out of range (the window holds 48 tokens)");
+    LRAM_REQUIRE(mode != 1 || lazy_geometry_ok(e),
+                 "lram_set_state_mode: lazy matrix memory needs an xLSTM head dim that is a multiple of 128");
     LRAM_HIP_CHECK(hipSetDevice(e->device));
     if (e->lazy_ready) {  // leave the current mode with a materialised state
       lazy_materialize(e, nullptr);
       LRAM_HIP_CHECK(hipDeviceSynchronize());
     }
-    e->lazy = lazy != 0;
+    e->lazy_mode = mode;
     if (fold_period > 0) e->lazy_period = fold_period;
     e->lazy_bound.clear();
-    if (e->lazy && e->B > 0) {
-      LRAM_REQUIRE(lazy_geometry_ok(e), "lram_set_state_mode: lazy matrix memory needs an xLSTM head dim that is a multiple of 128");
-      lazy_alloc(e);
-    }
+    e->lazy = e->B > 0 && lazy_choice(e);
+    if (e->lazy) lazy_alloc(e);
   });
 }
+
+int32_t lram_get_state_mode(const lram_engine* e) { return (e != nullptr && e->lazy && e->lazy_ready) ? 1 : 0; }
 
 int32_t lram_set_micro_batches(lram_engine* e, int32_t n) {
   return guarded([&] {
@@ -1413,14 +1436,16 @@ int32_t lram_profile_end(lram_engine* e, double* total_ms, int64_t* n_launches) 
   return guarded([&] {
     LRAM_REQUIRE(e && total_ms && n_launches, "lram_profile_end: bad argument");
     double tot = 0.0;
+    size_t n_aux = 0;
     for (size_t i = 0; i < e->prof_used; ++i) {
       LRAM_HIP_CHECK(hipEventSynchronize(e->prof_events[i].second));
       float ms = 0.f;
       LRAM_HIP_CHECK(hipEventElapsedTime(&ms, e->prof_events[i].first, e->prof_events[i].second));
       tot += ms;
+      if (e->prof_aux[i]) ++n_aux;
     }
     *total_ms = tot;
-    *n_launches = (int64_t)e->prof_used;
+    *n_launches = (int64_t)(e->prof_used - n_aux);
     e->prof_on = false;
     e->prof_used = 0;
   });

@@ -66,6 +66,7 @@ _SYMBOLS = {
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_embed_images": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
     "lram_set_state_mode": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32]),
+    "lram_get_state_mode": (ctypes.c_int32, [_VP]),
     "lram_stream_rmw": (ctypes.c_int32, [_VP, ctypes.c_size_t, _VP]),
     "lram_pad_obs": (ctypes.c_int32, [_VP, ctypes.c_int32, _VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_selftest_concurrent": (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]),
@@ -346,10 +347,17 @@ class Engine:
     def set_graph_mode(self, enable: bool):
         _check(self.lib, self.lib.lram_set_graph_mode(self._h, int(enable)))
 
-    def set_state_mode(self, lazy: bool, fold_period: int = 0):
-        """lazy=True: read-once matrix memory with a pending-token window, folded every `fold_period` steps
-        (lram_set_state_mode); lazy=False: materialised C (default)."""
-        _check(self.lib, self.lib.lram_set_state_mode(self._h, int(bool(lazy)), int(fold_period)))
+    def set_state_mode(self, mode, fold_period: int = 0):
+        """mode: False / 0 / "eager" = materialised C (the reference's representation); True / 1 / "lazy" = read-once
+        matrix memory with a pending-token window folded every `fold_period` steps; 2 / "auto" (default) = lazy where
+        the state pass dominates (lram_set_state_mode)."""
+        names = {"eager": 0, "materialised": 0, "lazy": 1, "auto": 2}
+        m = names[mode] if isinstance(mode, str) else int(mode)
+        _check(self.lib, self.lib.lram_set_state_mode(self._h, m, int(fold_period)))
+
+    @property
+    def state_mode(self) -> str:
+        return "lazy" if self.lib.lram_get_state_mode(self._h) else "materialised"
 
     def set_micro_batches(self, n: int):
         """Env slices pipelined on separate HIP streams (0 = auto, 1 = off); results are independent of n."""

@@ -32,8 +32,10 @@ def test_lazy_steps_match_oracle_and_eager(hip_lib, period):
     B, steps = 5, 45
     seq = make_inputs(spec, B, steps, seed=21, reset_prob=0.1)
     eager = Engine(spec, sd, B, device="cuda:0")
+    eager.set_state_mode("eager")
     lazy = Engine(spec, sd, B, device="cuda:0")
     lazy.set_state_mode(True, period)
+    assert eager.state_mode == "materialised" and lazy.state_mode == "lazy"
     a_e, a_l = _run(eager, seq), _run(lazy, seq)
     ora = dt_ref.OraclePolicy(spec, sd)
     for t, (obs, rtg, rew, mask) in enumerate(seq):
@@ -59,6 +61,7 @@ def test_lazy_export_prefill_and_mode_switches(hip_lib):
     rtg_seq = torch.stack([x[1] for x in ctx], 1).contiguous().cuda()
     rew_seq = torch.stack([x[2] for x in ctx], 1).contiguous().cuda()
     eager = Engine(spec, sd, B, device="cuda:0")
+    eager.set_state_mode("eager")
     lazy = Engine(spec, sd, B, device="cuda:0")
     lazy.set_state_mode(True)
     outs = []
@@ -116,3 +119,19 @@ def test_lazy_mode_is_refused_or_ignored_where_it_does_not_apply(hip_lib):
     with pytest.raises(LramError):
         eng.set_state_mode(True)
     eng.close()
+
+
+def test_auto_mode_picks_lazy_only_where_the_state_pass_dominates(hip_lib):
+    from lram_amd.engine import Engine
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=1)
+    small = Engine(spec, sd, 8, device="cuda:0")          # 8 MiB of matrix memory per block: materialised
+    assert small.state_mode == "materialised"
+    small.close()
+    big = Engine(spec, sd, 512, device="cuda:0")          # 512 MiB per block: lazy
+    assert big.state_mode == "lazy"
+    big.set_state_mode("eager")
+    assert big.state_mode == "materialised"
+    big.set_state_mode("auto")
+    assert big.state_mode == "lazy"
+    big.close()
