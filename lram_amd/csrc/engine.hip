@@ -113,6 +113,7 @@ struct lram_engine {
   int64_t lazy_step = 0;    // steps taken in lazy mode: fold phase and ping-pong parity
   std::vector<int> lazy_bound;  // host-side upper bound of pending tokens per fold class (b % period)
   bool lazy_compact = false;    // this step's fold launches may use the compact grid (no window can overflow)
+  bool lazy_dirty = false;      // a lazy step ran since the last materialise: windows may hold pending tokens
   DevBuf LZ_COUNT;          // [2][B] int32 pending tokens per env
   // state + workspace
   int B = 0;
@@ -517,7 +518,7 @@ MlstmLazyArgs lazy_args(lram_engine* e, int i, int T, const uint8_t* reset, int 
 // Fold every pending window into C_base and empty the bookkeeping: afterwards the state is the materialised
 // reference layout again (export / import, prefill, long encoder calls, leaving lazy mode).
 void lazy_materialize(lram_engine* e, hipStream_t s) {
-  if (!e->lazy_ready) return;
+  if (!e->lazy_ready || !e->lazy_dirty) return;
   const lram_config& c = e->cfg;
   const size_t B = e->B, NH = c.n_heads;
   for (int i = 0; i < c.n_blocks; ++i) {
@@ -533,6 +534,7 @@ void lazy_materialize(lram_engine* e, hipStream_t s) {
                               (int)B, (int)NH, s);
   }
   e->lazy_bound.assign(e->lazy_period, 0);
+  e->lazy_dirty = false;
 }
 
 void state_alloc(lram_engine* e, int B) {
@@ -900,7 +902,10 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
     for (const Slice& x : sl) mlstm_back(e, i, T, x);
   }
   if (lazy && fs != hbm) stream_after(e, hbm, fs);
-  if (lazy) ++e->lazy_step;
+  if (lazy) {
+    ++e->lazy_step;
+    e->lazy_dirty = true;
+  }
   for (const Slice& x : sl) {
     const size_t r0 = (size_t)x.b0 * T;
     launch_row_norm(e->X.p + r0 * D, D, e->HID.p + r0 * D, D, e->post_g, e->post_b, x.nb * T, D, c.ln_eps,

@@ -10,8 +10,11 @@ python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=
 tail -3 $OUT/pytest_gpu.log | cut -c1-200
 python bench.py --steps ${STEPS:-64} --warmup 8 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 cut -c1-400 $OUT/bench.json; tail -2 $OUT/bench.err | cut -c1-200
+python bench.py --steps ${STEPS:-64} --warmup 8 --state eager --no-cpu-baseline > $OUT/bench_eager.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_eager.json
 bash scripts/gpu_prof.sh headline --steps 16 --warmup 4
-bash scripts/pmc_pass.sh 2>&1 | grep -E "rc=|hbm_bytes_per_env|fetch_reported|write_reported"
+bash scripts/gpu_prof.sh headline_eager --steps 16 --warmup 4 --state eager | head -6
+rm -rf $OUT/pmc; bash scripts/pmc_pass.sh 2>&1 | grep -E "rc=|hbm_bytes_per_env|state_mode"; rm -rf $OUT/pmc_lazy; mv $OUT/pmc $OUT/pmc_lazy
+BENCH_ARGS="--state eager" bash scripts/pmc_pass.sh 2>&1 | grep -E "rc=|hbm_bytes_per_env|state_mode"; rm -rf $OUT/pmc_eager; mv $OUT/pmc $OUT/pmc_eager
 if [ "${FULL:-1}" = "1" ]; then
   bash scripts/gpu_prof.sh mamba --config mamba_48m --batch 2048 --steps 16 --warmup 4 | head -8
   PREFILL_MODES=chunkwise bash scripts/gpu_prof_prefill.sh xlstm_16m 512 63 1 | head -10
