@@ -135,3 +135,30 @@ def test_auto_mode_picks_lazy_only_where_the_state_pass_dominates(hip_lib):
     big.set_state_mode("auto")
     assert big.state_mode == "lazy"
     big.close()
+
+
+@pytest.mark.parametrize("period", [13, 3])
+def test_lazy_encoder_step_token_counts(hip_lib, period):
+    """lram_encoder_step with 1..4 tokens per call in lazy mode (4-token calls fill the 48-token window faster than the
+    fold phase empties it: the overflow folds take the full-grid path), longer calls fold first and run on the
+    materialised kernels; hidden states and the final state follow the oracle."""
+    from lram_amd.engine import Engine
+    from oracle import xlstm_ref
+    spec = ModelSpec(backbone="xlstm", d_model=256, n_blocks=3, slstm_at=[1])   # 4 heads x 128
+    sd = init_state_dict(spec, seed=61)
+    B = 3
+    eng = Engine(spec, sd, B, device="cuda:0")
+    eng.set_state_mode("lazy", period)
+    state = None
+    g = torch.Generator().manual_seed(12)
+    for T in [4] * 14 + [1, 2, 3, 4, 9, 4, 4, 1, 30, 2, 4, 4, 4]:
+        x = torch.randn(B, T, spec.d_model, generator=g)
+        ref, state = xlstm_ref.encoder_forward_cached(spec, sd, x, state)
+        out = eng.encoder_step(x.cuda())
+        torch.cuda.synchronize()
+        assert rel_err(out, ref) < 2e-4, T
+    pkv = eng.export_past_key_values()
+    for i in range(3):
+        assert rel_err(pkv["block_0"]["mlstm_state"][i], state["block_0"]["mlstm_state"][i]) < 2e-4, i
+    assert rel_err(pkv["block_2"]["mlstm_state"][0], state["block_2"]["mlstm_state"][0]) < 2e-4
+    eng.close()
