@@ -850,14 +850,12 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
     fs = e->fold_stream;
     stream_after(e, fs, hbm);  // hbm was forked from the caller's stream: inherit that dependency
   }
-  auto launch_folds = [&](int i) {
-    for (const Slice& x : sl) {
-      MlstmLazyArgs la = lazy_args(e, i, T, reset, x.b0, x.nb);
-      la.compact = e->lazy_compact ? 1 : 0;
-      prof_record(e, fs, true, true);
-      launch_mlstm_lazy_fold(la, fs);
-      prof_record(e, fs, false, true);
-    }
+  auto launch_folds = [&](int i) {  // one launch per block over all env slots: folds do not care about the slices
+    MlstmLazyArgs la = lazy_args(e, i, T, reset, 0, e->B);
+    la.compact = e->lazy_compact ? 1 : 0;
+    prof_record(e, fs, true, true);
+    launch_mlstm_lazy_fold(la, fs);
+    prof_record(e, fs, false, true);
   };
   auto next_mlstm = [&](int i) {
     for (int k = i + 1; k < c.n_blocks; ++k)
