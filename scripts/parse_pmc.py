@@ -30,9 +30,9 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                     lazy = lazy or "mlstm_lazy_cell_kernel" in row["Kernel_Name"]
     # median = steady-state launch (the first timestep resets every env and skips the C read)
     res[counter] = {k: (sorted(v)[len(v) // 2] if v else None, len(v)) for k, v in vals.items()}
-    # lazy matrix memory: a state pass = one read launch + its share of the fold launches (one fold launch per read
-    # launch; the mean, since a launch folds ~1/13 of its envs)
-    res[counter]["fold_mean"] = (sum(vals["fold"]) / len(vals["fold"]) if vals["fold"] else 0.0, len(vals["fold"]))
+    # lazy matrix memory: a state pass = one read launch + its share of the fold launches (all fold bytes of the run
+    # spread over the read launches; a fold launch covers every slice and ~1/13 of the envs)
+    res[counter]["fold_mean"] = (sum(vals["fold"]) / max(len(vals["cell"]), 1) if vals["fold"] else 0.0, len(vals["fold"]))
     res[counter]["lazy"] = lazy
 print(res)
 GiB = 1024 ** 3
