@@ -158,3 +158,74 @@ def test_mlstm_cell_matches_transformers_xlstm_native_step():
         assert torch.allclose(m.view(B, NH, 1), m_h, rtol=0, atol=1e-6), t
     assert torch.allclose(c * math.sqrt(DH), c_h, rtol=1e-5, atol=1e-6)
     assert torch.allclose(n.squeeze(-1) * math.sqrt(DH), n_h, rtol=1e-5, atol=1e-6)
+
+
+def _stabilised_factors(ig, fg, m0):
+    """Per-token factors the kernels share: f_t = exp(logsig(f~_t) + m_{t-1} - m_t), i_t = exp(i~_t - m_t)."""
+    import torch.nn.functional as F
+    f, i, m = [], [], []
+    mp = m0
+    for t in range(ig.shape[0]):
+        lf = F.logsigmoid(fg[t])
+        mn = torch.maximum(lf + mp, ig[t])
+        f.append(torch.exp(lf + mp - mn))
+        i.append(torch.exp(ig[t] - mn))
+        m.append(mn)
+        mp = mn
+    return torch.stack(f), torch.stack(i), torch.stack(m)
+
+
+def test_chunkwise_and_lazy_forms_equal_the_recurrent_step():
+    """CPU statement of the two algebraic rewrites the HIP kernels use, against the oracle's token-by-token recurrence
+    (one head, fp64 to separate algebra from rounding):
+      chunkwise (csrc/mlstm_chunk.hip):  H = diag(fcum) Q C_0 + A V,  C_T = fcum_T C_0 + (w K)^T V,
+                                         A[t][s] = (f_{s+1}..f_t) i_s (q_t . k_s),  q_t.n_t = fcum_t q_t.n_0 + sum_s A[t][s]
+      lazy (csrc/mlstm_lazy.hip):        C_t = g C_base + sum_j c_j k_j v_j^T read through a pending window, folded
+                                         every few steps."""
+    import math
+    from oracle import xlstm_ref
+    torch.manual_seed(0)
+    DH, T = 16, 23
+    dt = torch.float64
+    q, k, v = (torch.randn(T, DH, dtype=dt) for _ in range(3))
+    ig, fg = torch.randn(T, dtype=dt) * 2, torch.randn(T, dtype=dt) * 2 + 1
+    c0, n0, m0 = torch.randn(DH, DH, dtype=dt), torch.randn(DH, dtype=dt), torch.tensor(0.3, dtype=dt)
+    # reference: the oracle's recurrent step, token by token
+    c, n, m = c0.view(1, 1, DH, DH).clone(), n0.view(1, 1, DH, 1).clone(), m0.view(1, 1, 1, 1).clone()
+    h_ref = []
+    for t in range(T):
+        h, (c, n, m) = xlstm_ref.mlstm_recurrent_step(c, n, m, q[t].view(1, 1, 1, DH), k[t].view(1, 1, 1, DH),
+                                                      v[t].view(1, 1, 1, DH), ig[t].view(1, 1, 1, 1), fg[t].view(1, 1, 1, 1))
+        h_ref.append(h.view(DH))
+    h_ref = torch.stack(h_ref)
+    f, i, mt = _stabilised_factors(ig, fg, m0)
+    kh = k / math.sqrt(DH)
+    # ---- chunkwise form over the whole sequence as one chunk ----
+    fcum = torch.cumprod(f, 0)
+    A = torch.zeros(T, T, dtype=dt)
+    for t in range(T):
+        for s in range(t + 1):
+            A[t, s] = torch.prod(f[s + 1: t + 1]) * i[s] * (q[t] @ kh[s])
+    H = fcum[:, None] * (q @ c0) + A @ v
+    den = torch.maximum((fcum * (q @ n0) + A.sum(1)).abs(), torch.exp(-mt)) + 1e-6
+    w = torch.stack([torch.prod(f[s + 1:]) * i[s] for s in range(T)])
+    C_T = fcum[-1] * c0 + (w[:, None] * kh).T @ v
+    assert torch.allclose(H / den[:, None], h_ref, rtol=1e-9, atol=1e-10)
+    assert torch.allclose(C_T, c.view(DH, DH), rtol=1e-9, atol=1e-10)
+    assert torch.allclose(fcum[-1] * n0 + (w[:, None] * kh).sum(0), n.view(DH), rtol=1e-9, atol=1e-10)
+    # ---- lazy form: read-only base + window, folded every 5 tokens; denominators from the eager n recurrence ----
+    base, g, win_k, win_v, coef = c0.clone(), torch.tensor(1.0, dtype=dt), [], [], []
+    nn_ = n0.clone()
+    for t in range(T):
+        if t % 5 == 0 and win_k:   # fold
+            base = g * base + sum(cj * torch.outer(kj, vj) for cj, kj, vj in zip(coef, win_k, win_v))
+            g, win_k, win_v, coef = torch.tensor(1.0, dtype=dt), [], [], []
+        g = g * f[t]
+        coef = [cj * f[t] for cj in coef] + [i[t]]
+        win_k.append(kh[t]), win_v.append(v[t])
+        nn_ = f[t] * nn_ + i[t] * kh[t]
+        num = g * (q[t] @ base) + sum(cj * (q[t] @ kj) * vj for cj, kj, vj in zip(coef, win_k, win_v))
+        d = torch.maximum((q[t] @ nn_).abs(), torch.exp(-mt[t])) + 1e-6
+        assert torch.allclose(num / d, h_ref[t], rtol=1e-9, atol=1e-10), t
+    final = g * base + sum(cj * torch.outer(kj, vj) for cj, kj, vj in zip(coef, win_k, win_v))
+    assert torch.allclose(final, c.view(DH, DH), rtol=1e-9, atol=1e-10)
