@@ -189,6 +189,20 @@ int32_t lram_get_state_mode(const lram_engine* e);
  * Results do not depend on n (envs are independent). */
 int32_t lram_set_micro_batches(lram_engine* e, int32_t n);
 
+/* Reference-trajectory modes of the Mamba agent (Mamba engines only; defaults 1 / 0 = one state advance per
+ * env-step, a reset empties every layer).
+ *   mamba_repeat R > 1: DiscreteDecisionMamba.get_action_pred (src/algos/decision_mamba.py:107-122) calls the policy
+ *     once per action dim with the inference cache on, so the conv / ssm state advances R = env_act_dim times per
+ *     env-step on the same (state, rtg, reward) tokens and action dim i is the prediction of forward i.  lram_step
+ *     then runs R forwards (reset mask applied before the first); columns >= R hold forward R - 1.  Discrete heads
+ *     (act_dim 1 in the reference) always take one forward.
+ *   stale_state != 0: InferenceParams.reset() (src/algos/decision_mamba.py:20-25) only zeroes seqlen_offset, and
+ *     MambaEncoder.forward bumps it inside the layer loop (src/algos/models/decision_mamba.py:130-149): layer 0 runs
+ *     its full scan from an empty state, layers >= 1 step on from the previous episode's cache.  The reset mask of
+ *     lram_step / lram_prefill and lram_reset then re-initialise layer 0 only. */
+int32_t lram_set_compat_mode(lram_engine* e, int32_t mamba_repeat, int32_t stale_state);
+int32_t lram_get_compat_mode(const lram_engine* e, int32_t* mamba_repeat, int32_t* stale_state);
+
 /* Per-kernel timing of the recurrent step, measured with HIP events on the stream the kernels are
  * launched on.  lram_profile_begin arms it; every later lram_step records one (start, stop) event pair
  * around the mLSTM cell-update launches (xLSTM) or the selective-state-update launches (Mamba).

@@ -33,7 +33,8 @@ from .image_encoder import ImageEncoder
 
 class _InferenceParams:
     """Stand-in for the reference's InferenceParams (src/algos/decision_mamba.py:9-25): reset() clears the
-    cache.  Unlike the reference the engine zeroes *all* cached state on reset."""
+    cache -- every layer by default; with the agent's `compat_stale_state` only layer 0, as the reference does
+    (SURVEY.md 3.5 Q1)."""
 
     def __init__(self, agent: "RecurrentAgent"):
         self._agent = agent
@@ -49,7 +50,8 @@ class RecurrentAgent:
                  discrete: bool = False, state_mean: Optional[torch.Tensor] = None,
                  state_std: Optional[torch.Tensor] = None, target_return: float = 0.0, reward_scale: float = 1.0,
                  graph: bool = False, reprime_context: bool = False, persist_context: bool = False,
-                 torch_image_encoder: bool = False):
+                 torch_image_encoder: bool = False, compat_mamba_repeat: bool = False,
+                 compat_stale_state: bool = False):
         self.spec = spec
         # host copy of the weights: lets the agent cross a process boundary (make_pickleable / reinit_cuda_kernels)
         self._state_dict = {k: v.detach().to("cpu") for k, v in state_dict.items()}
@@ -86,6 +88,22 @@ class RecurrentAgent:
         if graph:
             self.engine.set_graph_mode(True)
         self._zero_reward = torch.zeros(n_envs, dtype=torch.float32, device=self.device)
+        # Reference-trajectory modes of the Mamba agent (lram_set_compat_mode).  Off: one state
+        # advance per env-step and a reset empties every layer.  On: the trajectory the reference's
+        # DiscreteDecisionMamba.get_action_pred / InferenceParams.reset() actually produce.
+        if (compat_mamba_repeat or compat_stale_state) and spec.backbone != "mamba":
+            raise ValueError("compat_mamba_repeat / compat_stale_state reproduce quirks of the reference's Mamba agent "
+                             "(src/algos/decision_mamba.py); the xLSTM agent has neither")
+        self.compat_mamba_repeat = bool(compat_mamba_repeat)
+        self.compat_stale_state = bool(compat_stale_state)
+        self._compat_repeat_now = 1
+        if self.compat_stale_state:
+            self.engine.set_compat_mode(1, True)
+
+    @property
+    def trajectory_mode(self) -> dict:
+        """Which trajectory semantics the rollout uses (logged by rollout / bench)."""
+        return {"compat_mamba_repeat": self.compat_mamba_repeat, "compat_stale_state": self.compat_stale_state}
 
     # ---- cache handle: `model.past_key_values = None` resets, reading exports the reference layout ----
     @property
@@ -113,6 +131,8 @@ class RecurrentAgent:
             self.engine = Engine(self.spec, self._state_dict, self.n_envs, self.device)
             if self._graph:
                 self.engine.set_graph_mode(True)
+            if self.compat_stale_state or self._compat_repeat_now != 1:
+                self.engine.set_compat_mode(self._compat_repeat_now, self.compat_stale_state)
 
     def __getstate__(self):
         d = dict(self.__dict__)
@@ -165,6 +185,12 @@ class RecurrentAgent:
         rew = self._zero_reward if rewards is None else rewards.to(self.device, torch.float32).reshape(-1).contiguous()
         if reset_mask is not None:
             reset_mask = reset_mask.to(self.device, torch.uint8).contiguous()
+        if self.compat_mamba_repeat:
+            # one forward per action dim of the env (decision_mamba.py:107: env_act_dim, else the padded action width)
+            rep = 1 if self.is_discrete else int(self.spec.act_dim if env_act_dim is None else env_act_dim)
+            if rep != self._compat_repeat_now:
+                self.engine.set_compat_mode(rep, self.compat_stale_state)
+                self._compat_repeat_now = rep
         actions, _ = self.engine.step(obs, rtg, rew, reset_mask, discrete=self.is_discrete, obs_is_embedding=is_emb)
         if self.is_discrete:
             return actions[:, :1].to(torch.int64)

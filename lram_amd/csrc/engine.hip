@@ -135,6 +135,9 @@ struct lram_engine {
   hipStream_t capture_stream = nullptr;  // capture needs a non-default stream; replay runs on the caller's
   // micro-batch pipeline: env slices on their own streams, cell kernels serialised on hbm_stream
   int n_micro = 0;  // 0 = auto
+  // reference-trajectory modes of the Mamba agent (lram_set_compat_mode)
+  int compat_repeat = 1;      // forwards per env-step: action dim i is read from forward min(i, repeat - 1)
+  bool compat_stale = false;  // a reset re-initialises layer 0 only; layers >= 1 keep the previous episode's state
   int cell_unroll = 16;   // C rows in flight per thread (LRAM_CELL_UNROLL overrides: 8 / 16 / 32)
   int cell_lds_pad = -1;  // -1 = auto;  // bytes of LDS the cell kernel requests per workgroup while pipelined (occupancy cap)
   std::vector<hipStream_t> micro_streams;
@@ -927,7 +930,9 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   float* Q = e->Q.p + r0 * ldx;
   float* DTP = e->DTP.p + r0 * di;
   float* H = e->H.p + r0 * di;
-  const uint8_t* rs = reset ? reset + b0 : nullptr;
+  // compat_stale (reference InferenceParams.reset(), decision_mamba.py:20-25 + models/decision_mamba.py:130-149):
+  // only layer 0 starts the episode from an empty state
+  const uint8_t* rs = (reset && !(e->compat_stale && i > 0)) ? reset + b0 : nullptr;
   hipStream_t gs = sl.s;
   if (stage == 0) {
     launch_add_rms_norm(X, i == 0 ? nullptr : RES, RES, XN, w.norm_g, rows, D, c.norm_eps, sl.s);
@@ -1051,7 +1056,8 @@ void embed_images(lram_engine* e, const uint8_t* images, int C, int H, int W, fl
 // reset mask applies before the first timestep; the action head runs on the last timestep only (and only if an
 // output buffer is given).  One fork / join of the slice streams brackets the whole call.
 void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* rtg, const float* rew, int L,
-                        const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s) {
+                        const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s,
+                        int col_begin = 0) {
   const lram_config& c = e->cfg;
   const int D = c.d_model, T = c.tokens_per_step;
   const int64_t obs_w = emb ? D : c.state_dim;
@@ -1106,7 +1112,7 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
       gemm(e, gh, x.s);
       launch_action_argmax(e->LOGITS.p + b0 * nlog, actions + b0 * c.act_dim,
                            tokens ? tokens + b0 * c.act_dim : nullptr, x.nb, c.act_dim, c.n_vocab, c.n_discrete,
-                           c.action_channels, c.tok_min, c.tok_max, discrete, x.s);
+                           c.action_channels, c.tok_min, c.tok_max, discrete, col_begin, x.s);
     }
   }
   if (multi) join_slices(e, sl, hbm, s);
@@ -1114,7 +1120,12 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
 
 void step_launches(lram_engine* e, const float* obs, int emb, const float* rtg, const float* rew,
                    const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s) {
-  timesteps_launches(e, obs, emb, rtg, rew, 1, reset, discrete, actions, tokens, s);
+  // compat_repeat (reference DiscreteDecisionMamba.get_action_pred, src/algos/decision_mamba.py:107-122): the same
+  // (state, rtg, reward) tokens go through the stack once per action dim with the cache on, and action dim i is the
+  // prediction of forward i.  Forward p writes action columns >= p, so column i keeps forward min(i, repeat - 1).
+  const int passes = discrete ? 1 : std::max(1, std::min(e->compat_repeat, e->cfg.act_dim));
+  for (int p = 0; p < passes; ++p)
+    timesteps_launches(e, obs, emb, rtg, rew, 1, p == 0 ? reset : nullptr, discrete, actions, tokens, s, p);
 }
 
 struct StateView {
@@ -1242,6 +1253,7 @@ int32_t lram_reset(lram_engine* e, const uint8_t* dev_env_mask, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = e->B;
     for (int i = 0; i < e->cfg.n_blocks; ++i) {
+      if (e->compat_stale && i > 0) break;  // reference Mamba reset: layers >= 1 keep their cached state (Q1)
       BlockState& st = e->st[i];
       const bool slstm = e->cfg.backbone == LRAM_BACKBONE_XLSTM && e->cfg.block_is_slstm[i];
       if (slstm)
@@ -1425,6 +1437,26 @@ int32_t lram_set_micro_batches(lram_engine* e, int32_t n) {
     e->n_micro = n;
     e->drop_graph();
   });
+}
+
+int32_t lram_set_compat_mode(lram_engine* e, int32_t mamba_repeat, int32_t stale_state) {
+  return guarded([&] {
+    LRAM_REQUIRE(e != nullptr, "lram_set_compat_mode: null engine");
+    LRAM_REQUIRE(mamba_repeat >= 1 && mamba_repeat <= 64, "lram_set_compat_mode: mamba_repeat must be in 1..64");
+    LRAM_REQUIRE(e->cfg.backbone == LRAM_BACKBONE_MAMBA || (mamba_repeat == 1 && stale_state == 0),
+                 "lram_set_compat_mode: the repeated-forward / stale-state quirks belong to the reference's Mamba agent "
+                 "(src/algos/decision_mamba.py); the xLSTM agent does a single forward and drops the whole cache");
+    if (e->compat_repeat != mamba_repeat || e->compat_stale != (stale_state != 0)) e->drop_graph();
+    e->compat_repeat = mamba_repeat;
+    e->compat_stale = stale_state != 0;
+  });
+}
+
+int32_t lram_get_compat_mode(const lram_engine* e, int32_t* mamba_repeat, int32_t* stale_state) {
+  if (e == nullptr) return 1;
+  if (mamba_repeat) *mamba_repeat = e->compat_repeat;
+  if (stale_state) *stale_state = e->compat_stale ? 1 : 0;
+  return 0;
 }
 
 int32_t lram_profile_begin(lram_engine* e) {

@@ -58,6 +58,8 @@ _SYMBOLS = {
     "lram_state_import": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
     "lram_set_graph_mode": (ctypes.c_int32, [_VP, ctypes.c_int32]),
     "lram_set_micro_batches": (ctypes.c_int32, [_VP, ctypes.c_int32]),
+    "lram_set_compat_mode": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32]),
+    "lram_get_compat_mode": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "lram_profile_begin": (ctypes.c_int32, [_VP]),
     "lram_profile_end": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "lram_gemm_f32": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
@@ -362,6 +364,18 @@ class Engine:
     def set_micro_batches(self, n: int):
         """Env slices pipelined on separate HIP streams (0 = auto, 1 = off); results are independent of n."""
         _check(self.lib, self.lib.lram_set_micro_batches(self._h, int(n)))
+
+    def set_compat_mode(self, mamba_repeat: int = 1, stale_state: bool = False):
+        """Reference-trajectory modes of the Mamba agent (lram_set_compat_mode):
+        `mamba_repeat` forwards per env-step with action dim i read from forward i
+        (src/algos/decision_mamba.py:107-122), `stale_state`: a reset re-initialises layer 0 only (:20-25)."""
+        _check(self.lib, self.lib.lram_set_compat_mode(self._h, int(mamba_repeat), int(bool(stale_state))))
+
+    @property
+    def compat_mode(self):
+        r, st = ctypes.c_int32(1), ctypes.c_int32(0)
+        self.lib.lram_get_compat_mode(self._h, ctypes.byref(r), ctypes.byref(st))
+        return {"mamba_repeat": int(r.value), "stale_state": bool(st.value)}
 
     def profile_begin(self):
         _check(self.lib, self.lib.lram_profile_begin(self._h))

@@ -106,7 +106,19 @@ class OraclePolicy:
     embed (s, rtg, r), run the 3 tokens through the recurrent stack, read the action at the rtg token.
     """
 
-    def __init__(self, spec, sd, state_mean=None, state_std=None):
+    def __init__(self, spec, sd, state_mean=None, state_std=None, mamba_repeat=1, stale_state=False):
+        """mamba_repeat / stale_state: the trajectory the reference's Mamba agent actually produces:
+        Q2  DiscreteDecisionMamba.get_action_pred (src/algos/decision_mamba.py:107-122) runs `policy(**inputs)` once
+            per action dim with the cache on -- the same (s, rtg, r) tokens advance the conv / ssm state
+            `mamba_repeat` = env_act_dim times per env-step, and action dim i is `action_preds[0, -1, i]` of forward i
+            (columns >= mamba_repeat, which the reference slices away, hold the last forward here);
+        Q1  InferenceParams.reset() (:20-25) only zeroes seqlen_offset; MambaEncoder.forward bumps the offset inside
+            its layer loop (src/algos/models/decision_mamba.py:130-149), so after a reset layer 0 takes the
+            full-sequence path from an empty state (overwriting its cache) while layers >= 1 take the step path on the
+            previous episode's conv / ssm state: `stale_state` resets layer 0 only."""
+        if (mamba_repeat != 1 or stale_state) and spec.backbone != "mamba":
+            raise ValueError("mamba_repeat / stale_state are quirks of the reference's Mamba agent")
+        self.mamba_repeat, self.stale_state = int(mamba_repeat), bool(stale_state)
         self.spec = spec
         self.sd = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
         self.state_mean, self.state_std = state_mean, state_std
@@ -125,13 +137,25 @@ class OraclePolicy:
             self.reset(obs.shape[0])
         mod = mamba_ref if spec.backbone == "mamba" else xlstm_ref
         if reset_mask is not None and bool(reset_mask.any()):
-            self.state = mod.reset_state_rows(self.state, reset_mask.bool())
+            if self.stale_state:
+                fresh = mod.reset_state_rows({0: self.state[0]}, reset_mask.bool())
+                self.state = {**self.state, 0: fresh[0]}
+            else:
+                self.state = mod.reset_state_rows(self.state, reset_mask.bool())
         x = embed_tokens(spec, sd, obs, rtg, reward, self.state_mean, self.state_std)
-        if spec.backbone == "mamba":
-            hidden, self.state = mamba_ref.encoder_forward_cached(spec, sd, x, self.state)
-        else:
-            hidden, self.state = xlstm_ref.encoder_forward_cached(spec, sd, x, self.state)
-        act, logits = action_head(spec, sd, hidden[:, 1], discrete)
+        passes = 1 if (discrete or spec.backbone != "mamba") else max(1, min(self.mamba_repeat, spec.act_dim))
+        act = logits = hidden = None
+        for p in range(passes):
+            if spec.backbone == "mamba":
+                hidden, self.state = mamba_ref.encoder_forward_cached(spec, sd, x, self.state)
+            else:
+                hidden, self.state = xlstm_ref.encoder_forward_cached(spec, sd, x, self.state)
+            act_p, logits_p = action_head(spec, sd, hidden[:, 1], discrete)
+            if p == 0:
+                act, logits = act_p.clone(), logits_p.clone()
+            else:  # action dim i comes from forward i (columns beyond the last forward follow it)
+                act[:, p:] = act_p[:, p:]
+                logits[:, p:] = logits_p[:, p:]
         if return_debug:
             return act, {"tokens": x, "hidden": hidden, "logits": logits}
         return act

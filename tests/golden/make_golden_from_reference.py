@@ -233,6 +233,118 @@ def agent_predict_trace(g):
             "returned_actions": [a.tolist() for a in returned]}
 
 
+def mamba_agent_trace():
+    """The reference's Mamba rollout control flow, executed: `DiscreteDecisionMamba.get_action_pred`
+    (src/algos/decision_mamba.py:76-127: one `policy(**inputs)` per action dim with the cache on, action dim i read from
+    forward i), the `InferenceParams` dataclass with its `reset()` (:8-25) and `MambaEncoder.forward`
+    (src/algos/models/decision_mamba.py:109-166: per-layer choice between the full call and the per-token loop,
+    `seqlen_offset` bumped inside the layer loop), over two envs x two episodes with `inference_params.reset()` at the
+    episode end as custom_evaluate_policy does (src/callbacks/evaluation.py:248-251).
+
+    mamba_ssm is absent, so each encoder layer is a stand-in that restates what [3P] mamba_ssm Block + Mamba.forward do
+    with an `inference_params` (add -> RMSNorm -> mixer; `_get_states_from_cache` allocates zero conv / ssm states for
+    an unseen layer_idx; seqlen_offset > 0: `step()` on the cached states in place; seqlen_offset == 0: the
+    full-sequence path from an EMPTY state whose final conv / ssm states overwrite the cache) around the oracle's
+    `mamba_step` mixer math.  What this vector pins is therefore the reference's control flow -- which layers restart,
+    how often the state advances per env-step, which forward each action dim comes from -- not the mixer arithmetic.
+    Stored: inputs, the weight seed, and the actions `get_action_pred` returned."""
+    import ast
+    from dataclasses import dataclass, field
+    from types import SimpleNamespace
+    from typing import Optional, Tuple, Union
+    from transformers.modeling_outputs import BaseModelOutputWithPastAndCrossAttentions
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from lram_amd import init_state_dict, preset
+    from oracle import dt_ref, mamba_ref
+
+    # --- reference code, executed ---
+    path = os.path.join(REF, "src/algos/decision_mamba.py")
+    tree = ast.parse(open(path).read())
+    ip_cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "InferenceParams")
+    ns = {"dataclass": dataclass, "field": field}
+    exec(compile(ast.Module(body=[ip_cls], type_ignores=[]), path, "exec"), ns)
+    InferenceParams = ns["InferenceParams"]
+    gap_ns = {"torch": torch, "sample_from_logits": None}
+    gcls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DiscreteDecisionMamba")
+    gfn = [n for n in gcls.body if isinstance(n, ast.FunctionDef) and n.name == "get_action_pred"]
+    exec(compile(ast.Module(body=gfn, type_ignores=[]), path, "exec"), gap_ns)
+    path2 = os.path.join(REF, "src/algos/models/decision_mamba.py")
+    tree2 = ast.parse(open(path2).read())
+    ecls = next(n for n in tree2.body if isinstance(n, ast.ClassDef) and n.name == "MambaEncoder")
+    efn = [n for n in ecls.body if isinstance(n, ast.FunctionDef) and n.name == "forward"]
+    enc_ns = {"torch": torch, "Optional": Optional, "Tuple": Tuple, "Union": Union, "RMSNorm": type(None),
+              "rms_norm_fn": None, "layer_norm_fn": None,
+              "BaseModelOutputWithPastAndCrossAttentions": BaseModelOutputWithPastAndCrossAttentions}
+    exec(compile(ast.Module(body=efn, type_ignores=[]), path2, "exec"), enc_ns)
+
+    seed, env_act_dim, B = 7, 3, 2
+    spec = preset("mamba_tiny")
+    sd = init_state_dict(spec, seed=seed)
+
+    class Layer:  # [3P] mamba_ssm Block (fused_add_norm off, fp32 residual) + Mamba.forward with inference_params
+        def __init__(self, idx):
+            self.idx, self.p = idx, f"encoder.layers.{idx}."
+
+        def __call__(self, hidden_states, residual=None, inference_params=None):
+            residual = hidden_states + residual if residual is not None else hidden_states
+            x = mamba_ref.rms_norm(residual, sd[self.p + "norm.weight"], spec.norm_eps)
+            cache = inference_params.key_value_memory_dict
+            if self.idx not in cache:
+                cache[self.idx] = (torch.zeros(1, spec.d_inner, spec.d_conv), torch.zeros(1, spec.d_inner, spec.d_state))
+            conv, ssm = cache[self.idx]
+            if inference_params.seqlen_offset > 0:
+                assert x.shape[1] == 1
+                o, c, s = mamba_ref.mamba_step(sd, self.p + "mixer.", x[:, 0], conv, ssm, spec.dt_rank, spec.d_state)
+                conv.copy_(c), ssm.copy_(s)
+                return o.unsqueeze(1), residual
+            c, s, outs = torch.zeros_like(conv), torch.zeros_like(ssm), []
+            for t in range(x.shape[1]):
+                o, c, s = mamba_ref.mamba_step(sd, self.p + "mixer.", x[:, t], c, s, spec.dt_rank, spec.d_state)
+                outs.append(o)
+            conv.copy_(c), ssm.copy_(s)
+            return torch.stack(outs, dim=1), residual
+
+    Enc = type("Enc", (), {"forward": enc_ns["forward"]})
+    enc = Enc()
+    enc.layers = [Layer(i) for i in range(spec.n_blocks)]
+    enc.config = SimpleNamespace(fused_add_norm=False, residual_in_fp32=True)
+    enc.norm_f = lambda r: mamba_ref.rms_norm(r, sd["encoder.norm_f.weight"], spec.norm_eps)
+    enc.norm_f.weight = sd["encoder.norm_f.weight"]
+
+    def make_policy():
+        def policy(**inputs):  # cache on: only the last timestep is embedded (online_decision_transformer_model.py:466-470)
+            x = dt_ref.embed_tokens(spec, sd, inputs["states"][:, -1], inputs["returns_to_go"][:, -1, 0],
+                                    inputs["rewards"][:, -1, 0])
+            hidden = enc.forward(inputs_embeds=x, inference_params=inputs["inference_params"]).last_hidden_state
+            act, _ = dt_ref.action_head(spec, sd, hidden[:, 1], False)
+            return SimpleNamespace(action_preds=act.view(1, 1, -1), attentions=None, cross_attentions=None)
+        return policy
+
+    g = torch.Generator().manual_seed(99)
+    steps = 7
+    ep_end = [{3}, {2, 5}]  # env e: inference_params.reset() after these steps (episode ends)
+    obs = torch.rand(steps, B, spec.state_dim, generator=g) * 2 - 1
+    rtg = 4.0 - 0.05 * torch.arange(steps).float().view(-1, 1).expand(steps, B).contiguous()
+    returned = torch.zeros(steps, B, env_act_dim)
+    for e in range(B):
+        me = SimpleNamespace(use_inference_cache=True, ddp_kwargs={}, target_return_type="predefined", use_amp=False,
+                             amp_dtype=torch.bfloat16, num_timesteps=1, log_attn_maps=False, a_sample_kwargs=None,
+                             inference_params=InferenceParams(max_seqlen=spec.max_length, max_batch_size=1))
+        policy = make_policy()
+        with torch.no_grad():
+            for t in range(steps):
+                a, _ = gap_ns["get_action_pred"](
+                    me, policy, obs[t, e].view(1, 1, -1).clone(), torch.zeros(1, 1, spec.act_dim),
+                    torch.zeros(1, 1, 1), rtg[t, e].view(1, 1, 1).clone(), torch.tensor([[t]]), torch.ones(1, 1),
+                    True, None, is_eval=True, task_id=None, env_act_dim=env_act_dim)
+                returned[t, e] = a
+                if t in ep_end[e]:
+                    me.inference_params.reset()
+    return {"preset": "mamba_tiny", "weight_seed": seed, "env_act_dim": env_act_dim, "obs": obs.tolist(),
+            "rtg": rtg.tolist(), "episode_end_after_step": [sorted(x) for x in ep_end],
+            "returned_actions": returned.tolist()}
+
+
 def main():
     sys.path.insert(0, REF)
     from src.tokenizers_custom import make_tokenizer  # reference code, executed not copied
@@ -270,6 +382,7 @@ def main():
     out["token_front_end"] = token_front_end_vectors(g)
     impala_cnn_vectors(g)
     out["agent_predict_trace"] = agent_predict_trace(g)
+    out["mamba_agent_trace"] = mamba_agent_trace()
 
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as fh:
         json.dump(out, fh)

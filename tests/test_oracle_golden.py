@@ -126,3 +126,43 @@ def test_impala_cnn_matches_the_reference_modules():
     out = dt_ref.impala_cnn(sd, "embed_image.", img.float() / 255.0)
     ref = torch.from_numpy(d["out"])
     assert out.shape == ref.shape and float((out - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def _mamba_trace_inputs(v):
+    spec = preset(v["preset"])
+    sd = init_state_dict(spec, seed=v["weight_seed"])
+    obs, rtg = torch.tensor(v["obs"]), torch.tensor(v["rtg"])
+    steps, B = obs.shape[0], obs.shape[1]
+    masks = torch.zeros(steps, B, dtype=torch.uint8)
+    masks[0] = 1
+    for e, ends in enumerate(v["episode_end_after_step"]):
+        for t in ends:
+            if t + 1 < steps:
+                masks[t + 1, e] = 1  # inference_params.reset() after step t == reset mask before step t + 1
+    return spec, sd, obs, rtg, masks, torch.tensor(v["returned_actions"])
+
+
+def test_oracle_mamba_compat_modes_follow_the_executed_reference_control_flow(ref_vectors):
+    """`mamba_agent_trace` = DiscreteDecisionMamba.get_action_pred + InferenceParams.reset() + MambaEncoder.forward
+    executed from the reference (stand-in layers around the oracle's mixer math): the oracle in
+    (mamba_repeat = env_act_dim, stale_state) mode must reproduce the returned actions; the default mode (one advance
+    per env-step, full reset) must NOT -- the two trajectories are different things."""
+    v = ref_vectors["mamba_agent_trace"]
+    spec, sd, obs, rtg, masks, want = _mamba_trace_inputs(v)
+    R = v["env_act_dim"]
+    ora = dt_ref.OraclePolicy(spec, sd, mamba_repeat=R, stale_state=True)
+    plain = dt_ref.OraclePolicy(spec, sd)
+    differs = 0
+    for t in range(obs.shape[0]):
+        a = ora.step(obs[t], rtg[t], torch.zeros(obs.shape[1]), masks[t])
+        assert torch.equal(a[:, :R], want[t]), f"step {t}: {a[:, :R]} vs {want[t]}"
+        b = plain.step(obs[t], rtg[t], torch.zeros(obs.shape[1]), masks[t])
+        differs += int((b[:, :R] != want[t]).sum())
+    assert differs > 0
+    # each quirk alone is not the reference trajectory either
+    for kw in ({"mamba_repeat": R}, {"stale_state": True}):
+        o = dt_ref.OraclePolicy(spec, sd, **kw)
+        d = 0
+        for t in range(obs.shape[0]):
+            d += int((o.step(obs[t], rtg[t], torch.zeros(obs.shape[1]), masks[t])[:, :R] != want[t]).sum())
+        assert d > 0, kw
