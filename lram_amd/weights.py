@@ -300,22 +300,63 @@ def engine_layout(spec: ModelSpec, sd: Dict[str, torch.Tensor]) -> Dict[str, tor
 def strip_prefixes(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Drop the `module.` (DDP) and `_orig_mod.` (torch.compile) prefixes the reference strips in
     load_model_weights (src/algos/decision_transformer_sb3.py:1138-1158)."""
-    out = {}
-    for k, v in sd.items():
-        changed = True
-        while changed:
-            changed = False
-            for pre in ("module.", "_orig_mod."):
-                if k.startswith(pre):
-                    k = k[len(pre):]
-                    changed = True
-        out[k] = v
+    return filter_policy_dict(sd, {"load_state_head": True})
+
+
+def filter_policy_dict(policy_dict: Dict[str, torch.Tensor], load_kwargs: Optional[dict] = None,
+                       compile: bool = False) -> Dict[str, torch.Tensor]:
+    """The key handling of the reference's `load_model_weights`
+    (src/algos/decision_transformer_sb3.py:1120-1168), in its order:
+      * the first "module." of every key is removed (DDP), keys then listed in `exclude_params` are dropped:
+        the action heads unless `load_action_head` (default True), `predict_state.*` unless `load_state_head`
+        (default False);
+      * `img_encoder_only` keeps keys containing "embed_image"; `exclude_heads` drops keys containing action_pred /
+        predict_state / predict_reward / predict_return;
+      * the first "_orig_mod." is removed when the receiving model is not compiled (it is added when the model is
+        compiled and the checkpoint was not);
+      * legacy `mu.* / log_std.*` heads are renamed to `mu.0.* / log_std.0.*`.
+    The result is what the reference hands to `policy.load_state_dict(..., strict=False)`; pinned against the executed
+    reference method by tests/golden/reference_vectors.json `load_model_weights_trace`."""
+    kw = load_kwargs if load_kwargs is not None else {}
+    exclude = []
+    if not kw.get("load_action_head", True):
+        for name in ("action_net", "action_pred", "mu", "log_std"):
+            exclude += [f"{name}.weight", f"{name}.bias", f"{name}.0.weight", f"{name}.0.bias", f"{name}.1.weight",
+                        f"{name}.1.bias"]
+    if not kw.get("load_state_head", False):
+        exclude += ["predict_state.weight", "predict_state.bias"]
+    out = {k.replace("module.", "", 1): v for k, v in policy_dict.items() if k.replace("module.", "", 1) not in exclude}
+    if kw.get("img_encoder_only", False):
+        out = {k: v for k, v in out.items() if "embed_image" in k}
+    if kw.get("exclude_heads", False):
+        for frag in ("action_pred", "predict_state", "predict_reward", "predict_return"):
+            out = {k: v for k, v in out.items() if frag not in k}
+    from_compiled = bool(out) and next(iter(out)).startswith("_orig_mod.")
+    if not compile:
+        out = {k.replace("_orig_mod.", "", 1): v for k, v in out.items()}
+    elif not from_compiled:
+        out = {f"_orig_mod.{k}": v for k, v in out.items()}
+    if "mu.weight" in out:
+        out["mu.0.weight"], out["mu.0.bias"] = out.pop("mu.weight"), out.pop("mu.bias")
+        out["log_std.0.weight"], out["log_std.0.bias"] = out.pop("log_std.weight"), out.pop("log_std.bias")
     return out
 
 
-def load_sb3_zip(path: str) -> Tuple[Dict[str, torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """Read `policy.pth` (+ `state_mean` / `state_std` from `pytorch_variables.pth`) out of an SB3 zip
-    written by the reference's save() (decision_transformer_sb3.py:1246-1280, agent_utils.py:165-202)."""
+def load_report(spec: ModelSpec, sd: Dict[str, torch.Tensor], with_image_encoder: bool = False):
+    """(missing, unexpected) against the keys the inference path reads -- what `load_state_dict(strict=False)` prints
+    in the reference (decision_transformer_sb3.py:1169-1173); heads the rollout never evaluates are not expected."""
+    lay = reference_layout(spec, with_image_encoder)
+    missing = [k for k in lay if k not in sd and k != "embed_ln.bias"]
+    unexpected = [k for k in sd if k not in lay]
+    return missing, unexpected
+
+
+def load_sb3_zip(path: str, load_kwargs: Optional[dict] = None
+                 ) -> Tuple[Dict[str, torch.Tensor], Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Read `policy.pth` (+ `state_mean` / `state_std` from `pytorch_variables.pth`) out of an SB3 zip written by the
+    reference's save() (decision_transformer_sb3.py:1246-1280, agent_utils.py:165-202: `data` json, one `<name>.pth` per
+    state dict, `pytorch_variables.pth`, `system_info.txt`) and apply load_model_weights' key handling
+    (`filter_policy_dict`).  Returns (state dict, state_mean, state_std)."""
     with zipfile.ZipFile(path) as zf:
         names = set(zf.namelist())
         if "policy.pth" not in names:
@@ -324,21 +365,28 @@ def load_sb3_zip(path: str) -> Tuple[Dict[str, torch.Tensor], Optional[torch.Ten
         mean = std = None
         if "pytorch_variables.pth" in names:
             pv = torch.load(io.BytesIO(zf.read("pytorch_variables.pth")), map_location="cpu", weights_only=False)
-            if isinstance(pv, dict):
-                mean, std = pv.get("state_mean"), pv.get("state_std")
-    return strip_prefixes(sd), mean, std
+            if isinstance(pv, dict) and "state_mean" in pv and "state_std" in pv:   # :1182-1184
+                mean, std = pv["state_mean"], pv["state_std"]
+    return filter_policy_dict(sd, load_kwargs), mean, std
 
 
-def save_sb3_zip(path: str, sd: Dict[str, torch.Tensor], state_mean=None, state_std=None, prefix: str = "") -> None:
-    """Write a minimal SB3-style zip (policy.pth + pytorch_variables.pth).  Test helper for the loader."""
+def save_sb3_zip(path: str, sd: Dict[str, torch.Tensor], state_mean=None, state_std=None, prefix: str = "",
+                 optimizer_state: Optional[dict] = None) -> None:
+    """Write an SB3-style zip with the members the reference's save() produces (agent_utils.py:165-202): `data`,
+    `pytorch_variables.pth`, `policy.pth` (+ `optimizer.pth`), `system_info.txt`.  Test helper for the loader."""
     with zipfile.ZipFile(path, "w") as zf:
-        buf = io.BytesIO()
-        torch.save({prefix + k: v for k, v in sd.items()}, buf)
-        zf.writestr("policy.pth", buf.getvalue())
+        zf.writestr("data", "{}")
         buf = io.BytesIO()
         torch.save({"state_mean": state_mean, "state_std": state_std}, buf)
         zf.writestr("pytorch_variables.pth", buf.getvalue())
-        zf.writestr("data", "{}")
+        buf = io.BytesIO()
+        torch.save({prefix + k: v for k, v in sd.items()}, buf)
+        zf.writestr("policy.pth", buf.getvalue())
+        if optimizer_state is not None:
+            buf = io.BytesIO()
+            torch.save(optimizer_state, buf)
+            zf.writestr("optimizer.pth", buf.getvalue())
+        zf.writestr("system_info.txt", "lram_amd test checkpoint")
 
 
 def check_state_dict(spec: ModelSpec, sd: Dict[str, torch.Tensor], with_image_encoder: bool = False) -> None:

@@ -345,6 +345,88 @@ def mamba_agent_trace():
             "returned_actions": returned.tolist()}
 
 
+def load_model_weights_trace():
+    """`DecisionTransformerSb3.load_model_weights` (src/algos/decision_transformer_sb3.py:1120-1184) executed on a
+    stand-in `self`, with `load_from_zip_file` (stable_baselines3, absent) replaced by a function that returns a canned
+    (data, params, variables) triple: for several `load_kwargs` / `compile` settings, which keys reach
+    `policy.load_state_dict(..., strict=False)` and whether state_mean / state_std are taken over."""
+    from types import SimpleNamespace
+    keys = ["embed_state.weight", "embed_state.bias", "embed_ln.weight", "action_net.0.weight", "action_net.0.bias",
+            "predict_state.weight", "predict_state.bias", "predict_return.weight", "predict_reward.bias",
+            "embed_image.cnn.0.conv.weight", "embed_image.linear.0.bias", "encoder.layers.blocks.0.xlstm_norm.weight",
+            "encoder.layers.blocks.1.xlstm.slstm_cell._recurrent_kernel_", "encoder.wpe.weight", "action_pred.0.weight",
+            "encoder.module.odd.weight"]
+    cases = []
+    for prefix in ("", "module.", "_orig_mod.", "module._orig_mod.", "_orig_mod.module."):
+        for load_kwargs in (None, {"load_action_head": False}, {"load_state_head": True}, {"exclude_heads": True},
+                            {"img_encoder_only": True}):
+            for compiled in (False, True):
+                for with_vars in (True, False):
+                    canned = {prefix + k: i for i, k in enumerate(keys)}
+                    variables = {"state_mean": "MEAN", "state_std": "STD"} if with_vars else {}
+                    got = {}
+
+                    def load_state_dict(d, strict=True, got=got):
+                        got["keys"], got["strict"] = list(d.keys()), strict
+                        return [], []
+
+                    ns = {"load_from_zip_file": lambda path, device=None, custom_objects=None:
+                          ({}, {"policy": dict(canned)}, dict(variables)), "print": lambda *a, **k: None}
+                    ns.update(_exec_methods(os.path.join(REF, "src/algos/decision_transformer_sb3.py"),
+                                            "DecisionTransformerSb3", ["load_model_weights"]))
+                    fn = ns["load_model_weights"]
+                    fn.__globals__.update(ns)
+                    me = SimpleNamespace(load_kwargs=load_kwargs, device="cpu", compile=compiled, state_mean=None,
+                                         state_std=None, freeze_kwargs=None,
+                                         policy=SimpleNamespace(load_state_dict=load_state_dict, num_task_heads=1,
+                                                                global_pos_embds=True))
+                    fn(me, "ckpt.zip")
+                    cases.append({"prefix": prefix, "load_kwargs": load_kwargs, "compile": compiled,
+                                  "with_variables": with_vars, "loaded_keys": got["keys"], "strict": got["strict"],
+                                  "state_mean": me.state_mean, "state_std": me.state_std})
+    return {"checkpoint_keys": keys, "cases": cases}
+
+
+def checkpoint_key_names():
+    """Names the checkpoint keys are built from, taken from code rather than recalled:
+      * `self.<name> = ...` module attributes assigned in the reference's own model classes (AST walk over the class
+        bodies: OnlineDecisionTransformerModel, DiscreteDTModel, MultiDomainDiscreteDTModel, ImpalaCNN, ImpalaCNNBlock,
+        ImpalaCNNResidual, MambaEncoder, DecisionMambaModel, xLSTMEncoder, DecisionXLSTMModel);
+      * the parameter names of transformers' DecisionTransformerModel (the HF base class the reference model derives
+        from, `embed_*` / `predict_*` / `embed_ln`), by instantiating the installed class;
+      * `make_head` executed: the action head is an nn.Sequential, hence `action_net.0.{weight,bias}`.
+    The third-party backbone sub-keys (`xlstm.*`, `mixer.*`) cannot be derived offline and stay as recalled."""
+    import ast
+    import torch.nn as nn
+    out = {}
+    files = {"src/algos/models/online_decision_transformer_model.py": ["OnlineDecisionTransformerModel"],
+             "src/algos/models/discrete_decision_transformer_model.py": ["DiscreteDTModel"],
+             "src/algos/models/multi_domain_discrete_dt_model.py": ["MultiDomainDiscreteDTModel"],
+             "src/algos/models/image_encoders.py": ["ImpalaCNN", "ImpalaCNNBlock", "ImpalaCNNResidual"],
+             "src/algos/models/decision_mamba.py": ["MambaEncoder", "DecisionMambaModel"],
+             "src/algos/models/decision_xlstm.py": ["xLSTMEncoder", "DecisionXLSTMModel"]}
+    for rel, classes in files.items():
+        tree = ast.parse(open(os.path.join(REF, rel)).read())
+        for cls in [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in classes]:
+            names = set()
+            for node in ast.walk(cls):
+                if isinstance(node, ast.Assign):
+                    for t in node.targets:
+                        if isinstance(t, ast.Attribute) and isinstance(t.value, ast.Name) and t.value.id == "self":
+                            names.add(t.attr)
+            out[cls.name] = sorted(names)
+    from transformers import DecisionTransformerConfig, DecisionTransformerModel
+    hf = DecisionTransformerModel(DecisionTransformerConfig(state_dim=4, act_dim=2, hidden_size=8, n_layer=1, n_head=1,
+                                                            max_ep_len=8))
+    out["hf_DecisionTransformerModel_params"] = sorted(k for k in hf.state_dict() if not k.startswith("encoder."))
+    ns = _exec_methods(os.path.join(REF, "src/algos/models/online_decision_transformer_model.py"),
+                       "OnlineDecisionTransformerModel", ["make_head"])
+    make_head = ns["make_head"].__func__ if isinstance(ns["make_head"], staticmethod) else ns["make_head"]
+    make_head.__globals__["nn"] = nn
+    out["make_head_params"] = sorted(make_head(8, 6, 1).state_dict())
+    return out
+
+
 def main():
     sys.path.insert(0, REF)
     from src.tokenizers_custom import make_tokenizer  # reference code, executed not copied
@@ -383,6 +465,8 @@ def main():
     impala_cnn_vectors(g)
     out["agent_predict_trace"] = agent_predict_trace(g)
     out["mamba_agent_trace"] = mamba_agent_trace()
+    out["load_model_weights_trace"] = load_model_weights_trace()
+    out["checkpoint_key_names"] = checkpoint_key_names()
 
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as fh:
         json.dump(out, fh)

@@ -102,13 +102,76 @@ def test_engine_layout_transforms():
         assert t.dtype == torch.float32 and t.is_contiguous(), name
 
 
+def _ref_vectors():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")) as fh:
+        return json.load(fh)
+
+
+def test_checkpoint_key_filter_equals_the_executed_reference_load_model_weights():
+    """100 cases (DDP / torch.compile prefixes in both orders, load_kwargs variants, compiled receiver or not) produced
+    by executing decision_transformer_sb3.py:1120-1184 (make_golden_from_reference.py::load_model_weights_trace)."""
+    from lram_amd.weights import filter_policy_dict
+    v = _ref_vectors()["load_model_weights_trace"]
+    assert len(v["cases"]) == 100
+    for case in v["cases"]:
+        canned = {case["prefix"] + k: i for i, k in enumerate(v["checkpoint_keys"])}
+        got = filter_policy_dict(canned, case["load_kwargs"], compile=case["compile"])
+        assert list(got.keys()) == case["loaded_keys"], case
+        assert case["strict"] is False
+        assert (case["state_mean"] == "MEAN") == case["with_variables"]
+
+
+def test_checkpoint_key_names_come_from_reference_code():
+    """Every non-third-party path component of the keys `reference_layout` expects is a module attribute the
+    reference's own classes assign (AST walk) or a parameter of the HF base class; the action head is a Sequential
+    (`make_head` executed) -> `action_net.0.*`."""
+    names = _ref_vectors()["checkpoint_key_names"]
+    top = set(names["OnlineDecisionTransformerModel"]) | set(names["DiscreteDTModel"]) | \
+        set(names["MultiDomainDiscreteDTModel"]) | {k.split(".")[0] for k in names["hf_DecisionTransformerModel_params"]}
+    assert names["make_head_params"] == ["0.bias", "0.weight"]
+    for spec_name, img in (("xlstm_16m", True), ("mamba_48m", False)):
+        spec = preset(spec_name)
+        for key in reference_layout(spec, with_image_encoder=img):
+            parts = key.split(".")
+            assert parts[0] in top, key
+            if parts[0] == "action_net":
+                assert parts[1] == "0" and parts[2] in ("weight", "bias")
+            if parts[0] == "embed_image":
+                assert parts[1] in names["ImpalaCNN"], key
+                if parts[1] == "cnn":
+                    assert parts[3] in names["ImpalaCNNBlock"], key
+                    if parts[3].startswith("residual_"):
+                        assert parts[4] in names["ImpalaCNNResidual"], key
+            if parts[0] == "encoder":
+                enc = names["xLSTMEncoder"] if spec.backbone == "xlstm" else names["MambaEncoder"]
+                assert parts[1] in enc, key
+    for k in ("embed_state.weight", "embed_return.bias", "embed_ln.weight"):
+        assert k in names["hf_DecisionTransformerModel_params"]
+
+
 def test_sb3_zip_roundtrip_and_prefix_strip(tmp_path):
+    import zipfile
     spec = preset("mamba_tiny")
     sd = init_state_dict(spec, seed=2)
-    sd["predict_state.weight"] = torch.zeros(3, 3)  # extra keys are ignored like strict=False upstream
+    sd["predict_state.weight"] = torch.zeros(3, 3)  # dropped: load_state_head defaults to False upstream
+    sd["predict_return.weight"] = torch.zeros(1, 3)  # extra keys are ignored like strict=False upstream
     path = str(tmp_path / "model.zip")
-    save_sb3_zip(path, sd, state_mean=torch.zeros(20), state_std=torch.ones(20), prefix="module._orig_mod.")
+    save_sb3_zip(path, sd, state_mean=torch.zeros(20), state_std=torch.ones(20), prefix="module._orig_mod.",
+                 optimizer_state={"state": {}, "param_groups": []})
+    assert set(zipfile.ZipFile(path).namelist()) == {"data", "pytorch_variables.pth", "policy.pth", "optimizer.pth",
+                                                     "system_info.txt"}   # agent_utils.py:165-202
     sd2, mean, std = load_sb3_zip(path)
+    # as upstream: the exclusion list is matched after removing "module." only, so behind a compile prefix the state
+    # head survives (and is then ignored by strict=False); from a DDP-only checkpoint it is dropped
+    assert "predict_state.weight" in sd2 and "predict_return.weight" in sd2
+    path_ddp = str(tmp_path / "model_ddp.zip")
+    save_sb3_zip(path_ddp, sd, prefix="module.")
+    sd3, mean3, _ = load_sb3_zip(path_ddp)
+    assert "predict_state.weight" not in sd3 and "predict_return.weight" in sd3 and mean3 is None
+    from lram_amd.weights import load_report
+    assert load_report(spec, sd3) == ([], ["predict_return.weight"])
     check_state_dict(spec, sd2)
     assert all(torch.equal(sd[k], sd2[k]) for k in reference_layout(spec))
     assert mean.shape == (20,) and std.shape == (20,)

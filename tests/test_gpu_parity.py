@@ -65,9 +65,10 @@ def test_gemm_bf16x3_matches_fp64(hip_lib, m, n, k):
     assert ((out2.cpu().double() - ref2).abs() / (scale + 1)).max().item() < 1.5 * e1 + 1e-7
 
 
-def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=2e-4, state_tol=2e-4, spec=None):
+def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=2e-4, state_tol=2e-4, spec=None,
+                sd=None):
     spec = preset(name) if spec is None else spec
-    sd = init_state_dict(spec, seed=seed)
+    sd = init_state_dict(spec, seed=seed) if sd is None else sd
     eng = _engine(spec, sd, B)
     if graph:
         eng.set_graph_mode(True)
