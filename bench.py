@@ -5,15 +5,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic env inputs: B env slots per GPU each
-advance one timestep (embed (s, rtg, r) -> 3 recurrent token steps through the block stack -> action head
--> argmax -> de-tokenise), plus, for N > 1, the all-gather of the action tensor (RCCL).  Inputs (observations,
-returns-to-go, reset masks for every step) are resident in HBM before the timed region starts.
-Workload = BASELINE.json's metric configuration: xLSTM[7:1] 16M, batch 4096 env slots per GPU (weak scaling).
+A "step" is one pass of the hot path over one batch of synthetic env inputs: B env slots per GPU each advance one
+timestep (embed (s, rtg, r) -> 3 recurrent token steps through the block stack -> action head -> argmax ->
+de-tokenise), plus, for N > 1, the all-gather of the action tensor (RCCL).  Workload = BASELINE.json's metric
+configuration: xLSTM[7:1] 16M, batch 4096 env slots per GPU (weak scaling).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = mLSTM
-cell update, HIP-event timed on its own stream inside the timed region) and `cpu_baseline` (the CPU oracle
-timed on the host cores on a bounded sample; rank 0, N = 1 only).
+`value`: inputs (observations, returns-to-go, reset masks for every step) are resident in HBM before the timed region
+starts; K steps are enqueued back to back between barrier + synchronize on both sides; max over ranks.
+`host_io` (extra object, rank 0's GPU): SURVEY.md 8d's host-inclusive variant of the same step, measured in the same
+run -- observations / returns-to-go / masks in pinned host memory, H2D copies, lram_step, D2H of the actions, host
+synchronisation EVERY step (so launch ramp and PCIe are inside the time).  It is reported beside `value`, never as it.
+
+`roofline` (dominant kernel = the mLSTM state pass, HIP-event timed on the stream it is launched on, inside the timed
+region): `achieved` = the bytes that kernel's algorithm has to move per launch / its average
+launch time, so `frac` <= 1 is HBM utilisation.  In the lazy matrix-memory mode the algorithm moves fewer bytes than
+SURVEY 8d's materialised read+write figure; the 8d-equivalent rate is reported apart as `effective_8d_GBps`.
+`traffic` = HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/, `traffic_source`), never measured
+in this process.  `cpu_baseline`: the CPU oracle timed on the host cores on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -28,64 +36,89 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s float4 copy measured)
+LAZY_PERIOD = 13        # engine default fold period (lram_set_state_mode)
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cell_kernel_algorithmic_bytes(spec, B, T):
-    """Algorithmic bytes of ONE mLSTM cell-update launch (one layer, B envs, T tokens): matrix memory C read
-    once + written once, q/k/v vectors read, h written, gate scalars read.  (DESIGN.md 'Kernels')"""
-    per_env = 2 * spec.n_heads * spec.head_dim ** 2 * 4 + T * 4 * spec.inner * 4 + T * spec.n_heads * 16
-    return per_env * B
+# ---- algorithmic bytes of the dominant kernel (per env slot, per launch = one block, T tokens) ------------------
+def cell_bytes_materialised(spec, T):
+    """mlstm_cell_kernel: matrix memory C read once + written once, q/k/v read, h written, gate scalars read.
+    This is SURVEY.md 8d's per-block state term."""
+    return 2 * spec.n_heads * spec.head_dim ** 2 * 4 + T * 4 * spec.inner * 4 + T * spec.n_heads * 16
 
 
-def ssm_kernel_algorithmic_bytes(spec, B, T):
-    per_env = 2 * spec.d_inner * spec.d_state * 4 + T * (4 * spec.d_inner + 2 * spec.d_state) * 4
-    return per_env * B
+def cell_bytes_lazy(spec, T, period=LAZY_PERIOD):
+    """Lazy state pass = mlstm_lazy_cell_kernel + its share of mlstm_lazy_fold_kernel:
+    C_base read once; the pending window's V rows (steady-state mean T (period - 1) / 2 tokens); q, v read, h written,
+    the step's khat / v rows appended; score rows; plus 1/period of a fold (C_base read + written, the whole window's
+    khat and v rows read)."""
+    nh, dh, inner = spec.n_heads, spec.head_dim, spec.inner
+    c = nh * dh * dh * 4
+    mean_pending = T * (period - 1) / 2.0
+    read_pass = c + mean_pending * inner * 4 + 3 * T * inner * 4 + 2 * T * inner * 4 + T * nh * 64 * 4
+    fold = 2 * c + 2 * T * period * inner * 4
+    return read_pass + fold / period
 
 
-def cpu_baseline(spec, sd, seconds_budget=20.0):
-    """The oracle (oracle/dt_ref.py, the parity checker) timed on the host cores: `kind: port`."""
+def ssm_bytes(spec, T):
+    return 2 * spec.d_inner * spec.d_state * 4 + T * (4 * spec.d_inner + 2 * spec.d_state) * 4
+
+
+# ---- CPU baseline ------------------------------------------------------------------------------------------
+def cpu_baseline(spec, sd, seconds_budget=22.0):
+    """The oracle (oracle/dt_ref.py, the parity checker) timed on the host cores: `kind: port`.  SURVEY 8d asks for the
+    config batch with 8 + 32 steps; at the oracle's rate that is most of an hour for 4096 envs, so the sample is bounded
+    (task statement: 10-30 s of CPU work): throughput at B = 256 over as many timesteps as fit the budget, plus the
+    B = 1 per-step latency (the reference's real operating point, src/callbacks/evaluation.py:80)."""
     from oracle.dt_ref import OraclePolicy
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    B = 64
-    g = torch.Generator().manual_seed(1234)
-    obs = torch.rand(B, spec.state_dim, generator=g) * 2 - 1
-    rtg = torch.full((B,), 4.5)
-    rew = torch.zeros(B)
 
-    def timed_steps(nthreads, max_s, max_n):
+    def inputs(B):
+        g = torch.Generator().manual_seed(1234)
+        return torch.rand(B, spec.state_dim, generator=g) * 2 - 1, torch.full((B,), 4.5), torch.zeros(B)
+
+    def timed_steps(B, nthreads, max_s, max_n, warm=1):
         torch.set_num_threads(nthreads)
+        obs, rtg, rew = inputs(B)
         ora = OraclePolicy(spec, sd)
-        ora.step(obs, rtg, rew)  # warm-up (allocations, thread pool)
+        for _ in range(warm):
+            ora.step(obs, rtg, rew)
         t0, n = time.time(), 0
         while n < max_n and (n == 0 or time.time() - t0 < max_s):
             ora.step(obs, rtg, rew)
             n += 1
         return n, time.time() - t0
 
-    # PyTorch-eager on many small ops does not scale to every core of a big host: calibrate the thread
-    # count on one timestep each (smallest first, stop when it gets slower), then time with the best.
+    # PyTorch-eager on many small ops does not scale to every core of a big host: calibrate the thread count on one
+    # timestep each (smallest first, stop when it gets slower), then time with the best.
     best_thr, best_t = None, None
     for thr in sorted({min(avail, c) for c in (8, 32, 128)}):
-        n, w = timed_steps(thr, 0.0, 1)
+        n, w = timed_steps(64, thr, 0.0, 1)
         if best_t is None or w < best_t:
             best_thr, best_t = thr, w
         elif w > 1.5 * best_t:
             break
-    n, wall = timed_steps(best_thr, seconds_budget, 64)
+    B = 256
+    n, wall = timed_steps(B, best_thr, seconds_budget - 6.0, 32)
+    n1, wall1 = timed_steps(1, min(best_thr, 8), 3.0, 32, warm=3)
     return {"value": B * n / wall, "unit": "env-steps/s", "cores": best_thr, "kind": "port",
             "sample": f"CPU oracle (PyTorch-eager fp32 restatement of the same path), same model and weights, "
                       f"B={B} envs x {n} timesteps after 1 warm-up, {wall:.1f} s wall, {best_thr} torch threads "
-                      f"(fastest of a 8/32/128 calibration; host exposes {avail} cores)"}
+                      f"(fastest of a 8/32/128 calibration at B=64; host exposes {avail} cores); SURVEY 8d's 8+32 steps "
+                      f"at the config batch would take ~{(8 + 32) * 4096 / max(B * n / wall, 1e-9) / 60:.0f} min, hence "
+                      f"the bounded sample",
+            "b1_latency_ms": wall1 / n1 * 1e3,
+            "b1_sample": f"B=1, {n1} timesteps after 3 warm-up, {min(best_thr, 8)} threads"}
 
 
-def main():
+# ---- the run ------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -103,32 +136,68 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph")
     ap.add_argument("--micro", type=int, default=0, help="env slices pipelined on separate streams (0 = auto, 1 = off)")
     ap.add_argument("--side-stream", action="store_true", help="issue the steps on a non-default HIP stream")
+    ap.add_argument("--mamba-compat", action="store_true",
+                    help="Mamba: the reference agent's trajectory (one forward per action dim, layer-0-only resets; "
+                         "lram_set_compat_mode) instead of one state advance per env-step")
+    ap.add_argument("--env-act-dim", type=int, default=0, help="action dims the env uses (compat forwards per step)")
+    ap.add_argument("--host-io-steps", type=int, default=16, help="steps of the host-inclusive leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-stream-ceilings", action="store_true")
+    return ap.parse_args(argv)
 
-    from lram_amd import build, dist as ldist, init_state_dict, preset
-    from lram_amd.engine import Engine, stream_copy, stream_rmw
 
-    if not torch.cuda.is_available():
+def timed_region(step_fn, first, K, sync, ldist, dev):
+    """EXACTLY K steps bracketed by barrier + device synchronize on both sides; max over ranks.  Returns
+    (wall seconds, last step's output)."""
+    ldist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for t in range(first, first + K):
+        last = step_fn(t)
+    sync()
+    ldist.barrier()
+    wall = time.perf_counter() - t0
+    return ldist.max_over_ranks(wall, dev), last
+
+
+def main(argv=None, engine_factory=None, device=None):
+    """engine_factory / device: test hooks (tests/test_dist_rollout.py drives this function on CPU over gloo with a
+    stand-in engine so that the N > 1 code path -- shard, step, all-gather, max over ranks -- is executed without GPUs)."""
+    args = parse_args(argv)
+    from lram_amd import dist as ldist, init_state_dict, preset
+    stub = engine_factory is not None
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the engine has no CPU fallback")
-    rank, world, local_rank = ldist.init_distributed()
+    rank, world, local_rank = ldist.init_distributed("gloo" if stub else None)
     if world != args.gpus:
         log(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if rank == 0:
-        build.build(force=False, verbose=False)
+    if stub:
+        dev = torch.device("cpu") if device is None else torch.device(device)
+    else:
+        from lram_amd import build
+        from lram_amd.engine import Engine
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if rank == 0:
+            build.build(force=False, verbose=False)
     ldist.barrier()
+    on_gpu = dev.type == "cuda"
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     spec = preset(args.config)
-    sd = init_state_dict(spec, seed=0, with_image_encoder=args.obs == "image")
+    sd = init_state_dict(spec, seed=0, with_image_encoder=args.obs == "image") if not stub else None
     B, T, K, W = args.batch, spec.tokens_per_step, args.steps, args.warmup
     if args.global_batch > 0:
         lo, hi = ldist.shard_bounds(args.global_batch, rank, world)
         B = hi - lo
-    eng = Engine(spec, sd, B, device=dev)
-    if spec.backbone == "xlstm" and (args.state != "auto" or "LRAM_STATE" not in os.environ):
+    global_batch = args.global_batch if args.global_batch > 0 else B * world
+    eng = engine_factory(spec, B, dev) if stub else Engine(spec, sd, B, device=dev)
+    if not stub and spec.backbone == "xlstm" and (args.state != "auto" or "LRAM_STATE" not in os.environ):
         try:
             eng.set_state_mode(args.state)
         except Exception:
@@ -138,6 +207,10 @@ def main():
         eng.set_graph_mode(True)
     eng.set_micro_batches(args.micro)
     state_mode = eng.state_mode
+    compat = {"mamba_repeat": 1, "stale_state": False}
+    if args.mamba_compat:
+        eng.set_compat_mode(args.env_act_dim if args.env_act_dim > 0 else spec.act_dim, True)
+        compat = eng.compat_mode
 
     # ---- synthetic inputs, all resident in HBM before timing (DummyEnv-style) ----------
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -149,14 +222,14 @@ def main():
     ep_len, rtg0, scale = 1000, 451.274 / 100.0, 100.0  # cheetah-run target / reward_scale
     phase = torch.arange(B, device=dev) % ep_len
     n_prime = 16  # untimed priming steps in lazy state mode (see below); the schedule covers them either way
-    steps_total = n_prime + K + W + 16  # + the standalone kernel measurement that follows the timed region
+    steps_total = n_prime + K + W + 16 + args.host_io_steps + 8
     tt = torch.arange(steps_total, device=dev).view(-1, 1)
     age = (phase.view(1, -1) + tt) % ep_len                       # steps since that env's last reset
     masks = (age == 0).to(torch.uint8).contiguous()
     masks[0] = 1                                                  # every env starts an episode
     rtgs = (rtg0 - age.float() * (1.0 / scale)).contiguous()     # env reward 1 per step
     reward_tok = torch.zeros(B, device=dev)                       # reward token is 0 in the reference loop (Q3)
-    torch.cuda.synchronize()
+    sync()
 
     img_ring = None
     if args.obs == "image":
@@ -165,9 +238,13 @@ def main():
 
     clock = [0]  # global timestep: the episode schedule (resets, returns-to-go) runs on without repeating step 0
 
-    def one_step(_t=None):
+    def next_t():
         t = clock[0] if clock[0] < steps_total else 1 + (clock[0] - 1) % (steps_total - 1)
         clock[0] += 1
+        return t
+
+    def one_step(_t=None):
+        t = next_t()
         if img_ring is not None:
             eng.embed_images(img_ring[t % n_ring], emb)
             a, _ = eng.step(emb, rtgs[t], reward_tok, masks[t], discrete=True, obs_is_embedding=True)
@@ -177,7 +254,7 @@ def main():
             a = ldist.all_gather_actions(a, args.global_batch if args.global_batch > 0 else None)
         return a
 
-    if args.side_stream:
+    if args.side_stream and on_gpu:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         torch.cuda.set_stream(side)
@@ -185,122 +262,178 @@ def main():
         # Untimed priming, not part of the W warm-up steps: every env starts with an empty matrix memory, and until an
         # env's first fold (at most one fold period, 13 steps) the read pass has nothing to read.  The timed region
         # must see the steady state, whatever W the caller picks.
-        for t in range(16):
+        for t in range(n_prime):
             one_step(t)
     for t in range(W):
         one_step(t)
-    timing = not args.no_kernel_timing and not args.graph
-    ldist.barrier()
-    torch.cuda.synchronize()
+    timing = not args.no_kernel_timing and not args.graph and not stub
     if timing:
+        sync()
         eng.profile_begin()
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        last = one_step(t)
-    torch.cuda.synchronize()
-    ldist.barrier()
-    wall = time.perf_counter() - t0
-    kern_ms, kern_n = eng.profile_end() if timing else (0.0, 0)
-    wall = ldist.max_over_ranks(wall, dev)
-
-    total_env_steps = (args.global_batch if args.global_batch > 0 else B * world) * K
-    value = total_env_steps / wall
-
-    # ---- roofline of the dominant kernel -----------------------------------------------------------
-    if spec.backbone == "xlstm":
-        kname, abytes = "mlstm_cell_kernel", cell_kernel_algorithmic_bytes(spec, B, T)
-        if state_mode == "lazy":
-            kname = "mlstm_lazy_cell_kernel (+ its share of mlstm_lazy_fold_kernel)"
+    wall, last = timed_region(one_step, W, K, sync, ldist, dev)
+    if timing:
+        kern_ms, kern_n, fold_ms, fold_n = eng.profile_end_split()
     else:
-        kname, abytes = "mamba_ssm_kernel", ssm_kernel_algorithmic_bytes(spec, B, T)
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": None, "traffic": None, "algorithmic_bytes_per_launch": abytes}
-    n_rec_blocks = (spec.n_blocks - len(spec.slstm_at)) if spec.backbone == "xlstm" else spec.n_blocks
-    if kern_n > 0:
-        # with the micro-batch pipeline one launch covers one env slice: bytes per launch follow from the
-        # number of launches actually timed (launches x slice == mLSTM blocks x B per step)
-        launches_per_step = kern_n / K
-        abytes = abytes * n_rec_blocks / launches_per_step
-        roofline["algorithmic_bytes_per_launch"] = abytes
-        roofline["launches_per_step"] = launches_per_step
-        avg_ms = kern_ms / kern_n
-        ach = abytes / (avg_ms * 1e-3) / 1e9
-        roofline.update(achieved=ach, frac=ach / HBM_PEAK_GBPS, avg_launch_ms=avg_ms, launches_timed=kern_n,
-                        kernel_share_of_step=kern_ms / (wall * 1e3))
-    if state_mode == "lazy":
-        roofline["note"] = ("lazy matrix memory: `achieved` prices the materialised algorithm's bytes (state read once + "
-                            "written once per env-step, SURVEY 8d) against the measured time of one read pass plus its share "
-                            "of the fold launches; the kernels move fewer bytes than that (`traffic`): C_base is read once "
-                            "per step and rewritten once per 13 steps")
-    if timing and spec.backbone == "xlstm" and args.micro != 1:
-        # the same kernel with the chip to itself (no overlapping slice): 8 extra, untimed-for-`value` steps
-        eng.set_micro_batches(1)
-        one_step(W)
-        torch.cuda.synchronize()
-        eng.profile_begin()
-        for t in range(W, W + 8):
-            one_step(t)
-        torch.cuda.synchronize()
-        ms1, n1 = eng.profile_end()
-        full = cell_kernel_algorithmic_bytes(spec, B, T)
-        roofline["standalone"] = {"avg_launch_ms": ms1 / n1, "achieved": full / (ms1 / n1 * 1e-3) / 1e9,
-                                  "frac": full / (ms1 / n1 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                  "algorithmic_bytes_per_launch": full,
-                                  "note": "micro-batch pipeline off: one launch per block over all env slots"}
-        eng.set_micro_batches(args.micro)
-    pmc_file = os.path.join(ROOT, "profiles", "r01_cell_kernel_hbm_traffic%s.json" % ("_lazy" if state_mode == "lazy" else ""))
-    if os.path.exists(pmc_file):  # PMC bytes per launch come from a separate rocprofv3 --pmc pass (profiles/)
-        try:
-            with open(pmc_file) as fh:
-                pm = json.load(fh)
-            if pm.get("config") == args.config and pm.get("batch") == B and "hbm_bytes_per_env_per_launch" in pm:
-                envs_per_launch = B * n_rec_blocks / roofline.get("launches_per_step", n_rec_blocks)
-                roofline["traffic"] = pm["hbm_bytes_per_env_per_launch"] * envs_per_launch
-        except Exception:
-            pass
-
-    # STREAM-like copy on this box, for context (not the roofline peak)
-    n_copy = 256 * 1024 * 1024
-    src = torch.empty(n_copy, device=dev)
-    dst = torch.empty(n_copy, device=dev)
-    stream_copy(dst, src)
-    torch.cuda.synchronize()
-    c0 = time.perf_counter()
-    for _ in range(5):
-        stream_copy(dst, src)
-    torch.cuda.synchronize()
-    copy_gbps = 5 * 2 * n_copy * 4 / (time.perf_counter() - c0) / 1e9
-    # the same bytes as an in-place read-modify-write with the cell kernel's access pattern (no arithmetic)
-    stream_rmw(src)
-    torch.cuda.synchronize()
-    c0 = time.perf_counter()
-    for _ in range(5):
-        stream_rmw(src)
-    torch.cuda.synchronize()
-    rmw_gbps = 5 * 2 * n_copy * 4 / (time.perf_counter() - c0) / 1e9
-    del src, dst
+        kern_ms, kern_n, fold_ms, fold_n = 0.0, 0, 0.0, 0
+    value = global_batch * K / wall
 
     out = {
         "metric": "env-steps/sec (action-inference)", "value": value, "unit": "env-steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3, "higher_is_better": True,
         "scaling": "strong" if args.global_batch > 0 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: xLSTM[7:1] 16M rollout, {B} env slots per GPU, 3 tokens/timestep, "
-                               "cheetah-run-shaped obs (17 of 204 dims), continuous 8x274 head"
-                   if args.config == "xlstm_16m" and args.obs == "state"
-                   else f"{args.config}, {B} env slots per GPU, {args.obs} observations",
-                   "batch_per_gpu": B, "global_batch": args.global_batch if args.global_batch > 0 else B * world, "tokens_per_step": T,
+        "config": {"workload": (f"{args.config}: xLSTM[7:1] 16M rollout, {B} env slots per GPU, 3 tokens/timestep, "
+                                "cheetah-run-shaped obs (17 of 204 dims), continuous 8x274 head; fp32 state and "
+                                "accumulation, dense projections as fp32-accurate 3-way bf16-split products on the bf16 "
+                                "matrix cores (bf16x3)"
+                                if args.config == "xlstm_16m" and args.obs == "state"
+                                else f"{args.config}, {B} env slots per GPU, {args.obs} observations; fp32 state, "
+                                     "bf16x3 projections"),
+                   "batch_per_gpu": B, "global_batch": global_batch, "tokens_per_step": T,
                    "state_bytes_per_env": spec.state_bytes_per_env(), "parallelism": f"env-shard x{world}",
-                   "graph": bool(args.graph), "micro_batches": args.micro, "state_mode": state_mode},
-        "roofline": roofline,
-        "hbm_copy_measured_GBps": copy_gbps,
-        "hbm_rmw_measured_GBps": rmw_gbps,
-        "algorithmic_bytes_per_env_step": 2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim,
+                   "graph": bool(args.graph), "micro_batches": args.micro, "state_mode": state_mode,
+                   "trajectory_mode": ("reference Mamba agent: %d forwards per env-step, layer-0-only resets"
+                                       % compat["mamba_repeat"]) if args.mamba_compat else
+                                      "one state advance per env-step, full reset"},
+        "inputs": "resident in HBM before the timed region (obs ring, per-step rtg and reset masks)",
     }
-    if roofline.get("achieved"):
-        roofline["frac_of_rmw_stream"] = roofline["achieved"] / rmw_gbps
-        if "standalone" in roofline:
-            roofline["standalone"]["frac_of_rmw_stream"] = roofline["standalone"]["achieved"] / rmw_gbps
-    out["whole_step_algorithmic_GBps"] = out["algorithmic_bytes_per_env_step"] * value / world / 1e9
+    if stub:
+        out["last_actions"] = last
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return out
+
+    # ---- host-inclusive leg: pinned host -> H2D -> step -> D2H -> host sync, every step ------
+    if args.host_io_steps > 0 and img_ring is None:
+        n_h = args.host_io_steps
+        h_obs = obs_ring.cpu().pin_memory()
+        t_base = clock[0]
+        h_rtg = rtgs.cpu().pin_memory()
+        h_mask = masks.cpu().pin_memory()
+        d_obs, d_rtg = torch.empty(B, spec.state_dim, device=dev), torch.empty(B, device=dev)
+        d_mask = torch.empty(B, dtype=torch.uint8, device=dev)
+        h_act = torch.empty(global_batch, spec.act_dim).pin_memory()   # every rank receives the gathered actions
+
+        def host_step(_t=None):
+            t = next_t()
+            d_obs.copy_(h_obs[t % n_ring], non_blocking=True)
+            d_rtg.copy_(h_rtg[t], non_blocking=True)
+            d_mask.copy_(h_mask[t], non_blocking=True)
+            a, _ = eng.step(d_obs, d_rtg, reward_tok, d_mask)
+            if world > 1:
+                a = ldist.all_gather_actions(a, args.global_batch if args.global_batch > 0 else None)
+            h_act.copy_(a, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()   # the caller needs the actions before it can step its envs
+            return h_act
+
+        for _ in range(2):
+            host_step()
+        wall_h, _ = timed_region(host_step, 0, n_h, sync, ldist, dev)
+        out["host_io"] = {"value": global_batch * n_h / wall_h, "unit": "env-steps/s", "ms_per_step": wall_h / n_h * 1e3,
+                          "steps": n_h,
+                          "bytes_h2d_per_step": B * (spec.state_dim * 4 + 4 + 1), "bytes_d2h_per_step": B * spec.act_dim * 4,
+                          "note": "SURVEY 8d's host-inclusive step: obs / rtg / reset mask in pinned host memory -> H2D -> "
+                                  "lram_step -> D2H of the actions -> host synchronisation after every step; measured after "
+                                  "the timed region of `value`, same engine and schedule (started at step %d)" % t_base}
+
+    # ---- roofline of the dominant kernel -----------------------------------------------------------
+    n_rec_blocks = (spec.n_blocks - len(spec.slstm_at)) if spec.backbone == "xlstm" else spec.n_blocks
+    lazy = state_mode == "lazy"
+    if spec.backbone == "xlstm":
+        kname = "mlstm_lazy_cell_kernel + its share of mlstm_lazy_fold_kernel" if lazy else "mlstm_cell_kernel"
+        per_env = cell_bytes_lazy(spec, T) if lazy else cell_bytes_materialised(spec, T)
+        per_env_8d = cell_bytes_materialised(spec, T)
+    else:
+        kname, per_env = "mamba_ssm_kernel", ssm_bytes(spec, T)
+        per_env_8d = per_env
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": None, "traffic": None, "traffic_source": None,
+                "algorithmic_bytes_per_env_per_launch": per_env}
+
+    def fill(r, main_ms, n_main, aux_ms, n_aux, steps, envs_total):
+        """One state pass = one launch of the dominant kernel over `envs_per_launch` env slots (one block); the lazy
+        mode's fold launches (own stream, one per block over all slots) are shared out over the state-pass launches."""
+        launches_per_step = n_main / steps
+        envs_per_launch = envs_total * n_rec_blocks / launches_per_step
+        avg_main = main_ms / n_main
+        avg = avg_main + (aux_ms / n_main if n_aux else 0.0)
+        ab = per_env * envs_per_launch
+        r.update(algorithmic_bytes_per_launch=ab, envs_per_launch=envs_per_launch, launches_per_step=launches_per_step,
+                 avg_launch_ms=avg, launches_timed=n_main, achieved=ab / (avg * 1e-3) / 1e9)
+        r["frac"] = r["achieved"] / HBM_PEAK_GBPS
+        if n_aux:
+            r["state_pass_avg_ms"] = avg_main
+            r["fold_avg_ms"] = aux_ms / n_aux
+            r["fold_launches_timed"] = n_aux
+        if lazy:
+            r["effective_8d_GBps"] = per_env_8d * envs_per_launch / (avg * 1e-3) / 1e9
+        return r
+
+    if kern_n > 0:
+        fill(roofline, kern_ms, kern_n, fold_ms, fold_n, K, B)
+        roofline["kernel_share_of_step"] = (kern_ms + fold_ms) / (wall * 1e3)
+    if lazy:
+        roofline["note"] = ("lazy matrix memory: `achieved` / `frac` price the bytes the lazy state pass has to move (C_base "
+                            "read once, window rows, q / v / h, 1/13 of a fold's read + write of C_base) against the measured "
+                            "time of one read pass plus its share of the fold launches; `effective_8d_GBps` prices SURVEY 8d's "
+                            "materialised read + write of C against the same time and is not a bandwidth")
+    if timing and spec.backbone == "xlstm" and args.micro != 1:
+        # the same kernel with the chip to itself (no overlapping slice): 8 extra, untimed-for-`value` steps
+        eng.set_micro_batches(1)
+        one_step()
+        sync()
+        eng.profile_begin()
+        for _ in range(8):
+            one_step()
+        sync()
+        roofline["standalone"] = fill({"note": "micro-batch pipeline off: one launch per block over all env slots"},
+                                      *eng.profile_end_split(), 8, B)
+        eng.set_micro_batches(args.micro)
+    # HBM bytes per launch come from a separate rocprofv3 --pmc pass (scripts/pmc_pass.sh -> profiles/): a constant
+    # read from a committed file, labelled as such
+    for rnd in ("r02", "r01"):
+        pmc_file = os.path.join(ROOT, "profiles", "%s_cell_kernel_hbm_traffic%s.json" % (rnd, "_lazy" if lazy else ""))
+        if not os.path.exists(pmc_file):
+            continue
+        try:
+            with open(pmc_file) as fh:
+                pm = json.load(fh)
+            if pm.get("config") == args.config and pm.get("batch") == B and "hbm_bytes_per_env_per_launch" in pm \
+                    and roofline.get("envs_per_launch"):
+                roofline["traffic"] = pm["hbm_bytes_per_env_per_launch"] * roofline["envs_per_launch"]
+                roofline["traffic_source"] = ("%s (separate rocprofv3 --pmc pass of the same command, FETCH_SIZE x2 + "
+                                              "WRITE_SIZE per MI355X_MICROARCH.md; not measured in this process)"
+                                              % os.path.relpath(pmc_file, ROOT))
+                if roofline.get("avg_launch_ms"):
+                    roofline["traffic_GBps"] = roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
+                break
+        except Exception:
+            pass
+    out["roofline"] = roofline
+
+    # STREAM-like ceilings on this box, for context (not the roofline peak)
+    if not args.no_stream_ceilings:
+        from lram_amd.engine import stream_copy, stream_rmw
+        n_copy = 256 * 1024 * 1024
+        src = torch.empty(n_copy, device=dev)
+        dst = torch.empty(n_copy, device=dev)
+
+        def rate(fn):
+            fn()
+            sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            sync()
+            return 5 * 2 * n_copy * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+        out["hbm_copy_measured_GBps"] = rate(lambda: stream_copy(dst, src))
+        # the same bytes as an in-place read-modify-write with the cell kernel's access pattern (no arithmetic)
+        out["hbm_rmw_measured_GBps"] = rate(lambda: stream_rmw(src))
+        del src, dst
+    out["algorithmic_bytes_per_env_step"] = 2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim
+    out["whole_step_8d_GBps"] = out["algorithmic_bytes_per_env_step"] * value / world / 1e9
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         eng.close()
         torch.cuda.empty_cache()
@@ -309,6 +442,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

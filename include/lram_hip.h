@@ -209,6 +209,9 @@ int32_t lram_get_compat_mode(const lram_engine* e, int32_t* mamba_repeat, int32_
  * lram_profile_end synchronises and returns total milliseconds and number of launches timed. */
 int32_t lram_profile_begin(lram_engine* e);
 int32_t lram_profile_end(lram_engine* e, double* total_ms, int64_t* n_launches);
+/* The same, with the lazy mode's fold launches (timed on their own stream) reported apart from the state-pass
+ * launches, so that each figure can be held against the per-kernel averages of a rocprofv3 --kernel-trace run. */
+int32_t lram_profile_end_split(lram_engine* e, double* main_ms, int64_t* n_main, double* aux_ms, int64_t* n_aux);
 
 /* Standalone kernel entry points used by tests and micro-benchmarks. */
 /* C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) (+ residual C_in)   fp32, MFMA 32x32x2 f32 (exact k-ordered fma chain) */

@@ -185,7 +185,7 @@ class RecurrentAgent:
         rew = self._zero_reward if rewards is None else rewards.to(self.device, torch.float32).reshape(-1).contiguous()
         if reset_mask is not None:
             reset_mask = reset_mask.to(self.device, torch.uint8).contiguous()
-        if self.compat_mamba_repeat:
+        if getattr(self, "compat_mamba_repeat", False):
             # one forward per action dim of the env (decision_mamba.py:107: env_act_dim, else the padded action width)
             rep = 1 if self.is_discrete else int(self.spec.act_dim if env_act_dim is None else env_act_dim)
             if rep != self._compat_repeat_now:

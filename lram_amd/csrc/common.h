@@ -8,6 +8,17 @@
 
 namespace lram {
 
+// True the first time a call site sees the current HIP device: per-device one-time setup such as raising a kernel's
+// dynamic-LDS limit (hipFuncSetAttribute applies to the current device only).  `mask` is the call site's static.
+inline bool first_use_on_device(uint64_t& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 struct Error : std::runtime_error {
   using std::runtime_error::runtime_error;
 };

@@ -237,6 +237,14 @@ void validate_config(const lram_config& c) {
     LRAM_REQUIRE(c.n_heads > 0 && c.inner > 0 && c.inner % (c.n_heads * 64) == 0,
                  "xLSTM inner dim must be a multiple of 64 * n_heads");
     LRAM_REQUIRE(c.d_model % (4 * c.n_heads) == 0, "d_model must be a multiple of 4 * n_heads");
+    // limits of the step kernels (xlstm_kernels.hip: kMaxGroups, kGnMaxV, the NH template instances), checked here so
+    // that lram_create fails up front instead of a launch throwing in the middle of a step.  Of the reference's
+    // configs/agent_params/huggingface/xlstm_*.yaml this excludes xlstm_medium_half (head dim 352), xlstm_large_half
+    // (720: not multiples of 64) and xlstm_huge_half (inner 3584, head dim 896); see DESIGN.md section 8.
+    LRAM_REQUIRE(c.n_heads == 1 || c.n_heads == 2 || c.n_heads == 4 || c.n_heads == 8, "xLSTM num_heads must be 1, 2, 4 or 8");
+    LRAM_REQUIRE(c.inner <= 3072, "xLSTM inner dim (proj_factor * embedding_dim, rounded up to 64) must be <= 3072");
+    LRAM_REQUIRE(c.inner / c.n_heads <= 768, "mLSTM head dim must be <= 768");
+    LRAM_REQUIRE(c.d_model / c.n_heads <= 768, "sLSTM head dim must be <= 768");
     LRAM_REQUIRE(c.conv_k == 4, "conv1d_kernel_size must be 4");
     LRAM_REQUIRE(c.qkv_blocksize == 4, "qkv_proj_blocksize must be 4");
     bool any_s = false;
@@ -1400,6 +1408,9 @@ int32_t lram_set_graph_mode(lram_engine* e, int32_t enable) {
     LRAM_REQUIRE(e != nullptr, "lram_set_graph_mode: null engine");
     if (enable != 0 && e->lazy_ready) {  // graph replay bakes kernel arguments: it runs on the materialised state
       LRAM_HIP_CHECK(hipSetDevice(e->device));
+      // steps may still be in flight on a non-blocking caller stream, which the null stream does not order against:
+      // drain the device before the folds touch the windows and C
+      LRAM_HIP_CHECK(hipDeviceSynchronize());
       lazy_materialize(e, nullptr);
       LRAM_HIP_CHECK(hipDeviceSynchronize());
     }
@@ -1418,6 +1429,7 @@ int32_t lram_set_state_mode(lram_engine* e, int32_t mode, int32_t fold_period) {
                  "lram_set_state_mode: lazy matrix memory needs an xLSTM head dim that is a multiple of 128");
     LRAM_HIP_CHECK(hipSetDevice(e->device));
     if (e->lazy_ready) {  // leave the current mode with a materialised state
+      LRAM_HIP_CHECK(hipDeviceSynchronize());  // pending steps on non-blocking streams first (see lram_set_graph_mode)
       lazy_materialize(e, nullptr);
       LRAM_HIP_CHECK(hipDeviceSynchronize());
     }
@@ -1481,6 +1493,29 @@ int32_t lram_profile_end(lram_engine* e, double* total_ms, int64_t* n_launches) 
     }
     *total_ms = tot;
     *n_launches = (int64_t)(e->prof_used - n_aux);
+    e->prof_on = false;
+    e->prof_used = 0;
+  });
+}
+
+int32_t lram_profile_end_split(lram_engine* e, double* main_ms, int64_t* n_main, double* aux_ms, int64_t* n_aux) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && main_ms && n_main && aux_ms && n_aux, "lram_profile_end_split: bad argument");
+    double tm = 0.0, ta = 0.0;
+    int64_t nm = 0, na = 0;
+    for (size_t i = 0; i < e->prof_used; ++i) {
+      LRAM_HIP_CHECK(hipEventSynchronize(e->prof_events[i].second));
+      float ms = 0.f;
+      LRAM_HIP_CHECK(hipEventElapsedTime(&ms, e->prof_events[i].first, e->prof_events[i].second));
+      if (e->prof_aux[i]) {
+        ta += ms;
+        ++na;
+      } else {
+        tm += ms;
+        ++nm;
+      }
+    }
+    *main_ms = tm, *n_main = nm, *aux_ms = ta, *n_aux = na;
     e->prof_on = false;
     e->prof_used = 0;
   });

@@ -5,6 +5,8 @@
 // (src/algos/models/online_decision_transformer_model.py:522-530), torch.argmax +
 // MinMaxTokenizer.inv_tokenize (src/algos/models/multi_domain_discrete_dt_model.py:83-94,
 // src/tokenizers_custom/minmax_tokenizer.py:31-47).
+#include <cstdlib>
+
 #include "common.h"
 #include "device_math.h"
 
@@ -207,6 +209,31 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(float4* dst, const flo
   for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// STREAM-like copy: one workgroup per contiguous UNR x 4 KiB block, UNR independent 16-byte loads in flight per lane
+// (each wave instruction touches whole 1 KiB rows), then UNR stores; NT = non-temporal loads and stores.
+typedef float v4c_t __attribute__((ext_vector_type(4)));
+template <int UNR, bool NT>
+__global__ __launch_bounds__(256) void stream_copy_blocked_kernel(v4c_t* __restrict__ dst, const v4c_t* __restrict__ src,
+                                                                  size_t n4) {
+  const size_t base = (size_t)blockIdx.x * (256 * UNR) + threadIdx.x;
+  v4c_t v[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const size_t i = base + (size_t)u * 256;
+    if (i < n4) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+  }
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const size_t i = base + (size_t)u * 256;
+    if (i < n4) {
+      if (NT)
+        __builtin_nontemporal_store(v[u], dst + i);
+      else
+        dst[i] = v[u];
+    }
+  }
+}
+
 // In-place read-modify-write stream with the access pattern of mlstm_cell_kernel and none of its arithmetic: one
 // workgroup per contiguous 256 KiB block (256 rows of 1 KiB), a wave reads whole rows, 16 rows (16 x 16 B per lane)
 // in flight per thread, non-temporal loads and stores, one workgroup per CU (LDS request).  Its rate is the
@@ -299,18 +326,35 @@ void launch_pad_obs(const float* native, int n_native, const int32_t* inv_index,
 
 void launch_stream_copy(float* dst, const float* src, size_t numel, hipStream_t stream) {
   LRAM_REQUIRE(numel % 4 == 0, "stream copy: numel must be a multiple of 4");
-  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, stream, reinterpret_cast<float4*>(dst),
-                     reinterpret_cast<const float4*>(src), numel / 4);
+  // LRAM_COPY_VARIANT (measurement knob): 0 grid-stride loop, 1 blocked x8, 2 blocked x8 non-temporal (default),
+  // 3 blocked x16 non-temporal, 4 blocked x4 non-temporal
+  static const int variant = [] {
+    const char* v = std::getenv("LRAM_COPY_VARIANT");
+    return v ? std::atoi(v) : 2;
+  }();
+  const size_t n4 = numel / 4;
+  v4c_t* d = reinterpret_cast<v4c_t*>(dst);
+  const v4c_t* sp = reinterpret_cast<const v4c_t*>(src);
+  auto blocks = [&](int unr) { return dim3((unsigned)((n4 + 256 * (size_t)unr - 1) / (256 * (size_t)unr))); };
+  switch (variant) {
+    case 0:
+      hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, stream, reinterpret_cast<float4*>(dst),
+                         reinterpret_cast<const float4*>(src), n4);
+      break;
+    case 1: hipLaunchKernelGGL((stream_copy_blocked_kernel<8, false>), blocks(8), dim3(256), 0, stream, d, sp, n4); break;
+    case 3: hipLaunchKernelGGL((stream_copy_blocked_kernel<16, true>), blocks(16), dim3(256), 0, stream, d, sp, n4); break;
+    case 4: hipLaunchKernelGGL((stream_copy_blocked_kernel<4, true>), blocks(4), dim3(256), 0, stream, d, sp, n4); break;
+    default: hipLaunchKernelGGL((stream_copy_blocked_kernel<8, true>), blocks(8), dim3(256), 0, stream, d, sp, n4); break;
+  }
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
 void launch_stream_rmw(float* buf, size_t numel, hipStream_t stream) {
   LRAM_REQUIRE(numel % 65536 == 0 && numel > 0, "stream rmw: numel must be a positive multiple of 65536");
-  static bool raised = false;
-  if (!raised) {
+  static uint64_t raised = 0;
+  if (first_use_on_device(raised)) {
     LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_rmw_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
-    raised = true;
   }
   hipLaunchKernelGGL(stream_rmw_kernel, dim3((unsigned)(numel / 65536)), dim3(256), 84 * 1024, stream, buf, 1.0f);
   LRAM_HIP_CHECK(hipGetLastError());

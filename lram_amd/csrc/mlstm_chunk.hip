@@ -583,11 +583,10 @@ void launch_mlstm_chunk_cell(const MlstmCellArgs& a, hipStream_t stream) {
   LRAM_REQUIRE(a.T >= 4 && a.T <= kChunkMaxTokens, "chunkwise mLSTM: 4..64 tokens per chunk");
   LRAM_REQUIRE(a.DH % kCW == 0, "chunkwise mLSTM: head dim must be a multiple of 128");
   LRAM_REQUIRE(a.amat != nullptr && a.vec != nullptr, "chunkwise mLSTM: missing work buffers");
-  static bool raised = false;
-  if (!raised) {
+  static uint64_t raised = 0;
+  if (first_use_on_device(raised)) {
     LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_cell_chunk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCellChunkLds));
-    raised = true;
   }
   const long nwg = (long)a.B * a.NH * (a.DH / kCW);
   hipLaunchKernelGGL(mlstm_cell_chunk_kernel, dim3((unsigned)nwg), dim3(kThreads), kCellChunkLds, stream, a);

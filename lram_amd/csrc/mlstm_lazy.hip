@@ -395,11 +395,10 @@ void launch_cell_tl(const MlstmLazyArgs& a, hipStream_t s) {
   size_t shmem = sizeof(float) * (T * a.DH + RP * T * CW + T * kLazyWT);
   shmem = std::max(shmem, (size_t)a.min_lds_bytes);
   if (shmem > 48 * 1024) {
-    static bool raised = false;
-    if (!raised) {
+    static uint64_t raised = 0;
+    if (first_use_on_device(raised)) {
       LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      raised = true;
     }
   }
   hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR>), grid, block, shmem, s, a);

@@ -718,11 +718,10 @@ static void launch_cell_tlu(const MlstmCellArgs& a, hipStream_t s) {
   // GEMM workgroups (37 KB LDS each) when the engine overlaps the two.
   shmem = std::max(shmem, (size_t)a.min_lds_bytes);
   if (shmem > 48 * 1024) {
-    static bool raised = false;
-    if (!raised) {
+    static uint64_t raised = 0;
+    if (first_use_on_device(raised)) {
       LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_cell_kernel<T, LPR, UNR>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      raised = true;
     }
   }
   hipLaunchKernelGGL((mlstm_cell_kernel<T, LPR, UNR>), grid, block, shmem, s, a);

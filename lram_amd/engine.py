@@ -62,6 +62,8 @@ _SYMBOLS = {
     "lram_get_compat_mode": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "lram_profile_begin": (ctypes.c_int32, [_VP]),
     "lram_profile_end": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "lram_profile_end_split": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "lram_gemm_f32": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_bf16x3": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
@@ -384,6 +386,15 @@ class Engine:
         ms, n = ctypes.c_double(0.0), ctypes.c_int64(0)
         _check(self.lib, self.lib.lram_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+
+    def profile_end_split(self):
+        """(state-pass ms, state-pass launches, fold ms, fold launches) -- lram_profile_end_split."""
+        m, a = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        nm, na = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self.lib, self.lib.lram_profile_end_split(self._h, ctypes.byref(m), ctypes.byref(nm), ctypes.byref(a),
+                                                         ctypes.byref(na)))
+        return m.value, nm.value, a.value, na.value
 
 
 def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,

@@ -39,7 +39,9 @@ def _worker(rank, world, port, total, q):
     ldist.barrier()
     mx = ldist.max_over_ranks(float(rank + 1), torch.device("cpu"))
     if rank == 0:
-        q.put((torch.stack(outs), mx))
+        # plain nested lists: a tensor on an mp.Queue travels as a file descriptor that the receiver can only open
+        # while the sender is still alive (ConnectionResetError otherwise)
+        q.put((torch.stack(outs).tolist(), mx))
     dist.destroy_process_group()
 
 
@@ -55,6 +57,7 @@ def test_env_sharded_rollout_equals_single_process(total):
     for p in procs:
         p.start()
     gathered, mx = q.get(timeout=120)
+    gathered = torch.tensor(gathered)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -64,6 +67,74 @@ def test_env_sharded_rollout_equals_single_process(total):
     ref = torch.stack([pol.step(*x) for x in make_inputs(spec, total, 3, seed=9)])
     assert torch.equal(gathered, ref)  # envs are independent: sharding changes nothing
     assert mx == 2.0
+
+
+class _StubEngine:
+    """Stands in for lram_amd.engine.Engine inside bench.main on CPU: actions are a fixed function of the inputs, so
+    the sharded + gathered result can be compared with a single-process run."""
+
+    def __init__(self, spec, batch, device):
+        self.spec, self.batch, self.device = spec, batch, device
+        self.state_mode = "materialised"
+        self.steps = 0
+
+    def set_micro_batches(self, n):
+        pass
+
+    def set_graph_mode(self, on):
+        pass
+
+    def step(self, obs, rtg, reward, reset_mask=None, **kw):
+        self.steps += 1
+        a = obs[:, :self.spec.act_dim] * 0.5 + rtg.view(-1, 1) + reset_mask.float().view(-1, 1)
+        return a, None
+
+
+def _bench_worker(rank, world, port, argv, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import bench
+    engines = []
+
+    def factory(spec, batch, device):
+        engines.append(_StubEngine(spec, batch, device))
+        return engines[-1]
+
+    out = bench.main(argv, engine_factory=factory)
+    q.put((rank, {k: v for k, v in out.items() if k != "last_actions"}, out["last_actions"].tolist(), engines[0].batch,
+           engines[0].steps))
+
+
+@pytest.mark.parametrize("argv,total", [(["--batch", "6"], 12), (["--global-batch", "7"], 7)])
+def test_bench_multi_rank_code_path_on_gloo(argv, total):
+    """bench.py's own N > 1 path (shard -> step -> all_gather_actions -> barrier -> max over ranks), weak scaling and
+    the ragged strong-scaling split, executed on CPU over gloo with a stand-in engine: the first 8-GPU run is then not
+    the first execution of that code."""
+    import socket
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    full = ["--gpus", "2", "--steps", "3", "--warmup", "2", "--config", "xlstm_tiny"] + argv
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, full, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in range(2)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, line0, act0, b0, n0), (_, line1, act1, b1, n1) = got
+    assert b0 + b1 == total and abs(b0 - b1) <= 1
+    assert n0 == n1 == 2 + 3                                   # W warm-up + exactly K timed steps per rank
+    assert line0["n_gpus"] == 2 and line0["steps"] == 3 and line0["warmup"] == 2
+    assert line0["scaling"] == ("strong" if "--global-batch" in argv else "weak")
+    assert line0["config"]["global_batch"] == total
+    assert line0["value"] == line1["value"] > 0               # max over ranks: both ranks report the same wall
+    assert abs(line0["value"] - total * 3 / (line0["ms_per_step"] * 3e-3)) < 1e-6 * line0["value"]
+    a0, a1 = torch.tensor(act0), torch.tensor(act1)
+    assert a0.shape == (total, 4) and torch.equal(a0, a1)     # every rank holds the full gathered action tensor
 
 
 class _FakeAgent:
