@@ -41,6 +41,54 @@ def assert_actions_match(a_gpu, a_ref, logits_ref, spec, discrete=False, gap_tol
     return int(bad.sum())
 
 
+def _as_double(x):
+    if not torch.is_tensor(x):
+        import numpy as np
+        x = torch.from_numpy(np.asarray(x))
+    return x.detach().cpu().double()
+
+
 def rel_err(a, b):
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    a, b = _as_double(a), _as_double(b)
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+class Fp64Oracle:
+    """The oracle evaluated in float64 on the same weights and inputs: the reference point for conditioning.  Some
+    inputs are ill-conditioned for ANY fp32 evaluation of the recurrence (the mLSTM normaliser max(|q.n|, e^-m) turns
+    a 1e-6 perturbation of q.k into a 1e-3 change of h when |q.n| sits next to e^-m, and 20 blocks carry it on); there
+    the fp32 CPU path itself is that far from the exact result, and a fixed tolerance between two fp32 evaluations
+    means nothing.  Tests then require the engine to be as close to the fp64 result as the fp32 oracle is (times a
+    small factor), wherever the fp32 oracle's own distance exceeds the fixed tolerance."""
+
+    def __init__(self, spec, sd, **kw):
+        from oracle.dt_ref import OraclePolicy
+        self._prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            self.ora = OraclePolicy(spec, sd, **kw)
+            self.ora.sd = {k: v.detach().double().cpu() for k, v in sd.items()}
+        finally:
+            torch.set_default_dtype(self._prev)
+
+    def step(self, obs, rtg, rew, mask=None, **kw):
+        torch.set_default_dtype(torch.float64)
+        try:
+            obs = obs if obs.dtype == torch.uint8 else obs.double()
+            return self.ora.step(obs, rtg.double(), rew.double(), mask, **kw)
+        finally:
+            torch.set_default_dtype(self._prev)
+
+
+def assert_close_or_as_close_as_fp32_oracle(got, ref32, ref64, tol=2e-4, factor=8.0, what=""):
+    """|got - ref32| <= tol * scale, or -- per row of the last axis -- got is within `factor` x the fp32 oracle's own
+    distance from the fp64 result."""
+    got, ref32, ref64 = _as_double(got), _as_double(ref32), _as_double(ref64)
+    scale = float(ref64.abs().max()) + 1e-12
+    err_engine = (got - ref64).abs().amax(dim=-1)
+    err_oracle = (ref32 - ref64).abs().amax(dim=-1)
+    direct = (got - ref32).abs().amax(dim=-1)
+    ok = (direct <= tol * scale) | (err_engine <= factor * err_oracle)
+    assert bool(ok.all()), (f"{what}: engine vs fp32 oracle {float(direct.max() / scale):.2e}, engine vs fp64 "
+                            f"{float(err_engine.max() / scale):.2e}, fp32 oracle vs fp64 {float(err_oracle.max() / scale):.2e}")
+    return float((err_engine / (err_oracle + 1e-30))[direct > tol * scale].max()) if bool((direct > tol * scale).any()) else 0.0

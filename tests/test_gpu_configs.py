@@ -39,7 +39,7 @@ def test_c4_206m_full_depth_continuous_head(hip_lib, model_206m):
     spec, sd = model_206m
     sd = {k: v for k, v in sd.items() if not k.startswith("embed_image.")}
     # all 20 blocks, 7 env-steps, random resets: tokens, hidden states, actions (1e-4, no ties) and the whole final state
-    assert _run_parity("xlstm_206m", B=3, steps=7, spec=spec, sd=sd) == 0
+    assert _run_parity("xlstm_206m", B=3, steps=7, spec=spec, sd=sd, cond_aware=True) == 0
 
 
 def test_c4_206m_atari_frames_discrete_head(hip_lib, model_206m):
@@ -68,8 +68,9 @@ def test_c5_206m_prefill_512_then_graph_decode_matches_oracle_fixture(hip_lib, m
     from lram_amd.engine import Engine
     from tests.golden.make_c5_fixture import (B, L, N_DECODE, SLSTM_BLOCK, STATE_BLOCKS, c5_inputs, probe,
                                               weight_checksum)
-    spec, sd = model_206m
-    sd = {k: v for k, v in sd.items() if not k.startswith("embed_image.")}
+    from tests.golden.make_c5_fixture import WEIGHT_SEED
+    spec, _ = model_206m
+    sd = init_state_dict(spec, seed=WEIGHT_SEED)   # as the fixture script draws them (no image encoder in the stream)
     fx = np.load(os.path.join(GOLD, "c5_prefill_206m.npz"))
     assert abs(weight_checksum(sd) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"]), \
         "seeded weights differ from the ones the fixture was computed with"
@@ -196,8 +197,8 @@ def test_lazy_matrix_memory_at_4096_slots_42_steps_vs_oracle(hip_lib):
 
 @pytest.mark.parametrize("B,steps", [(64, 400), (600, 120)])
 def test_lazy_equals_materialised_over_long_runs(hip_lib, B, steps):
-    """Same inputs through both representations of the matrix memory, random restarts: actions agree (a neighbouring
-    bin only at numerical ties, at most 1 in 1e5 elements) and the exported states stay within 5e-5."""
+    """Same inputs through both representations of the matrix memory, random restarts: actions agree except at numerical
+    ties of the top two logits (gap < 2e-4; at most 1 in 1e5 elements), and the exported states stay within 5e-5."""
     from lram_amd.engine import Engine
     spec = preset("xlstm_16m")
     sd = init_state_dict(spec, seed=3)
@@ -214,9 +215,12 @@ def test_lazy_equals_materialised_over_long_runs(hip_lib, B, steps):
         mask = (torch.rand(B, generator=g, device="cuda:0") < (1.0 if t == 0 else 0.01)).to(torch.uint8)
         rtg = torch.where(mask.bool(), torch.full_like(rtg, 4.5), rtg - 0.01)
         a = {m: e.step(obs, rtg, rew, mask)[0].clone() for m, e in eng.items()}
-        d = (a["eager"] - a["lazy"]).abs()
-        assert float(d.max()) <= 2.0 / 256 + 1e-6
-        mism += int((d > 1e-4).sum())
+        d = (a["eager"] - a["lazy"]).abs() > 1e-4
+        if bool(d.any()):   # only where the materialised path's own top-2 logits are tied
+            lg = eng["eager"].taps()[2].view(B, spec.act_dim, spec.n_vocab)
+            top2 = lg.topk(2, dim=-1).values
+            assert float((top2[..., 0] - top2[..., 1])[d].max()) < 2e-4, t
+        mism += int(d.sum())
     assert mism <= max(1, int(1e-5 * steps * B * spec.act_dim)), mism
     for blk in range(spec.n_blocks):
         if blk in spec.slstm_at:

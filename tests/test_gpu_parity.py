@@ -7,7 +7,8 @@ import torch
 
 from lram_amd import init_state_dict, preset
 from oracle import dt_ref
-from tests.helpers import assert_actions_match, make_inputs, rel_err
+from tests.helpers import (Fp64Oracle, assert_actions_match, assert_close_or_as_close_as_fp32_oracle, make_inputs,
+                           rel_err)
 
 pytestmark = pytest.mark.gpu
 
@@ -66,13 +67,17 @@ def test_gemm_bf16x3_matches_fp64(hip_lib, m, n, k):
 
 
 def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=2e-4, state_tol=2e-4, spec=None,
-                sd=None):
+                sd=None, cond_aware=False):
+    """cond_aware: where the engine is further than the tolerance from the fp32 oracle, accept it if it is as close to
+    the float64 evaluation as the fp32 oracle itself is (tests/helpers.py::Fp64Oracle) -- deep stacks meet inputs that
+    are ill-conditioned for any fp32 evaluation."""
     spec = preset(name) if spec is None else spec
     sd = init_state_dict(spec, seed=seed) if sd is None else sd
     eng = _engine(spec, sd, B)
     if graph:
         eng.set_graph_mode(True)
     ora = dt_ref.OraclePolicy(spec, sd)
+    o64 = Fp64Oracle(spec, sd) if cond_aware else None
     ties = 0
     # fixed device buffers so that graph mode sees stable pointers
     d_obs = torch.empty(B, spec.state_dim, device="cuda:0")
@@ -86,7 +91,12 @@ def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=
         torch.cuda.synchronize()
         tokens, hidden, logits = eng.taps()
         assert rel_err(tokens, dbg["tokens"]) < 1e-5, f"{name} step {t}: embed tokens"
-        assert rel_err(hidden, dbg["hidden"]) < hidden_tol, f"{name} step {t}: hidden {rel_err(hidden, dbg['hidden'])}"
+        if cond_aware:
+            _, d64 = o64.step(obs, rtg, rew, mask, discrete=discrete, return_debug=True)
+            assert_close_or_as_close_as_fp32_oracle(hidden, dbg["hidden"], d64["hidden"], tol=hidden_tol,
+                                                    what=f"{name} step {t}: hidden")
+        else:
+            assert rel_err(hidden, dbg["hidden"]) < hidden_tol, f"{name} step {t}: hidden {rel_err(hidden, dbg['hidden'])}"
         a_cmp = a_gpu[:, :1] if discrete else a_gpu
         ties += assert_actions_match(a_cmp, a_ref, dbg["logits"], spec, discrete, what=f"{name} step {t}")
     # final recurrent state against the oracle's, in the reference's past_key_values layout
@@ -96,14 +106,23 @@ def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=
             assert rel_err(pkv[i][0], ora.state[i][0]) < state_tol
             assert rel_err(pkv[i][1], ora.state[i][1]) < state_tol
     else:
+        def close(got, want, want64, what):
+            if cond_aware:   # per env: flatten everything behind the env axis
+                nb = want.shape[0]
+                assert_close_or_as_close_as_fp32_oracle(got.reshape(nb, 1, -1), want.reshape(nb, 1, -1),
+                                                        want64.reshape(nb, 1, -1), tol=state_tol, what=what)
+            else:
+                assert rel_err(got, want) < state_tol, what
         for i in range(spec.n_blocks):
             blk, ref = pkv[f"block_{i}"], ora.state[f"block_{i}"]
-            assert rel_err(blk["conv_state"][0], ref["conv_state"][0]) < state_tol
+            r64 = o64.ora.state[f"block_{i}"] if cond_aware else ref
+            close(blk["conv_state"][0], ref["conv_state"][0], r64["conv_state"][0], f"conv {i}")
             if "mlstm_state" in blk:
                 for j in range(3):
-                    assert rel_err(blk["mlstm_state"][j], ref["mlstm_state"][j]) < state_tol, (i, j)
-            else:
-                assert rel_err(blk["slstm_state"], ref["slstm_state"]) < state_tol, i
+                    close(blk["mlstm_state"][j], ref["mlstm_state"][j], r64["mlstm_state"][j], f"mlstm state {i}.{j}")
+            else:   # [4, B, D] -> env-major
+                close(blk["slstm_state"].transpose(0, 1), ref["slstm_state"].transpose(0, 1),
+                      r64["slstm_state"].transpose(0, 1), f"slstm state {i}")
     eng.close()
     return ties
 
