@@ -148,7 +148,8 @@ int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_
                           const uint8_t* dev_reset_mask, float* dev_hidden_out, void* stream);
 
 /* Debug/parity taps of the last lram_step: copies into caller device buffers when non-NULL.
- *   dev_tokens_embed float[batch, tokens_per_step, d_model]  embed_ln output
+ *   dev_tokens_embed float[batch, tokens_per_step, d_model]  embed_ln output (batches of up to 1024 env slots: larger
+ *                                                             ones skip the per-step copy this tap costs; pass NULL)
  *   dev_hidden       float[batch, tokens_per_step, d_model]  encoder output (after the final norm)
  *   dev_logits       float[batch, act_dim * n_vocab]         action_net output */
 int32_t lram_get_taps(lram_engine* e, float* dev_tokens_embed, float* dev_hidden, float* dev_logits,

@@ -153,7 +153,7 @@ void launch_mlstm_chunk_cell(const MlstmCellArgs& a, hipStream_t stream);
 // and appends its tokens to a window; C_base is rewritten (folded) once every `period` steps per env.
 // ---------------------------------------------------------------------------------------------
 constexpr int kLazyWindow = 48;  // window capacity in tokens
-constexpr int kLazyWT = kLazyWindow + 4;  // row pitch of the per-step attention weights: window + this step's tokens
+constexpr int kLazyWT = kLazyWindow + 4;  // row pitch of the per-step window scores (LDS): window + this step's tokens
 struct MlstmLazyArgs {
   float* C;               // [B, NH, DH, DH] C_base (fold: in/out; cell: in)
   float* wk;              // [B, NH, W, DH] window khat_j = k_j / sqrt(DH)
@@ -169,7 +169,6 @@ struct MlstmLazyArgs {
   const float* v;
   const float* scal;      // [B*T, NH, 4] (f_t, i_t, denom_t, m_t) from mlstm_pre_kernel
   float* h;               // [B*T, inner] out
-  float* pw;              // [B, NH, T, kLazyWT] p[t][j] = c_{t,j} (q_t . khat_j): score kernel out, cell kernel in
   const uint8_t* reset;   // [B] or null
   int B, T, NH, DH;
   int phase, period;      // env b folds when (phase + b) % period == 0 (staggered), or when the window would overflow
@@ -179,7 +178,6 @@ struct MlstmLazyArgs {
   int min_lds_bytes = 0;
 };
 void launch_mlstm_lazy_fold(const MlstmLazyArgs& a, hipStream_t stream);
-void launch_mlstm_lazy_book(const MlstmLazyArgs& a, hipStream_t stream);
 void launch_mlstm_lazy_cell(const MlstmLazyArgs& a, hipStream_t stream);
 bool mlstm_lazy_supported(int DH, int T);
 // count[b] = 0, g[b, :] = 1 for masked envs (mask == nullptr: all), both parities handled by the caller

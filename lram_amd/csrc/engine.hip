@@ -63,7 +63,6 @@ struct BlockState {
   DevBuf wk, wv;    // [B, NH, W, DH] each
   DevBuf coef;      // [2][B, NH, W]
   DevBuf gsc;       // [2][B, NH]
-  DevBuf pw;        // [B, NH, 4, kLazyWT] window attention weights of the current step
 };
 
 struct GraphKey {
@@ -77,6 +76,8 @@ struct GraphKey {
 };
 
 }  // namespace
+
+constexpr int kTokenTapMaxBatch = 1024;  // larger batches skip the per-step copy of the embed_ln tokens (lram_get_taps)
 
 struct lram_engine {
   lram_config cfg{};
@@ -110,6 +111,8 @@ struct lram_engine {
   bool lazy = false;        // effective choice for the current batch (decided in state_alloc / set_state_mode)
   bool lazy_ready = false;  // buffers allocated for the current batch
   int lazy_period = 13;
+  bool split_up = true;     // LRAM_SPLIT_UP=0: proj_up as one GEMM ahead of the front end
+  bool fold_ahead = false;  // LRAM_FOLD_AHEAD=1: every fold queued at the step start (measured: no gain over one block ahead)
   int64_t lazy_step = 0;    // steps taken in lazy mode: fold phase and ping-pong parity
   std::vector<int> lazy_bound;  // host-side upper bound of pending tokens per fold class (b % period)
   bool lazy_compact = false;    // this step's fold launches may use the compact grid (no window can overflow)
@@ -187,7 +190,6 @@ struct lram_engine {
       s.wv.release();
       s.coef.release();
       s.gsc.release();
-      s.pw.release();
     }
     LZ_COUNT.release();
     lazy_ready = false;
@@ -471,9 +473,7 @@ void lazy_alloc(lram_engine* e) {
     s.wv.alloc(B * NH * kLazyWindow * DH);
     s.coef.alloc(2 * B * NH * kLazyWindow);
     s.gsc.alloc(2 * B * NH);
-    s.pw.alloc(B * NH * 4 * kLazyWT);
     s.coef.zero();
-    s.pw.zero();
   }
   e->LZ_COUNT.alloc(2 * B);
   e->LZ_COUNT.zero();
@@ -518,7 +518,6 @@ MlstmLazyArgs lazy_args(lram_engine* e, int i, int T, const uint8_t* reset, int 
   a.g_out = st.gsc.p + (out * B + b0) * NH;
   a.count_in = reinterpret_cast<const int32_t*>(e->LZ_COUNT.p) + in * B + b0;
   a.count_out = reinterpret_cast<int32_t*>(e->LZ_COUNT.p) + out * B + b0;
-  a.pw = st.pw.p + (size_t)b0 * NH * T * kLazyWT;
   a.reset = reset ? reset + b0 : nullptr;
   a.B = nb, a.T = T, a.NH = (int)NH, a.DH = (int)DH;
   // the fold phase is taken relative to the env's global index, so slices fold the same envs as the whole batch
@@ -598,9 +597,10 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
     g.splitk_ws_elems = (int64_t)lram_engine::kSplitKSlotElems;
   }
   if (e->use_bf16x3 && !gemm_small_m(g)) {
-    auto it = e->split.find(g.w);
-    if (it != e->split.end()) {
-      g.w3 = it->second.p;
+    // planes of the weight tensor that contains g.w (a GEMM may address a row range of a weight: proj_up's halves)
+    auto it = e->split.upper_bound(g.w);
+    if (it != e->split.begin() && (--it, g.w < it->first + it->second.n)) {
+      g.w3 = it->second.p + (g.w - it->first);
       g.w3_plane = (int64_t)it->second.n;
       if (gemm_bf16x3_supported(g)) {
         launch_gemm_bf16x3(g, s);
@@ -661,6 +661,19 @@ void stream_after(lram_engine* e, hipStream_t dst, hipStream_t src) {
   LRAM_HIP_CHECK(hipStreamWaitEvent(dst, ev, 0));
 }
 
+// Split form of stream_after: record now, let another stream wait later (same event ring).
+hipEvent_t record_on(lram_engine* e, hipStream_t src) {
+  constexpr size_t kRing = 512;
+  if (e->sync_events.size() < kRing && e->sync_used >= e->sync_events.size()) {
+    hipEvent_t nev;
+    LRAM_HIP_CHECK(hipEventCreateWithFlags(&nev, hipEventDisableTiming));
+    e->sync_events.push_back(nev);
+  }
+  hipEvent_t ev = e->sync_events[e->sync_used++ % e->sync_events.size()];
+  LRAM_HIP_CHECK(hipEventRecord(ev, src));
+  return ev;
+}
+
 // Slices for this call.  One slice on the caller's stream unless micro-batching is on: then n_micro slices on
 // engine-owned streams plus one stream that serialises the HBM-bound cell kernels (see run_xlstm_stack).
 std::vector<Slice> make_slices(lram_engine* e, hipStream_t s, hipStream_t* hbm) {
@@ -706,9 +719,11 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   const BlockWeights& w = e->bw[i];
   BlockState& st = e->st[i];
   launch_row_norm(e->X.p + r0 * D, D, e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps, c.norm_is_rms, sl.s);
+  // proj_up in two halves: the x_m half feeds the conv / q / k / v front end and is on the block's critical path; the
+  // z half is only needed by the output gate after the state pass and is issued beside it (mlstm_up_z)
   GemmArgs up;
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p + r0 * e->ucols, up.ldc = 2 * inner;
-  up.m = rows, up.n = 2 * inner, up.k = D;
+  up.m = rows, up.n = e->split_up ? inner : 2 * inner, up.k = D;
   gemm(e, up, sl.s);
   MlstmPreArgs pa;
   pa.u = e->U.p + r0 * e->ucols, pa.conv_state = st.conv.p + b0 * c.conv_k * inner, pa.n_state = st.n.p + b0 * inner;
@@ -726,6 +741,17 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     pa.vec = e->VEC.p + b0 * NH * 3 * kChunkMaxTokens;
   }
   launch_mlstm_pre(pa, sl.s);
+}
+
+void mlstm_up_z(lram_engine* e, int i, int T, const Slice& sl) {
+  if (!e->split_up) return;
+  const lram_config& c = e->cfg;
+  const int D = c.d_model, inner = c.inner, rows = sl.nb * T;
+  const size_t r0 = (size_t)sl.b0 * T;
+  GemmArgs up;
+  up.a = e->XN.p + r0 * D, up.lda = D, up.w = e->bw[i].proj_up + (size_t)inner * D, up.ldw = D;
+  up.c = e->U.p + r0 * e->ucols + inner, up.ldc = 2 * inner, up.m = rows, up.n = inner, up.k = D;
+  gemm(e, up, sl.s);
 }
 
 void mlstm_cell(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl, hipStream_t s) {
@@ -873,13 +899,27 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
       if (!c.block_is_slstm[k]) return k;
     return -1;
   };
-  if (lazy && next_mlstm(-1) >= 0) launch_folds(next_mlstm(-1));
+  // fold_ahead: every block's fold is queued when the step starts (own stream, one event per block), so the folds
+  // stream through HBM while the state pass has nothing to do -- the first front end of the step and the sLSTM
+  // blocks -- instead of one block ahead of the cells, beside them.
+  const bool fold_ahead = lazy && fs != hbm && e->fold_ahead;
+  std::vector<hipEvent_t> fold_done(c.n_blocks, nullptr);
+  if (fold_ahead) {
+    for (int i = next_mlstm(-1); i >= 0; i = next_mlstm(i)) {
+      launch_folds(i);
+      fold_done[i] = record_on(e, fs);
+    }
+  } else if (lazy && next_mlstm(-1) >= 0) {
+    launch_folds(next_mlstm(-1));
+  }
   for (int i = 0; i < c.n_blocks; ++i) {
     if (c.block_is_slstm[i]) {
       for (const Slice& x : sl) slstm_block(e, i, T, reset, x);
       continue;
     }
-    if (lazy) {
+    if (fold_ahead) {
+      LRAM_HIP_CHECK(hipStreamWaitEvent(hbm, fold_done[i], 0));  // fold(i) done before cell(i)
+    } else if (lazy) {
       stream_after(e, hbm, fs);  // fold(i) done before cell(i)
       const int nxt = next_mlstm(i);
       if (nxt >= 0) launch_folds(nxt);
@@ -887,8 +927,8 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
     for (const Slice& x : sl) {
       mlstm_front(e, i, T, reset, x);
       if (lazy) {
-        // lazy matrix memory: bookkeeping beside the front end; on the HBM stream the (mostly empty) fold launch, then
-        // the read-only pass + window attention
+        // lazy matrix memory: on the HBM stream the read-only pass with the window scores, the window attention and the
+        // step's bookkeeping
         MlstmLazyArgs la = lazy_args(e, i, T, reset, x.b0, x.nb);
         const size_t r0 = (size_t)x.b0 * T;
         la.q = e->Q.p + r0 * e->icols, la.k = e->K.p + r0 * e->icols, la.v = e->V.p + r0 * e->icols;
@@ -896,16 +936,17 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
         // the read-only pass runs best with two workgroups per CU (one's prologue / epilogue under the other's
         // stream; 362k vs 308k env-steps/s at B = 4096 against the single-workgroup cap the read-modify-write kernel likes)
         la.min_lds_bytes = e->cell_lds_pad >= 0 ? e->cell_lds_pad : 0;
-        launch_mlstm_lazy_book(la, x.s);
         stream_after(e, hbm, x.s);
         prof_record(e, hbm, true);
         launch_mlstm_lazy_cell(la, hbm);
         prof_record(e, hbm, false);
+        mlstm_up_z(e, i, T, x);  // on the slice's stream, beside its own state pass
         stream_after(e, x.s, hbm);
         continue;
       }
       stream_after(e, hbm, x.s);
       mlstm_cell(e, i, T, reset, x, hbm);
+      mlstm_up_z(e, i, T, x);
       stream_after(e, x.s, hbm);
     }
     for (const Slice& x : sl) mlstm_back(e, i, T, x);
@@ -1102,7 +1143,7 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
                              x.nb, Tc, D, x.s);
       }
       launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s);
-      if (L == 1)  // taps (lram_get_taps) are defined for single env-steps
+      if (L == 1 && e->B <= kTokenTapMaxBatch)  // taps (lram_get_taps) are defined for single env-steps
         LRAM_HIP_CHECK(hipMemcpyAsync(e->TOK.p + r0 * D, X, sizeof(float) * (size_t)x.nb * Tc * D,
                                       hipMemcpyDeviceToDevice, x.s));
     }
@@ -1197,6 +1238,8 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
       const std::string m(v);
       e->lazy_mode = m == "lazy" ? 1 : (m == "eager" || m == "materialised" || m == "materialized") ? 0 : 2;
     }
+    if (const char* v = std::getenv("LRAM_SPLIT_UP")) e->split_up = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
     *out = e.release();
   });
@@ -1369,7 +1412,12 @@ int32_t lram_get_taps(lram_engine* e, float* dev_tokens_embed, float* dev_hidden
     LRAM_REQUIRE(e && e->B > 0, "lram_get_taps: state not allocated");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t btd = sizeof(float) * (size_t)e->B * e->cfg.tokens_per_step * e->cfg.d_model;
-    if (dev_tokens_embed) LRAM_HIP_CHECK(hipMemcpyAsync(dev_tokens_embed, e->TOK.p, btd, hipMemcpyDeviceToDevice, s));
+    if (dev_tokens_embed) {
+      LRAM_REQUIRE(e->B <= kTokenTapMaxBatch,
+                   "lram_get_taps: the embed_ln token tap is kept for batches of up to 1024 env slots only (it costs a "
+                   "copy of the token buffer per step); pass NULL for it");
+      LRAM_HIP_CHECK(hipMemcpyAsync(dev_tokens_embed, e->TOK.p, btd, hipMemcpyDeviceToDevice, s));
+    }
     if (dev_hidden) LRAM_HIP_CHECK(hipMemcpyAsync(dev_hidden, e->HID.p, btd, hipMemcpyDeviceToDevice, s));
     if (dev_logits)
       LRAM_HIP_CHECK(hipMemcpyAsync(dev_logits, e->LOGITS.p, sizeof(float) * e->LOGITS.n, hipMemcpyDeviceToDevice, s));

@@ -14,10 +14,11 @@
 // (fewer roundings: C_base is touched once per period), results stay within the parity bars.
 //
 // Bookkeeping (per env: pending token count; per (env, head): scale g and the coefficients c_j) is ping-ponged
-// between two buffers by step parity: the kernels of one step read the "in" side, `mlstm_lazy_book_kernel` writes
-// the "out" side.  Whether an env folds / restarts this step is a pure function of (count_in, reset, phase), which
+// between two buffers by step parity: the kernels of one step read the "in" side, the cell kernel's column slice 0
+// writes the "out" side.  Whether an env folds / restarts this step is a pure function of (count_in, reset, phase), which
 // every kernel evaluates identically -- no flags, no inter-workgroup hand-off.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "device_math.h"
@@ -158,33 +159,53 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
 }
 
 // =============================================================================================
-// score: one workgroup per (env, head), on the slice's stream beside the front end (off the HBM stream):
-//   * bookkeeping after this step's T tokens (coefficients, scale, count) into the "out" side;
-//   * the window attention weights of this step, p[t][j] = c_{t,j} (q_t . khat_j), j over the pending window and
-//     this step's own tokens, written to `pw` [B, NH, T, kLazyWT] for the cell kernel.
+// cell: read-only pass over C_base + the window terms + the step's bookkeeping.  One workgroup per (env, head, column
+// slice); thread c of the slice owns column c of the window's V rows, fetched into registers before the pass over
+// C_base starts.
+//   y_t = q_t^T C_base ;   p[t][j] = c_{t,j} (q_t . khat_j) ;   h_t = ( G_t y_t + sum_j p[t][j] v_j ) / den_t
+// The window scores p (formerly a kernel of their own on the slice's stream, with a round trip through HBM) are
+// computed here: the window's khat rows are fetched into registers before the pass starts (KPL > 0: DH == 64 KPL,
+// each wave keeps every fourth row) or loaded four rows per wave at a time after it (KPL == 0: any head dim), the
+// dot products are reduced per wave and land in LDS while the row-group partial sums of the pass are being combined.
+// Column slice 0 also appends the step's T tokens to the window and writes the bookkeeping of the next step
+// (coefficients, scale, pending count) into the "out" side.
 // =============================================================================================
-constexpr int WT = kLazyWT;  // window + this step's tokens (row pitch of pw)
+constexpr int WT = kLazyWT;  // window + this step's tokens (row pitch of the score rows in LDS)
+constexpr int kRowsPerWave = (W + 4 + 3) / 4;
 
-template <int T>
-__global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) {
-  extern __shared__ float qk[];  // qs [T][DH], ks [T][DH]
-  __shared__ float s_coef[W];
-  const int h = blockIdx.x, b = blockIdx.y;
+template <int T, int LPR, int UNR, int KPL>
+__global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
+  constexpr int CW = 4 * LPR;
+  constexpr int RP = 256 / LPR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int DH = a.DH;
+  float* qs = smem;                 // [T][DH]
+  float* ks = qs + T * DH;          // [T][DH] khat of this step's tokens
+  float* red = ks + T * DH;         // [RP][T][CW]
+  float* pw = red + RP * T * CW;    // [T][WT]
+  float* s_coef = pw + T * WT;      // [W]
+
+  const int b = blockIdx.z, h = blockIdx.y, slice = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int NH = a.NH, DH = a.DH, inner = NH * DH;
-  float* qs = qk;
-  float* ks = qk + T * DH;
+  const int cl = tid % LPR, rg = tid / LPR;
+  const int NH = a.NH, inner = NH * DH;
   const LazyView lv = lazy_view(a, b);
   const int n = lv.n;
-  float f[T], ig[T], F[T];
-  float Fc = 1.f;
+
+  float den[T], G[T], f[T], ig[T], F[T];
+  const float g0 = (lv.rs || lv.fold) ? 1.f : a.g_in[(int64_t)b * NH + h];
+  {
+    float Fc = 1.f;
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const float4 s = *reinterpret_cast<const float4*>(a.scal + (((int64_t)b * T + t) * NH + h) * 4);
-    f[t] = s.x;
-    ig[t] = s.y;
-    Fc *= s.x;
-    F[t] = Fc;
+    for (int t = 0; t < T; ++t) {
+      const float4 s = *reinterpret_cast<const float4*>(a.scal + (((int64_t)b * T + t) * NH + h) * 4);
+      f[t] = s.x;
+      ig[t] = s.y;
+      den[t] = s.z;
+      Fc *= s.x;
+      F[t] = Fc;          // f_1 .. f_t
+      G[t] = g0 * Fc;     // g f_1 .. f_t
+    }
   }
   const float sqrt_dh = sqrtf((float)DH);
   for (int r = tid; r < DH; r += 256) {
@@ -197,115 +218,9 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
   }
   const int64_t base = ((int64_t)b * NH + h) * W;
   if (tid < W) s_coef[tid] = tid < n ? a.coef_in[base + tid] : 0.f;
-  __syncthreads();
-  // ---- bookkeeping for the next step ----
-  if (tid < n) a.coef_out[base + tid] = s_coef[tid] * F[T - 1];
-  if (tid < T) {
-    float c = 1.f;
-#pragma unroll
-    for (int x = 0; x < T; ++x) {
-      if (x == tid) c *= ig[x];
-      if (x > tid) c *= f[x];
-    }
-    a.coef_out[base + n + tid] = c;
-  }
-  if (tid == 0) {
-    const float g = (lv.rs || lv.fold) ? 1.f : a.g_in[(int64_t)b * NH + h];
-    a.g_out[(int64_t)b * NH + h] = g * F[T - 1];
-    if (h == 0) a.count_out[b] = (n + T) | (lv.zero ? kZeroBit : 0);
-  }
-  // ---- p[t][j]: each wave takes four window rows at a time (their loads are issued together) ----
-  const float* wkb = a.wk + base * DH;
-  float* pwo = a.pw + (((int64_t)b * NH + h) * T) * WT;
-  for (int j0 = 4 * wave; j0 < n + T; j0 += 16) {
-    float p[4][T];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int t = 0; t < T; ++t) p[i][t] = 0.f;
-    for (int r = lane; r < DH; r += 64) {
-      float kv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = j0 + i;
-        kv[i] = j < n ? wkb[(int64_t)j * DH + r] : (j < n + T ? ks[(j - n) * DH + r] : 0.f);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < T; ++t) p[i][t] += qs[t * DH + r] * kv[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = j0 + i;
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const float s = wave_sum(p[i][t]);
-        if (lane == 0 && j < n + T) {
-          float c;
-          if (j < n) {
-            c = s_coef[j] * F[t];
-          } else {
-            const int u = j - n;  // this step's token u reaches t >= u with i_u f_{u+1} .. f_t
-            c = 0.f;
-            if (u <= t) {
-              c = 1.f;
-#pragma unroll
-              for (int x = 0; x < T; ++x) {
-                if (x == u) c *= ig[x];
-                if (x > u && x <= t) c *= f[x];
-              }
-            }
-          }
-          pwo[t * WT + j] = c * s;
-        }
-      }
-    }
-  }
-}
-
-// =============================================================================================
-// cell: read-only pass over C_base + the window terms.  One workgroup per (env, head, column slice); thread c of the
-// slice owns column c of the window's V rows, fetched into registers before the pass over C_base starts.
-//   y_t = q_t^T C_base ;   h_t = ( G_t y_t + sum_j p[t][j] v_j ) / den_t
-// and the step's T tokens are appended to the window.
-// =============================================================================================
-template <int T, int LPR, int UNR>
-__global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
-  constexpr int CW = 4 * LPR;
-  constexpr int RP = 256 / LPR;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int DH = a.DH;
-  float* qs = smem;                 // [T][DH]
-  float* red = smem + T * DH;       // [RP][T][CW]
-  float* pw = red + RP * T * CW;    // [T][WT]
-
-  const int b = blockIdx.z, h = blockIdx.y, slice = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int cl = tid % LPR, rg = tid / LPR;
-  const int NH = a.NH, inner = NH * DH;
-  const LazyView lv = lazy_view(a, b);
-  const int n = lv.n;
-
-  float den[T], G[T];
-  {
-    float Fc = (lv.rs || lv.fold) ? 1.f : a.g_in[(int64_t)b * NH + h];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const float4 s = *reinterpret_cast<const float4*>(a.scal + (((int64_t)b * T + t) * NH + h) * 4);
-      den[t] = s.z;
-      Fc *= s.x;
-      G[t] = Fc;  // g f_1 .. f_t
-    }
-  }
-  for (int r = tid; r < DH; r += 256) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) qs[t * DH + r] = a.q[((int64_t)b * T + t) * inner + (int64_t)h * DH + r];
-  }
-  const float* pwi = a.pw + (((int64_t)b * NH + h) * T) * WT;
-  for (int idx = tid; idx < T * WT; idx += 256) pw[idx] = pwi[idx];
+  for (int idx = tid; idx < T * WT; idx += 256) pw[idx] = 0.f;
   // window V column of this thread (threads >= CW idle here): in flight during the pass over C_base
-  const float* wvb = a.wv + (((int64_t)b * NH + h) * W) * DH + slice * CW + (tid < CW ? tid : 0);
+  const float* wvb = a.wv + (base * DH) + slice * CW + (tid < CW ? tid : 0);
   float vw[W];
 #pragma unroll
   for (int j = 0; j < W; ++j) vw[j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
@@ -313,6 +228,17 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
 #pragma unroll
   for (int t = 0; t < T; ++t)
     vcur[t] = tid < CW ? a.v[((int64_t)b * T + t) * inner + (int64_t)h * DH + slice * CW + tid] : 0.f;
+  // window khat rows of this wave (rows wave, wave + 4, ...), KPL values per lane and row
+  const float* wkb = a.wk + base * DH;
+  float kreg[KPL > 0 ? kRowsPerWave : 1][KPL > 0 ? KPL : 1];
+  if (KPL > 0) {
+#pragma unroll
+    for (int i = 0; i < kRowsPerWave; ++i) {
+      const int j = wave + 4 * i;
+#pragma unroll
+      for (int c = 0; c < KPL; ++c) kreg[i][c] = j < n ? wkb[(int64_t)j * DH + lane + 64 * c] : 0.f;
+    }
+  }
   __syncthreads();
 
   const int col0 = slice * CW + 4 * cl;
@@ -340,6 +266,72 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   }
 #pragma unroll
   for (int t = 0; t < T; ++t) *reinterpret_cast<v4f*>(red + ((rg * T + t) * CW) + 4 * cl) = acc[t];
+
+  // ---- window scores p[t][j] = c_{t,j} (q_t . khat_j), j over the pending window and this step's own tokens ----
+  auto coefficient = [&](int j, int t) -> float {
+    if (j < n) return s_coef[j] * F[t];
+    const int u = j - n;  // this step's token u reaches t >= u with i_u f_{u+1} .. f_t
+    if (u > t) return 0.f;
+    float c = 1.f;
+#pragma unroll
+    for (int x = 0; x < T; ++x) {
+      if (x == u) c *= ig[x];
+      if (x > u && x <= t) c *= f[x];
+    }
+    return c;
+  };
+  if (KPL > 0) {
+#pragma unroll
+    for (int i = 0; i < kRowsPerWave; ++i) {
+      const int j = wave + 4 * i;
+      if (j < n + T) {
+        float p[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) p[t] = 0.f;
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) {
+          const int r = lane + 64 * c;
+          const float kv = j < n ? kreg[i][c] : ks[(j - n) * DH + r];
+#pragma unroll
+          for (int t = 0; t < T; ++t) p[t] += qs[t * DH + r] * kv;
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float sm = wave_sum(p[t]);
+          if (lane == 0) pw[t * WT + j] = coefficient(j, t) * sm;
+        }
+      }
+    }
+  } else {
+    for (int j0 = 4 * wave; j0 < n + T; j0 += 16) {  // four rows per wave at a time (their loads are issued together)
+      float p[4][T];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t) p[i][t] = 0.f;
+      for (int r = lane; r < DH; r += 64) {
+        float kv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = j0 + i;
+          kv[i] = j < n ? wkb[(int64_t)j * DH + r] : (j < n + T ? ks[(j - n) * DH + r] : 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < T; ++t) p[i][t] += qs[t * DH + r] * kv[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = j0 + i;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float sm = wave_sum(p[i][t]);
+          if (lane == 0 && j < n + T) pw[t * WT + j] = coefficient(j, t) * sm;
+        }
+      }
+    }
+  }
   __syncthreads();
   if (tid < CW) {
     const int c = tid;
@@ -354,7 +346,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
 #pragma unroll
     for (int j = 0; j < W; ++j) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) hn[t] += pw[t * WT + j] * vw[j];  // pw == 0 beyond the window
+      for (int t = 0; t < T; ++t) hn[t] += pw[t * WT + j] * vw[j];  // vw == 0 beyond the window, pw zero-filled
     }
 #pragma unroll
     for (int u = 0; u < T; ++u)
@@ -363,17 +355,28 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
 #pragma unroll
     for (int t = 0; t < T; ++t)
       a.h[((int64_t)b * T + t) * inner + (int64_t)h * DH + slice * CW + c] = hn[t] / den[t];
-    // append this step's v rows; khat rows are appended by slice 0 below
-    float* wvo = a.wv + (((int64_t)b * NH + h) * W + n) * DH + slice * CW + c;
+    // append this step's v rows; khat rows and the bookkeeping are written by slice 0 below
+    float* wvo = a.wv + (base + n) * DH + slice * CW + c;
 #pragma unroll
     for (int t = 0; t < T; ++t) wvo[(int64_t)t * DH] = vcur[t];
   }
   if (slice == 0) {
-    const float sqrt_dh = sqrtf((float)DH);
-    float* wko = a.wk + (((int64_t)b * NH + h) * W + n) * DH;
-    for (int idx = tid; idx < T * DH; idx += 256) {
-      const int t = idx / DH, r = idx - t * DH;
-      wko[idx] = a.k[((int64_t)b * T + t) * inner + (int64_t)h * DH + r] / sqrt_dh;
+    float* wko = a.wk + (base + n) * DH;
+    for (int idx = tid; idx < T * DH; idx += 256) wko[idx] = ks[idx];
+    // ---- bookkeeping for the next step ("out" side of the ping-pong) ----
+    if (tid < n) a.coef_out[base + tid] = s_coef[tid] * F[T - 1];
+    if (tid < T) {
+      float c = 1.f;
+#pragma unroll
+      for (int x = 0; x < T; ++x) {
+        if (x == tid) c *= ig[x];
+        if (x > tid) c *= f[x];
+      }
+      a.coef_out[base + n + tid] = c;
+    }
+    if (tid == 0) {
+      a.g_out[(int64_t)b * NH + h] = g0 * F[T - 1];
+      if (h == 0) a.count_out[b] = (n + T) | (lv.zero ? kZeroBit : 0);
     }
   }
 }
@@ -388,28 +391,40 @@ __global__ __launch_bounds__(256) void mlstm_lazy_clear_kernel(int32_t* count, f
   if (gid == b * NH) count[b] = 0;
 }
 
-template <int T, int LPR>
-void launch_cell_tl(const MlstmLazyArgs& a, hipStream_t s) {
-  constexpr int CW = 4 * LPR, RP = 256 / LPR, UNR = 16;
+template <int T, int LPR, int UNR, int KPL>
+void launch_cell_tluk(const MlstmLazyArgs& a, hipStream_t s) {
+  constexpr int CW = 4 * LPR, RP = 256 / LPR;
   dim3 grid(a.DH / CW, a.NH, a.B), block(256);
-  size_t shmem = sizeof(float) * (T * a.DH + RP * T * CW + T * kLazyWT);
+  size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW + T * kLazyWT + W);
   shmem = std::max(shmem, (size_t)a.min_lds_bytes);
   if (shmem > 48 * 1024) {
     static uint64_t raised = 0;
     if (first_use_on_device(raised)) {
-      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR>),
+      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR, KPL>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
   }
-  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR>), grid, block, shmem, s, a);
+  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR, KPL>), grid, block, shmem, s, a);
 }
 
 template <int T>
 void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
-  if (a.DH % 256 == 0)
-    launch_cell_tl<T, 64>(a, s);
-  else
-    launch_cell_tl<T, 32>(a, s);
+  // LRAM_LAZY_UNROLL (measurement knob, T == 3 on the 256-wide geometry only): C_base rows in flight per lane
+  static const int unroll = [] {
+    const char* v = std::getenv("LRAM_LAZY_UNROLL");
+    return v ? std::atoi(v) : 4;  // measured at 4096 env slots: 4 rows in flight 377k env-steps/s, 8: 371k, 16: 362k
+  }();
+  static const bool prefetch = [] {
+    const char* v = std::getenv("LRAM_LAZY_KPREFETCH");
+    return v ? std::atoi(v) != 0 : true;
+  }();
+  if (a.DH == 256 && prefetch) {
+    if (T == 3 && unroll == 4) return launch_cell_tluk<T, 64, 4, 4>(a, s);
+    if (T == 3 && unroll == 8) return launch_cell_tluk<T, 64, 8, 4>(a, s);
+    return launch_cell_tluk<T, 64, 16, 4>(a, s);
+  }
+  if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 16, 0>(a, s);
+  launch_cell_tluk<T, 32, 16, 0>(a, s);
 }
 
 }  // namespace
@@ -427,20 +442,6 @@ void launch_mlstm_lazy_fold(const MlstmLazyArgs& a_in, hipStream_t stream) {
   }
   const long nwg = envs * a.NH * (a.DH / kFC) * (a.DH / kFR);
   hipLaunchKernelGGL(mlstm_lazy_fold_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, a);
-  LRAM_HIP_CHECK(hipGetLastError());
-}
-
-void launch_mlstm_lazy_book(const MlstmLazyArgs& a, hipStream_t stream) {
-  LRAM_REQUIRE(a.T >= 1 && a.T <= 4, "lazy mLSTM: 1..4 tokens per step");
-  LRAM_REQUIRE(a.pw != nullptr, "lazy mLSTM: missing score buffer");
-  dim3 grid(a.NH, a.B), block(256);
-  const size_t shmem = sizeof(float) * 2 * a.T * a.DH;
-  switch (a.T) {
-    case 1: hipLaunchKernelGGL(mlstm_lazy_score_kernel<1>, grid, block, shmem, stream, a); break;
-    case 2: hipLaunchKernelGGL(mlstm_lazy_score_kernel<2>, grid, block, shmem, stream, a); break;
-    case 3: hipLaunchKernelGGL(mlstm_lazy_score_kernel<3>, grid, block, shmem, stream, a); break;
-    default: hipLaunchKernelGGL(mlstm_lazy_score_kernel<4>, grid, block, shmem, stream, a); break;
-  }
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

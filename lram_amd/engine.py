@@ -281,8 +281,8 @@ class Engine:
     def taps(self):
         """(embed_ln tokens [B,T,D], encoder hidden [B,T,D], logits [B, act_dim*n_vocab]) of the last step."""
         B, s = self.batch, self.spec
-        tok = torch.empty(B, s.tokens_per_step, s.d_model, dtype=torch.float32, device=self.device)
-        hid = torch.empty_like(tok)
+        hid = torch.empty(B, s.tokens_per_step, s.d_model, dtype=torch.float32, device=self.device)
+        tok = torch.empty_like(hid) if B <= 1024 else None   # the token tap is kept for small batches only
         logits = torch.empty(B, s.act_dim * s.n_vocab, dtype=torch.float32, device=self.device)
         _check(self.lib, self.lib.lram_get_taps(self._h, _ptr(tok), _ptr(hid), _ptr(logits), _stream_ptr(self.device)))
         return tok, hid, logits
