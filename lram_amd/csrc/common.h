@@ -169,6 +169,7 @@ struct MlstmLazyArgs {
   const float* v;
   const float* scal;      // [B*T, NH, 4] (f_t, i_t, denom_t, m_t) from mlstm_pre_kernel
   float* h;               // [B*T, inner] out
+  float* pw = nullptr;    // [B, NH, T, kLazyWT] window scores: only for geometries with several column slices per head
   const uint8_t* reset;   // [B] or null
   int B, T, NH, DH;
   int phase, period;      // env b folds when (phase + b) % period == 0 (staggered), or when the window would overflow
@@ -179,6 +180,10 @@ struct MlstmLazyArgs {
 };
 void launch_mlstm_lazy_fold(const MlstmLazyArgs& a, hipStream_t stream);
 void launch_mlstm_lazy_cell(const MlstmLazyArgs& a, hipStream_t stream);
+// one column slice per head (DH 128 / 256): the cell kernel computes the window scores and the bookkeeping itself;
+// otherwise launch_mlstm_lazy_book must run before it (fills a.pw, coef_out, g_out, count_out)
+bool mlstm_lazy_fused_scores(int DH);
+void launch_mlstm_lazy_book(const MlstmLazyArgs& a, hipStream_t stream);
 bool mlstm_lazy_supported(int DH, int T);
 // count[b] = 0, g[b, :] = 1 for masked envs (mask == nullptr: all), both parities handled by the caller
 void launch_mlstm_lazy_clear(int32_t* count, float* g, const uint8_t* mask, int B, int NH, hipStream_t stream);

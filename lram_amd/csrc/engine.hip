@@ -63,6 +63,7 @@ struct BlockState {
   DevBuf wk, wv;    // [B, NH, W, DH] each
   DevBuf coef;      // [2][B, NH, W]
   DevBuf gsc;       // [2][B, NH]
+  DevBuf pw;        // [B, NH, 4, kLazyWT] window scores (head dims with several column slices per head only)
 };
 
 struct GraphKey {
@@ -190,6 +191,7 @@ struct lram_engine {
       s.wv.release();
       s.coef.release();
       s.gsc.release();
+      s.pw.release();
     }
     LZ_COUNT.release();
     lazy_ready = false;
@@ -473,6 +475,10 @@ void lazy_alloc(lram_engine* e) {
     s.wv.alloc(B * NH * kLazyWindow * DH);
     s.coef.alloc(2 * B * NH * kLazyWindow);
     s.gsc.alloc(2 * B * NH);
+    if (!mlstm_lazy_fused_scores((int)DH)) {
+      s.pw.alloc(B * NH * 4 * kLazyWT);
+      s.pw.zero();
+    }
     s.coef.zero();
   }
   e->LZ_COUNT.alloc(2 * B);
@@ -518,6 +524,7 @@ MlstmLazyArgs lazy_args(lram_engine* e, int i, int T, const uint8_t* reset, int 
   a.g_out = st.gsc.p + (out * B + b0) * NH;
   a.count_in = reinterpret_cast<const int32_t*>(e->LZ_COUNT.p) + in * B + b0;
   a.count_out = reinterpret_cast<int32_t*>(e->LZ_COUNT.p) + out * B + b0;
+  a.pw = st.pw.p ? st.pw.p + (size_t)b0 * NH * T * kLazyWT : nullptr;
   a.reset = reset ? reset + b0 : nullptr;
   a.B = nb, a.T = T, a.NH = (int)NH, a.DH = (int)DH;
   // the fold phase is taken relative to the env's global index, so slices fold the same envs as the whole batch
@@ -712,6 +719,10 @@ void join_slices(lram_engine* e, const std::vector<Slice>& sl, hipStream_t hbm, 
 }
 
 // ---- mLSTM block, split at the cell kernel -----------------------------------------------------------
+// proj_up in two halves pays from 2048 env slots (measured at 16M: 4096 slots 370k -> 374k env-steps/s, 1024 slots 292k
+// -> 287k, 32 slots 45.4k -> 40.0k: below that the extra launch costs more than the shorter critical path gives)
+bool split_up_now(const lram_engine* e) { return e->split_up && e->B >= 2048 && !e->graph_mode; }
+
 void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl) {
   const lram_config& c = e->cfg;
   const int D = c.d_model, inner = c.inner, NH = c.n_heads, rows = sl.nb * T;
@@ -723,7 +734,7 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   // z half is only needed by the output gate after the state pass and is issued beside it (mlstm_up_z)
   GemmArgs up;
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p + r0 * e->ucols, up.ldc = 2 * inner;
-  up.m = rows, up.n = e->split_up ? inner : 2 * inner, up.k = D;
+  up.m = rows, up.n = split_up_now(e) ? inner : 2 * inner, up.k = D;
   gemm(e, up, sl.s);
   MlstmPreArgs pa;
   pa.u = e->U.p + r0 * e->ucols, pa.conv_state = st.conv.p + b0 * c.conv_k * inner, pa.n_state = st.n.p + b0 * inner;
@@ -744,7 +755,7 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
 }
 
 void mlstm_up_z(lram_engine* e, int i, int T, const Slice& sl) {
-  if (!e->split_up) return;
+  if (!split_up_now(e)) return;
   const lram_config& c = e->cfg;
   const int D = c.d_model, inner = c.inner, rows = sl.nb * T;
   const size_t r0 = (size_t)sl.b0 * T;
@@ -936,6 +947,7 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
         // the read-only pass runs best with two workgroups per CU (one's prologue / epilogue under the other's
         // stream; 362k vs 308k env-steps/s at B = 4096 against the single-workgroup cap the read-modify-write kernel likes)
         la.min_lds_bytes = e->cell_lds_pad >= 0 ? e->cell_lds_pad : 0;
+        if (!mlstm_lazy_fused_scores(la.DH)) launch_mlstm_lazy_book(la, x.s);  // scores beside the front end
         stream_after(e, hbm, x.s);
         prof_record(e, hbm, true);
         launch_mlstm_lazy_cell(la, hbm);

@@ -158,6 +158,115 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
   }
 }
 
+constexpr int WT = kLazyWT;  // window + this step's tokens (row pitch of the score rows)
+
+// =============================================================================================
+// score (geometries with several column slices per head, where the cell kernel's own score computation would be
+// repeated by every slice): one workgroup per (env, head), on the slice's stream beside the front end:
+//   * bookkeeping after this step's T tokens (coefficients, scale, count) into the "out" side;
+//   * the window attention weights of this step, p[t][j] = c_{t,j} (q_t . khat_j), j over the pending window and
+//     this step's own tokens, written to `pw` [B, NH, T, kLazyWT] for the cell kernel.
+// =============================================================================================
+
+template <int T>
+__global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) {
+  extern __shared__ float qk[];  // qs [T][DH], ks [T][DH]
+  __shared__ float s_coef[W];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NH = a.NH, DH = a.DH, inner = NH * DH;
+  float* qs = qk;
+  float* ks = qk + T * DH;
+  const LazyView lv = lazy_view(a, b);
+  const int n = lv.n;
+  float f[T], ig[T], F[T];
+  float Fc = 1.f;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float4 s = *reinterpret_cast<const float4*>(a.scal + (((int64_t)b * T + t) * NH + h) * 4);
+    f[t] = s.x;
+    ig[t] = s.y;
+    Fc *= s.x;
+    F[t] = Fc;
+  }
+  const float sqrt_dh = sqrtf((float)DH);
+  for (int r = tid; r < DH; r += 256) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r;
+      qs[t * DH + r] = a.q[off];
+      ks[t * DH + r] = a.k[off] / sqrt_dh;
+    }
+  }
+  const int64_t base = ((int64_t)b * NH + h) * W;
+  if (tid < W) s_coef[tid] = tid < n ? a.coef_in[base + tid] : 0.f;
+  __syncthreads();
+  // ---- bookkeeping for the next step ----
+  if (tid < n) a.coef_out[base + tid] = s_coef[tid] * F[T - 1];
+  if (tid < T) {
+    float c = 1.f;
+#pragma unroll
+    for (int x = 0; x < T; ++x) {
+      if (x == tid) c *= ig[x];
+      if (x > tid) c *= f[x];
+    }
+    a.coef_out[base + n + tid] = c;
+  }
+  if (tid == 0) {
+    const float g = (lv.rs || lv.fold) ? 1.f : a.g_in[(int64_t)b * NH + h];
+    a.g_out[(int64_t)b * NH + h] = g * F[T - 1];
+    if (h == 0) a.count_out[b] = (n + T) | (lv.zero ? kZeroBit : 0);
+  }
+  // ---- p[t][j]: each wave takes four window rows at a time (their loads are issued together) ----
+  const float* wkb = a.wk + base * DH;
+  float* pwo = a.pw + (((int64_t)b * NH + h) * T) * WT;
+  for (int j0 = 4 * wave; j0 < n + T; j0 += 16) {
+    float p[4][T];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < T; ++t) p[i][t] = 0.f;
+    for (int r = lane; r < DH; r += 64) {
+      float kv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = j0 + i;
+        kv[i] = j < n ? wkb[(int64_t)j * DH + r] : (j < n + T ? ks[(j - n) * DH + r] : 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < T; ++t) p[i][t] += qs[t * DH + r] * kv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = j0 + i;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float s = wave_sum(p[i][t]);
+        if (lane == 0 && j < n + T) {
+          float c;
+          if (j < n) {
+            c = s_coef[j] * F[t];
+          } else {
+            const int u = j - n;  // this step's token u reaches t >= u with i_u f_{u+1} .. f_t
+            c = 0.f;
+            if (u <= t) {
+              c = 1.f;
+#pragma unroll
+              for (int x = 0; x < T; ++x) {
+                if (x == u) c *= ig[x];
+                if (x > u && x <= t) c *= f[x];
+              }
+            }
+          }
+          pwo[t * WT + j] = c * s;
+        }
+      }
+    }
+  }
+}
+
 // =============================================================================================
 // cell: read-only pass over C_base + the window terms + the step's bookkeeping.  One workgroup per (env, head, column
 // slice); thread c of the slice owns column c of the window's V rows, fetched into registers before the pass over
@@ -170,7 +279,6 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
 // Column slice 0 also appends the step's T tokens to the window and writes the bookkeeping of the next step
 // (coefficients, scale, pending count) into the "out" side.
 // =============================================================================================
-constexpr int WT = kLazyWT;  // window + this step's tokens (row pitch of the score rows in LDS)
 constexpr int kRowsPerWave = (W + 4 + 3) / 4;
 
 template <int T, int LPR, int UNR, int KPL>
@@ -218,7 +326,12 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   }
   const int64_t base = ((int64_t)b * NH + h) * W;
   if (tid < W) s_coef[tid] = tid < n ? a.coef_in[base + tid] : 0.f;
-  for (int idx = tid; idx < T * WT; idx += 256) pw[idx] = 0.f;
+  if (KPL < 0) {  // scores and bookkeeping come from mlstm_lazy_score_kernel
+    const float* pwi = a.pw + (((int64_t)b * NH + h) * T) * WT;
+    for (int idx = tid; idx < T * WT; idx += 256) pw[idx] = pwi[idx];
+  } else {
+    for (int idx = tid; idx < T * WT; idx += 256) pw[idx] = 0.f;
+  }
   // window V column of this thread (threads >= CW idle here): in flight during the pass over C_base
   const float* wvb = a.wv + (base * DH) + slice * CW + (tid < CW ? tid : 0);
   float vw[W];
@@ -231,6 +344,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   // window khat rows of this wave (rows wave, wave + 4, ...), KPL values per lane and row
   const float* wkb = a.wk + base * DH;
   float kreg[KPL > 0 ? kRowsPerWave : 1][KPL > 0 ? KPL : 1];
+  (void)kreg;
   if (KPL > 0) {
 #pragma unroll
     for (int i = 0; i < kRowsPerWave; ++i) {
@@ -280,7 +394,8 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
     }
     return c;
   };
-  if (KPL > 0) {
+  if (KPL < 0) {
+  } else if (KPL > 0) {
 #pragma unroll
     for (int i = 0; i < kRowsPerWave; ++i) {
       const int j = wave + 4 * i;
@@ -363,6 +478,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   if (slice == 0) {
     float* wko = a.wk + (base + n) * DH;
     for (int idx = tid; idx < T * DH; idx += 256) wko[idx] = ks[idx];
+    if (KPL < 0) return;
     // ---- bookkeeping for the next step ("out" side of the ping-pong) ----
     if (tid < n) a.coef_out[base + tid] = s_coef[tid] * F[T - 1];
     if (tid < T) {
@@ -423,8 +539,11 @@ void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
     if (T == 3 && unroll == 8) return launch_cell_tluk<T, 64, 8, 4>(a, s);
     return launch_cell_tluk<T, 64, 16, 4>(a, s);
   }
-  if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 16, 0>(a, s);
-  launch_cell_tluk<T, 32, 16, 0>(a, s);
+  if (a.DH == 128) return launch_cell_tluk<T, 32, 16, 0>(a, s);  // one column slice per head: fused scores
+  // several column slices per head: scores from mlstm_lazy_score_kernel (launch_mlstm_lazy_book)
+  LRAM_REQUIRE(a.pw != nullptr, "lazy mLSTM: missing score buffer");
+  if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 16, -1>(a, s);
+  launch_cell_tluk<T, 32, 16, -1>(a, s);
 }
 
 }  // namespace
@@ -442,6 +561,22 @@ void launch_mlstm_lazy_fold(const MlstmLazyArgs& a_in, hipStream_t stream) {
   }
   const long nwg = envs * a.NH * (a.DH / kFC) * (a.DH / kFR);
   hipLaunchKernelGGL(mlstm_lazy_fold_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, a);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+bool mlstm_lazy_fused_scores(int DH) { return DH == 256 || DH == 128; }
+
+void launch_mlstm_lazy_book(const MlstmLazyArgs& a, hipStream_t stream) {
+  LRAM_REQUIRE(a.T >= 1 && a.T <= 4, "lazy mLSTM: 1..4 tokens per step");
+  LRAM_REQUIRE(a.pw != nullptr, "lazy mLSTM: missing score buffer");
+  dim3 grid(a.NH, a.B), block(256);
+  const size_t shmem = sizeof(float) * 2 * a.T * a.DH;
+  switch (a.T) {
+    case 1: hipLaunchKernelGGL(mlstm_lazy_score_kernel<1>, grid, block, shmem, stream, a); break;
+    case 2: hipLaunchKernelGGL(mlstm_lazy_score_kernel<2>, grid, block, shmem, stream, a); break;
+    case 3: hipLaunchKernelGGL(mlstm_lazy_score_kernel<3>, grid, block, shmem, stream, a); break;
+    default: hipLaunchKernelGGL(mlstm_lazy_score_kernel<4>, grid, block, shmem, stream, a); break;
+  }
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

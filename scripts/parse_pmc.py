@@ -13,7 +13,7 @@ import sys
 
 out_dir, tag, batch = sys.argv[1], sys.argv[2], int(sys.argv[3])
 n_micro = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # env slices per step: one launch covers batch / n_micro envs
-KERNELS = {"cell": ("mlstm_cell_kernel", "mlstm_lazy_cell_kernel", "mamba_ssm_kernel"), "copy": ("stream_copy_kernel",),
+KERNELS = {"cell": ("mlstm_cell_kernel", "mlstm_lazy_cell_kernel", "mamba_ssm_kernel"), "copy": ("stream_copy",),
            "fold": ("mlstm_lazy_fold_kernel",)}
 res = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -61,6 +61,7 @@ if fetch_cell is not None and write_cell is not None:
         summary["calibration_stream_copy"] = {"fetch_reported_over_true": fetch_copy * 1024 / GiB,
                                               "write_reported_over_true": write_copy * 1024 / GiB}
 os.makedirs("profiles", exist_ok=True)
-path = f"profiles/r01_cell_kernel_hbm_traffic{'' if tag == 'xlstm_16m' else '_' + tag}{'_lazy' if lazy else ''}.json"
+rnd = os.environ.get("PMC_ROUND", "r02")
+path = f"profiles/{rnd}_cell_kernel_hbm_traffic{'' if tag == 'xlstm_16m' else '_' + tag}{'_lazy' if lazy else ''}.json"
 json.dump(summary, open(path, "w"), indent=1)
 print(json.dumps(summary, indent=1))
