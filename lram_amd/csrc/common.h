@@ -76,8 +76,9 @@ void launch_split_bf16x3(const float* w, uint16_t* out, size_t n, hipStream_t st
 // normalisation / elementwise
 // ---------------------------------------------------------------------------------------------
 // out[r, :] = norm(in[r, :]) * gamma (+ beta);  rms != 0 -> RMSNorm (no mean subtraction).
+// (out2: optional second copy of the result, same row stride as out)
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
-                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream);
+                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2 = nullptr);
 // Mamba block entry: res_out = hidden (+ res_in);  normed = RMSNorm(res_out) * gamma.
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
                          const float* gamma, int rows, int d, float eps, hipStream_t stream);

@@ -1257,10 +1257,9 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
         launch_embed_scalars(Xj, rtg + b0 * L + l + j, rew + b0 * L + l + j, L, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew,
                              x.nb, Tc, D, x.s);
       }
-      launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s);
-      if (L == 1 && e->B <= kTokenTapMaxBatch)  // taps (lram_get_taps) are defined for single env-steps
-        LRAM_HIP_CHECK(hipMemcpyAsync(e->TOK.p + r0 * D, X, sizeof(float) * (size_t)x.nb * Tc * D,
-                                      hipMemcpyDeviceToDevice, x.s));
+      // embed_ln in place; single env-steps of small batches also keep a copy for lram_get_taps (written by the same launch)
+      launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s,
+                      (L == 1 && e->B <= kTokenTapMaxBatch) ? e->TOK.p + r0 * D : nullptr);
     }
     run_stack(e, Tc, l == 0 ? reset : nullptr, sl, hbm);
   }

@@ -19,7 +19,7 @@ constexpr int kNormMaxV = 8;  // float4 per lane: d <= 2048
 // RMSNorm: gamma * (x * rsqrt(mean(x^2) + eps)).
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t in_stride, float* out,
                                                        int64_t out_stride, const float* gamma, const float* beta,
-                                                       int rows, int d, float eps, int rms) {
+                                                       int rows, int d, float eps, int rms, float* out2) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
       o.w += bb.w;
     }
     *reinterpret_cast<float4*>(dst + 4 * i) = o;
+    if (out2 != nullptr) *reinterpret_cast<float4*>(out2 + (int64_t)row * out_stride + 4 * i) = o;  // second copy (taps)
   }
 }
 
@@ -275,10 +276,10 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* buf, const uint8_
 }  // namespace
 
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
-                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream) {
+                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "row norm: d must be a multiple of 4 and <= 2048");
   hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, in_stride, out, out_stride,
-                     gamma, beta, rows, d, eps, rms);
+                     gamma, beta, rows, d, eps, rms, out2);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
