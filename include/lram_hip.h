@@ -249,6 +249,11 @@ int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64
 int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                          int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                          int32_t k, void* stream);
+/* The same with the activation operand pre-split into three bf16 planes first (the form in which the engine's norm /
+ * gate / state-update kernels hand their results to the big projections): bit-identical to lram_gemm_bf16x3. */
+int32_t lram_gemm_bf16x3_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
+                         int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
+                         int32_t k, void* stream);
 /* Image observations: uint8 frames [batch, channels, height, width] -> state-token embeddings [batch, d_model]
  * through the IMPALA CNN (3 x [conv3x3 -> maxpool(3,2,1) -> 2 residual blocks], 16/32/32 channels, ReLU, flatten,
  * Linear, ReLU).  Replaces `self.embed_image(state.float() / 255)` (online_decision_transformer_model.py:523-526;

@@ -57,6 +57,10 @@ struct GemmArgs {
   // optional: W pre-split into three bf16 planes (hi, mid, lo), each laid out like w, `w3_plane` elements apart
   const uint16_t* w3 = nullptr;
   int64_t w3_plane = 0;
+  // optional: A pre-split by its producer into three bf16 planes laid out like a (row stride lda), `a3_plane` elements
+  // apart (bf16x3 kernel only; `a` may then be null)
+  const uint16_t* a3 = nullptr;
+  int64_t a3_plane = 0;
   // optional split-K workspace (un-batched GEMMs with few output tiles: skinny N or small M): partial [S][M][N]
   // slabs are written by S x tiles workgroups and summed, in fixed order, by a second tiny kernel (deterministic)
   float* splitk_ws = nullptr;
@@ -78,10 +82,13 @@ void launch_split_bf16x3(const float* w, uint16_t* out, size_t n, hipStream_t st
 // out[r, :] = norm(in[r, :]) * gamma (+ beta);  rms != 0 -> RMSNorm (no mean subtraction).
 // (out2: optional second copy of the result, same row stride as out)
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
-                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2 = nullptr);
+                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2 = nullptr,
+                     uint16_t* planes = nullptr, int64_t plane_stride = 0);  // planes: bf16x3 GEMM operand (row stride
+                                                                             // out_stride); out may then be null
 // Mamba block entry: res_out = hidden (+ res_in);  normed = RMSNorm(res_out) * gamma.
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
-                         const float* gamma, int rows, int d, float eps, hipStream_t stream);
+                         const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes = nullptr,
+                         int64_t plane_stride = 0);  // planes: `normed` as a bf16x3 GEMM operand (normed may be null)
 
 // ---------------------------------------------------------------------------------------------
 // front end / head
@@ -240,7 +247,9 @@ struct GroupNormArgs {
   const float* skip;   // mode 0
   const float* xa;     // mode 0 [rows, NH*DH]
   const float* u;      // mode 0 [rows, 2*NH*DH]
-  float* out;          // mode 0: g [rows, NH*DH]; mode 1: x [rows, NH*DH] (+=)
+  float* out;          // mode 0: g [rows, NH*DH] (may be null when planes are given); mode 1: x [rows, NH*DH] (+=)
+  uint16_t* planes = nullptr;  // mode 0: g as a bf16x3 GEMM operand (three planes, row stride NH*DH)
+  int64_t plane_stride = 0;
   int rows, NH, DH, mode;
   float eps;
 };
@@ -296,9 +305,11 @@ struct MambaSsmArgs {
   const float* A_log;   // [d_inner, N]
   const float* Dp;      // [d_inner]
   const float* xz;      // [B*T, 2*d_inner] (z at + d_inner)
-  float* y;             // [B*T, d_inner] out
+  float* y;             // [B*T, d_inner] out (may be null when y3 is given)
   const uint8_t* reset;
   int B, T, d_inner, N, R;
+  uint16_t* y3 = nullptr;   // y as a bf16x3 GEMM operand: three planes [B*T, d_inner], y3_plane elements apart
+  int64_t y3_plane = 0;
 };
 void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream);
 

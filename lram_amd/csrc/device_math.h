@@ -27,4 +27,32 @@ __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// Exact 3-way bf16 split of an fp32 value, x = hi + mid + lo (the operand format of gemm_bf16x3.hip): producers that
+// feed a projection write these three planes instead of (or next to) the fp32 value, so the GEMM stages its A operand
+// with plain 16-byte copies.  p points at the element in plane 0; the planes are `plane` elements apart.
+__device__ __forceinline__ void split3_store(float x, uint16_t* p, int64_t plane) {
+  const __bf16 hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  const __bf16 mid = (__bf16)r1;
+  const __bf16 lo = (__bf16)(r1 - (float)mid);
+  p[0] = __builtin_bit_cast(uint16_t, hi);
+  p[plane] = __builtin_bit_cast(uint16_t, mid);
+  p[2 * plane] = __builtin_bit_cast(uint16_t, lo);
+}
+__device__ __forceinline__ void split3_store4(const float4& v, uint16_t* p, int64_t plane) {
+  const float xs[4] = {v.x, v.y, v.z, v.w};
+  uint16_t h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 hi = (__bf16)xs[e];
+    const float r1 = xs[e] - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const __bf16 lo = (__bf16)(r1 - (float)mid);
+    h[e] = __builtin_bit_cast(uint16_t, hi), m[e] = __builtin_bit_cast(uint16_t, mid), l[e] = __builtin_bit_cast(uint16_t, lo);
+  }
+  *reinterpret_cast<uint2*>(p) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+  *reinterpret_cast<uint2*>(p + plane) = make_uint2(m[0] | ((uint32_t)m[1] << 16), m[2] | ((uint32_t)m[3] << 16));
+  *reinterpret_cast<uint2*>(p + 2 * plane) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+}
+
 }  // namespace lram

@@ -123,6 +123,12 @@ struct lram_engine {
   int B = 0;
   std::vector<BlockState> st;
   DevBuf X, XN, TOK, HID, U, Q, K, V, XA, H, G, SCAL, RY, LOGITS, RES, DTP;
+  // bf16x3 operand planes written by the producers of the big projections' A operands (row norm -> proj_up / in_proj,
+  // output gate -> proj_down, selective state update -> out_proj): three planes each, `*_plane` elements apart
+  uint16_t *XN3 = nullptr, *G3 = nullptr;
+  size_t xn3_plane = 0, g3_plane = 0;
+  bool use_a3 = false;               // LRAM_GEMM_A3=1: producers write pre-split operand planes (measured 1-2 % slower
+                                     // than splitting on the fly in the GEMM: 16M 372k vs 379k, Mamba-48M 316k vs 322k)
   DevBuf GATES, AMAT, VEC;           // chunkwise mLSTM prefill work buffers (allocated with the first long chunk)
   int tok_cap = 0;                   // tokens per env the activation workspace holds (kMaxTokens until a prefill grows it)
   bool chunk_prefill = true;         // LRAM_PREFILL_CHUNK=0: keep the token-sequential kernels for prefill
@@ -212,6 +218,9 @@ struct lram_engine {
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
                       &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T})
       b->release();
+    if (XN3) (void)hipFree(XN3);
+    if (G3) (void)hipFree(G3);
+    XN3 = G3 = nullptr;
     img_cap = 0;
     B = 0;
     tok_cap = 0;
@@ -275,6 +284,7 @@ void validate_config(const lram_config& c) {
 
 void make_split(lram_engine* e, const float* w, size_t n);
 void persist_prepare(lram_engine* e);
+bool a3_for(const lram_engine* e, const float* w, int rows, int k, int64_t lda);
 
 void finalize(lram_engine* e) {
   const lram_config& c = e->cfg;
@@ -441,6 +451,16 @@ void alloc_workspace(lram_engine* e, int tokens) {
       e->AMAT.alloc(B * c.n_heads * kChunkMaxTokens * kChunkMaxTokens);
       e->VEC.alloc(B * c.n_heads * 3 * kChunkMaxTokens);
     }
+  }
+  // operand planes of the big projections
+  if (e->XN3) (void)hipFree(e->XN3);
+  if (e->G3) (void)hipFree(e->G3);
+  e->XN3 = e->G3 = nullptr;
+  if (e->use_a3 && e->use_bf16x3) {
+    e->xn3_plane = BT * D;
+    e->g3_plane = BT * (c.backbone == LRAM_BACKBONE_MAMBA ? (size_t)c.d_inner : e->icols);
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->XN3), 3 * e->xn3_plane * sizeof(uint16_t)));
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->G3), 3 * e->g3_plane * sizeof(uint16_t)));
   }
   e->tok_cap = tokens;
 }
@@ -630,7 +650,16 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
       }
     }
   }
+  LRAM_REQUIRE(g.a3 == nullptr, "gemm: a pre-split A operand was produced for a GEMM that does not take the bf16x3 kernel");
   launch_gemm_f32(g, s);
+}
+
+// Does the projection `rows x k` against weight w take the bf16x3 kernel with a pre-split A operand?  (Same conditions
+// as gemm() uses to pick that kernel: the producer then writes planes instead of fp32.)
+bool a3_for(const lram_engine* e, const float* w, int rows, int k, int64_t lda) {
+  if (!e->use_a3 || !e->use_bf16x3 || e->XN3 == nullptr || rows <= 8 || (k & 7) != 0 || (lda & 7) != 0) return false;
+  auto it = e->split.upper_bound(w);
+  return it != e->split.begin() && (--it, w < it->first + it->second.n);
 }
 
 void make_split(lram_engine* e, const float* w, size_t n) {
@@ -744,12 +773,15 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   const size_t r0 = (size_t)sl.b0 * T, b0 = sl.b0;
   const BlockWeights& w = e->bw[i];
   BlockState& st = e->st[i];
-  launch_row_norm(e->X.p + r0 * D, D, e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps, c.norm_is_rms, sl.s);
+  const bool a3 = a3_for(e, w.proj_up, rows, D, D);  // the norm then writes the GEMM's operand planes, no fp32 copy
+  launch_row_norm(e->X.p + r0 * D, D, a3 ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
+                  c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane);
   // proj_up in two halves: the x_m half feeds the conv / q / k / v front end and is on the block's critical path; the
   // z half is only needed by the output gate after the state pass and is issued beside it (mlstm_up_z)
   GemmArgs up;
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p + r0 * e->ucols, up.ldc = 2 * inner;
   up.m = rows, up.n = split_up_now(e) ? inner : 2 * inner, up.k = D;
+  if (a3) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
   gemm(e, up, sl.s);
   MlstmPreArgs pa;
   pa.u = e->U.p + r0 * e->ucols, pa.conv_state = st.conv.p + b0 * c.conv_k * inner, pa.n_state = st.n.p + b0 * inner;
@@ -777,6 +809,7 @@ void mlstm_up_z(lram_engine* e, int i, int T, const Slice& sl) {
   GemmArgs up;
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = e->bw[i].proj_up + (size_t)inner * D, up.ldw = D;
   up.c = e->U.p + r0 * e->ucols + inner, up.ldc = 2 * inner, up.m = rows, up.n = inner, up.k = D;
+  if (a3_for(e, e->bw[i].proj_up, rows, D, D)) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
   gemm(e, up, sl.s);
 }
 
@@ -812,11 +845,14 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
   ga.h = e->H.p + r0 * e->icols, ga.gamma = w.on_g, ga.beta = w.on_b, ga.skip = w.skip, ga.xa = e->XA.p + r0 * e->icols;
   ga.u = e->U.p + r0 * e->ucols, ga.out = e->G.p + r0 * e->icols, ga.rows = rows, ga.NH = NH, ga.DH = DH, ga.mode = 0;
   ga.eps = c.ln_eps;
+  const bool a3 = a3_for(e, w.proj_down, rows, inner, inner);
+  if (a3) ga.out = nullptr, ga.planes = e->G3 + r0 * e->icols, ga.plane_stride = (int64_t)e->g3_plane;
   launch_group_norm(ga, sl.s);
   float* X = e->X.p + r0 * D;
   GemmArgs dn;
   dn.a = e->G.p + r0 * e->icols, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
   dn.m = rows, dn.n = D, dn.k = inner;
+  if (a3) dn.a3 = e->G3 + r0 * e->icols, dn.a3_plane = (int64_t)e->g3_plane;
   gemm(e, dn, sl.s);
 }
 
@@ -1010,8 +1046,10 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   // only layer 0 starts the episode from an empty state
   const uint8_t* rs = (reset && !(e->compat_stale && i > 0)) ? reset + b0 : nullptr;
   hipStream_t gs = sl.s;
+  const bool a3_in = a3_for(e, w.in_proj, rows, D, D), a3_out = a3_for(e, w.out_proj, rows, di, di);
   if (stage == 0) {
-    launch_add_rms_norm(X, i == 0 ? nullptr : RES, RES, XN, w.norm_g, rows, D, c.norm_eps, sl.s);
+    launch_add_rms_norm(X, i == 0 ? nullptr : RES, RES, a3_in ? nullptr : XN, w.norm_g, rows, D, c.norm_eps, sl.s,
+                        a3_in ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane);
   } else if (stage == 1) {
     MambaConvArgs ca;
     ca.xz = U, ca.conv_state = st.conv.p + b0 * di * c.d_conv, ca.conv_w = w.conv_w, ca.conv_b = w.conv_b, ca.xc = XA;
@@ -1022,6 +1060,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     sa.ssm_state = st.s0.p + b0 * di * N, sa.xc = XA, sa.dtp = DTP, sa.dt_bias = w.dt_bias, sa.xdb = Q;
     sa.A_log = w.A_log, sa.Dp = w.Dp, sa.xz = U, sa.y = H, sa.reset = rs;
     sa.B = sl.nb, sa.T = T, sa.d_inner = di, sa.N = N, sa.R = R;
+    if (a3_out) sa.y = nullptr, sa.y3 = e->G3 + r0 * di, sa.y3_plane = (int64_t)e->g3_plane;
     prof_record(e, sl.s, true);
     launch_mamba_ssm(sa, sl.s);
     prof_record(e, sl.s, false);
@@ -1030,6 +1069,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     GemmArgs in;
     in.a = XN, in.lda = D, in.w = w.in_proj, in.ldw = D, in.c = U, in.ldc = 2 * di, in.bias = w.in_proj_b;
     in.m = rows, in.n = 2 * di, in.k = D;
+    if (a3_in) in.a3 = e->XN3 + r0 * D, in.a3_plane = (int64_t)e->xn3_plane;
     gemm(e, in, gs);
   } else if (stage == 1) {
     GemmArgs xp;
@@ -1044,6 +1084,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     GemmArgs op;
     op.a = H, op.lda = di, op.w = w.out_proj, op.ldw = di, op.c = X, op.ldc = D, op.bias = w.out_proj_b;
     op.m = rows, op.n = D, op.k = di;
+    if (a3_out) op.a3 = e->G3 + r0 * di, op.a3_plane = (int64_t)e->g3_plane;
     gemm(e, op, gs);
   }
 }
@@ -1354,6 +1395,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     }
     if (const char* v = std::getenv("LRAM_PERSISTENT")) e->persist_mode = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_PERSIST_WGS")) e->persist_wgs = std::max(8, std::min(256, std::atoi(v)));
+    if (const char* v = std::getenv("LRAM_GEMM_A3")) e->use_a3 = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SPLIT_UP")) e->split_up = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
@@ -1743,6 +1785,32 @@ int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, in
       g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
       g.residual = accumulate ? dev_c : nullptr;
       g.m = m, g.n = n, g.k = k, g.w3 = planes, g.w3_plane = (int64_t)numel;
+      launch_gemm_bf16x3(g, s);
+      LRAM_HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      (void)hipFree(planes);
+      throw;
+    }
+    (void)hipFree(planes);
+  });
+}
+
+int32_t lram_gemm_bf16x3_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
+                                  const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(ldw == k && lda == k, "lram_gemm_bf16x3_presplit: A and W must be contiguous [m, k] / [n, k]");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nw = (size_t)n * k, na = (size_t)m * k;
+    uint16_t* planes = nullptr;
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&planes), 3 * (nw + na) * sizeof(uint16_t)));
+    try {
+      launch_split_bf16x3(dev_w, planes, nw, s);
+      launch_split_bf16x3(dev_a, planes + 3 * nw, na, s);  // what a producer kernel writes with split3_store
+      GemmArgs g;
+      g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
+      g.residual = accumulate ? dev_c : nullptr;
+      g.m = m, g.n = n, g.k = k, g.w3 = planes, g.w3_plane = (int64_t)nw;
+      g.a3 = planes + 3 * nw, g.a3_plane = (int64_t)na;
       launch_gemm_bf16x3(g, s);
       LRAM_HIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {

@@ -35,7 +35,10 @@ __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16&
   lo = (__bf16)r2;
 }
 
-template <bool HAS_BIAS, bool HAS_RES>
+// A_PRE: the activation operand arrives pre-split (three bf16 planes written by its producer, g.a3): staged like W with
+// 16-byte loads and conflict-free 16-byte LDS writes, no fp32 -> 3 x bf16 conversion (about a quarter of a wave's
+// instruction stream per K step) and no 8-byte plane writes in the loop.
+template <bool HAS_BIAS, bool HAS_RES, bool A_PRE>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_ELEMS];
   __bf16* As = lds;               // [3][128][PITCH]
@@ -50,6 +53,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   const int z1 = z / g.nb2, z2 = z - z1 * g.nb2;
   const float* A = g.a + z1 * g.sA1 + z2 * g.sA2;
   const __bf16* W3 = reinterpret_cast<const __bf16*>(g.w3) + z1 * g.sW1 + z2 * g.sW2;
+  const __bf16* A3 = A_PRE ? reinterpret_cast<const __bf16*>(g.a3) + z1 * g.sA1 + z2 * g.sA2 : nullptr;
   float* C = g.c + z1 * g.sC1 + z2 * g.sC2;
   const float* R = HAS_RES ? g.residual + z1 * g.sC1 + z2 * g.sC2 : nullptr;
   const float* bias = HAS_BIAS ? g.bias + z1 * g.sBias1 + z2 * g.sBias2 : nullptr;
@@ -66,14 +70,28 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   // staging registers: A 4 x float4 (fp32), W 6 x 16 B (bf16 planes)
   const int lr = tid >> 3;        // A: row within a 32-row slab
   const int lc = (tid & 7) << 2;  // A: k offset 0,4,..,28
-  float4 ra[4];
+  float4 ra[A_PRE ? 1 : 4];
+  uint4 rap[A_PRE ? 6 : 1];
   uint4 rw[6];
   auto load_tile = [&](int k0) {
+    if (A_PRE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gm = m0 + lr + 32 * i, kk = k0 + lc;
-      ra[i] = (gm < g.m && kk < g.k) ? *reinterpret_cast<const float4*>(A + (int64_t)gm * g.lda + kk)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < 6; ++j) {
+        const int q = tid + 256 * j;          // 16-byte chunk id: 3 planes x 128 rows x 4 chunks
+        const int plane = q >> 9, rem = q & 511;
+        const int r = rem >> 2, c = (rem & 3) << 3;
+        const int gm = m0 + r, kk = k0 + c;
+        rap[j] = (gm < g.m && kk < g.k)
+                     ? *reinterpret_cast<const uint4*>(A3 + (int64_t)plane * g.a3_plane + (int64_t)gm * g.lda + kk)
+                     : make_uint4(0u, 0u, 0u, 0u);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + lr + 32 * i, kk = k0 + lc;
+        ra[i] = (gm < g.m && kk < g.k) ? *reinterpret_cast<const float4*>(A + (int64_t)gm * g.lda + kk)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -87,8 +105,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     }
   };
   auto store_tile = [&]() {
+    if (A_PRE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int j = 0; j < 6; ++j) {
+        const int q = tid + 256 * j;
+        const int plane = q >> 9, rem = q & 511;
+        const int r = rem >> 2, c = (rem & 3) << 3;
+        *reinterpret_cast<uint4*>(As + plane * PLANE + r * PITCH + c) = rap[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (A_PRE ? 0 : 4); ++i) {
       bf16x4 hi, mid, lo;
       const float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
 #pragma unroll
@@ -225,14 +252,25 @@ void launch_gemm_bf16x3(const GemmArgs& g_in, hipStream_t stream) {
   dim3 grid(tiles, g.nb1 * g.nb2, S);
   dim3 block(256);
   const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
-  if (hb && hr)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, block, 0, stream, g);
+  if (g.a3 != nullptr) {
+    LRAM_REQUIRE((g.lda & 7) == 0 && (g.a3_plane & 7) == 0 && ((g.sA1 | g.sA2) & 7) == 0,
+                 "gemm bf16x3: pre-split A needs lda / plane stride / batch strides in multiples of 8");
+    if (hb && hr)
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, true>), grid, block, 0, stream, g);
+    else if (hb)
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, true>), grid, block, 0, stream, g);
+    else if (hr)
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, true>), grid, block, 0, stream, g);
+    else
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, true>), grid, block, 0, stream, g);
+  } else if (hb && hr)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, false>), grid, block, 0, stream, g);
   else if (hb)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, false>), grid, block, 0, stream, g);
   else if (hr)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, false>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, false>), grid, block, 0, stream, g);
   LRAM_HIP_CHECK(hipGetLastError());
   if (S > 1) launch_splitk_reduce(g, stream);
 }

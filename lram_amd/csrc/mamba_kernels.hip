@@ -141,7 +141,12 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
   __syncthreads();
   for (int i = tid; i < ne * T * cpb; i += 256) {
     const int c = i % cpb, et = i / cpb;
-    if (dbase + c < di) a.y[((int64_t)b0 * T + et) * di + dbase + c] = yo[et / T][et % T][c];
+    if (dbase + c < di) {
+      const int64_t off = ((int64_t)b0 * T + et) * di + dbase + c;
+      const float yv = yo[et / T][et % T][c];
+      if (a.y != nullptr) a.y[off] = yv;
+      if (a.y3 != nullptr) split3_store(yv, a.y3 + off, a.y3_plane);
+    }
   }
 }
 

@@ -19,7 +19,8 @@ constexpr int kNormMaxV = 8;  // float4 per lane: d <= 2048
 // RMSNorm: gamma * (x * rsqrt(mean(x^2) + eps)).
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t in_stride, float* out,
                                                        int64_t out_stride, const float* gamma, const float* beta,
-                                                       int rows, int d, float eps, int rms, float* out2) {
+                                                       int rows, int d, float eps, int rms, float* out2,
+                                                       uint16_t* planes, int64_t plane_stride) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
       o.z += bb.z;
       o.w += bb.w;
     }
-    *reinterpret_cast<float4*>(dst + 4 * i) = o;
+    if (out != nullptr) *reinterpret_cast<float4*>(dst + 4 * i) = o;
     if (out2 != nullptr) *reinterpret_cast<float4*>(out2 + (int64_t)row * out_stride + 4 * i) = o;  // second copy (taps)
+    if (planes != nullptr) split3_store4(o, planes + (int64_t)row * out_stride + 4 * i, plane_stride);  // GEMM operand
   }
 }
 
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
 // res_out = hidden + res_in ; normed = res_out * rsqrt(mean(res_out^2) + eps) * gamma
 __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, const float* res_in, float* res_out,
                                                            float* normed, const float* gamma, int rows, int d,
-                                                           float eps) {
+                                                           float eps, uint16_t* planes, int64_t plane_stride) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, 
     o.y = v[j].y * rstd * g.y;
     o.z = v[j].z * rstd * g.z;
     o.w = v[j].w * rstd * g.w;
-    *reinterpret_cast<float4*>(normed + base + 4 * i) = o;
+    if (normed != nullptr) *reinterpret_cast<float4*>(normed + base + 4 * i) = o;
+    if (planes != nullptr) split3_store4(o, planes + base + 4 * i, plane_stride);
   }
 }
 
@@ -276,18 +279,20 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* buf, const uint8_
 }  // namespace
 
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
-                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2) {
+                     const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2,
+                     uint16_t* planes, int64_t plane_stride) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "row norm: d must be a multiple of 4 and <= 2048");
   hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, in_stride, out, out_stride,
-                     gamma, beta, rows, d, eps, rms, out2);
+                     gamma, beta, rows, d, eps, rms, out2, planes, plane_stride);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
-                         const float* gamma, int rows, int d, float eps, hipStream_t stream) {
+                         const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes,
+                         int64_t plane_stride) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "rms norm: d must be a multiple of 4 and <= 2048");
   hipLaunchKernelGGL(add_rms_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, hidden, res_in, res_out,
-                     normed, gamma, rows, d, eps);
+                     normed, gamma, rows, d, eps, planes, plane_stride);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
       o.z += bb.z;
       o.w += bb.w;
     }
-    float* dst = a.out + (int64_t)row * D + hd;
+    float* dst = a.out != nullptr ? a.out + (int64_t)row * D + hd : nullptr;
     if (a.mode == 0) {
       const float4 sk = *reinterpret_cast<const float4*>(a.skip + hd);
       const float4 xa = *reinterpret_cast<const float4*>(a.xa + (int64_t)row * D + hd);
@@ -525,7 +525,8 @@ __global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
       o.y = (o.y + sk.y * xa.y) * silu_f(z.y);
       o.z = (o.z + sk.z * xa.z) * silu_f(z.z);
       o.w = (o.w + sk.w * xa.w) * silu_f(z.w);
-      *reinterpret_cast<float4*>(dst) = o;
+      if (a.out != nullptr) *reinterpret_cast<float4*>(dst) = o;
+      if (a.planes != nullptr) split3_store4(o, a.planes + (int64_t)row * D + hd, a.plane_stride);
     } else {
       float4 x = *reinterpret_cast<const float4*>(dst);
       x.x += o.x;

@@ -66,6 +66,21 @@ def test_gemm_bf16x3_matches_fp64(hip_lib, m, n, k):
     assert ((out2.cpu().double() - ref2).abs() / (scale + 1)).max().item() < 1.5 * e1 + 1e-7
 
 
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 80, 1536), (4096, 512, 1024), (257, 129, 48)])
+def test_gemm_bf16x3_presplit_operand_is_bit_identical(hip_lib, m, n, k):
+    """The projection kernel fed with pre-split A planes (what the norm / gate / state-update kernels write) gives
+    exactly the result of the on-the-fly split."""
+    from lram_amd.engine import gemm_f32
+    g = torch.Generator().manual_seed(m + n)
+    a = (torch.randn(m, k, generator=g) * torch.exp(torch.randn(m, 1, generator=g))).cuda()
+    w = torch.randn(n, k, generator=g).cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    ref = gemm_f32(a, w, bias, kernel="bf16x3")
+    out = gemm_f32(a, w, bias, kernel="bf16x3_presplit")
+    torch.cuda.synchronize()
+    assert torch.equal(ref, out)
+
+
 def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=2e-4, state_tol=2e-4, spec=None,
                 sd=None, cond_aware=False):
     """cond_aware: where the engine is further than the tolerance from the fp32 oracle, accept it if it is as close to
