@@ -22,7 +22,11 @@ PARITY PINNING STATUS
   end (``compute_inputs`` ... ``prepare_inputs_and_masks``), the head post-processing
   (``prepare_action_logits`` / ``get_action_from_logits``), the ImpalaCNN block modules and
   the DMControl / Mimicgen full-space observation mapping.  ``oracle.dt_ref`` is pinned
-  against them (tests/test_oracle_golden.py).
+  against them (tests/test_oracle_golden.py).  Round 2 added the Mamba agent's control flow
+  (``DiscreteDecisionMamba.get_action_pred`` + ``InferenceParams.reset`` + ``MambaEncoder.forward``
+  executed over two envs x two episodes; ``OraclePolicy(mamba_repeat=..., stale_state=True)``
+  reproduces the returned actions exactly) and the checkpoint key handling of
+  ``load_model_weights`` (checked by tests/test_config_weights.py against lram_amd.weights).
 * The recurrent arithmetic itself lives in third-party, un-vendored packages that
   are NOT under /root/reference and NOT installed here: ``xlstm`` (unpinned,
   reference README.md:94-97, API of 1.0.x), ``mamba_ssm==2.1.0``,
