@@ -12,6 +12,7 @@
 // W is split once when the weights are finalised (three [N,K] bf16 planes); A is split on the fly while its
 // fp32 tile is staged into LDS.  Tiling as gemm_f32.hip: 128 x 128 x 32 block tile, 4 waves, 64 x 64 per wave.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -22,10 +23,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BN = 128, BK = 32;
 constexpr int PITCH = 40;                 // bf16 elements per LDS row (80 B: conflict-free ds_read_b128)
-constexpr int PLANE = BM * PITCH;         // elements per (128-row) plane
-constexpr int LDS_ELEMS = 6 * PLANE;      // A: 3 planes, W: 3 planes  (61,440 B)
+constexpr int PLANE = BN * PITCH;         // elements per 128-row plane (W; A when BM = 128)
 
 __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
   hi = (__bf16)x;
@@ -38,11 +38,17 @@ __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16&
 // A_PRE: the activation operand arrives pre-split (three bf16 planes written by its producer, g.a3): staged like W with
 // 16-byte loads and conflict-free 16-byte LDS writes, no fp32 -> 3 x bf16 conversion (about a quarter of a wave's
 // instruction stream per K step) and no 8-byte plane writes in the loop.
-template <bool HAS_BIAS, bool HAS_RES, bool A_PRE>
+// BM = 128: 64 x 64 per wave (2 x 2 MFMA tiles).  BM = 64: 32 x 64 per wave -- twice the workgroups for outputs with few
+// 128-wide column tiles (proj_down, out_proj, ffn_down: N = 512 .. 1280 gives 192 .. 290 tiles of 128 x 128 for 512
+// workgroup slots), 46 KB of LDS instead of 61 KB.
+template <bool HAS_BIAS, bool HAS_RES, bool A_PRE, int BM>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[LDS_ELEMS];
-  __bf16* As = lds;               // [3][128][PITCH]
-  __bf16* Bs = lds + 3 * PLANE;   // [3][128][PITCH]
+  constexpr int WM = BM / 2;          // rows per wave
+  constexpr int TI = WM / 32;         // MFMA row tiles per wave
+  constexpr int APLANE = BM * PITCH;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[3 * APLANE + 3 * PLANE];
+  __bf16* As = lds;                // [3][BM][PITCH]
+  __bf16* Bs = lds + 3 * APLANE;   // [3][128][PITCH]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -70,15 +76,17 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   // staging registers: A 4 x float4 (fp32), W 6 x 16 B (bf16 planes)
   const int lr = tid >> 3;        // A: row within a 32-row slab
   const int lc = (tid & 7) << 2;  // A: k offset 0,4,..,28
-  float4 ra[A_PRE ? 1 : 4];
-  uint4 rap[A_PRE ? 6 : 1];
+  constexpr int NA = BM / 32;          // fp32 A: float4 per thread and K tile
+  constexpr int NAP = 3 * BM * 4 / 256;  // pre-split A: 16-byte chunks per thread and K tile
+  float4 ra[A_PRE ? 1 : NA];
+  uint4 rap[A_PRE ? NAP : 1];
   uint4 rw[6];
   auto load_tile = [&](int k0) {
     if (A_PRE) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const int q = tid + 256 * j;          // 16-byte chunk id: 3 planes x 128 rows x 4 chunks
-        const int plane = q >> 9, rem = q & 511;
+      for (int j = 0; j < NAP; ++j) {
+        const int q = tid + 256 * j;          // 16-byte chunk id: 3 planes x BM rows x 4 chunks
+        const int plane = q / (BM * 4), rem = q % (BM * 4);
         const int r = rem >> 2, c = (rem & 3) << 3;
         const int gm = m0 + r, kk = k0 + c;
         rap[j] = (gm < g.m && kk < g.k)
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NA; ++i) {
         const int gm = m0 + lr + 32 * i, kk = k0 + lc;
         ra[i] = (gm < g.m && kk < g.k) ? *reinterpret_cast<const float4*>(A + (int64_t)gm * g.lda + kk)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -107,15 +115,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   auto store_tile = [&]() {
     if (A_PRE) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
+      for (int j = 0; j < NAP; ++j) {
         const int q = tid + 256 * j;
-        const int plane = q >> 9, rem = q & 511;
+        const int plane = q / (BM * 4), rem = q % (BM * 4);
         const int r = rem >> 2, c = (rem & 3) << 3;
-        *reinterpret_cast<uint4*>(As + plane * PLANE + r * PITCH + c) = rap[j];
+        *reinterpret_cast<uint4*>(As + plane * APLANE + r * PITCH + c) = rap[j];
       }
     }
 #pragma unroll
-    for (int i = 0; i < (A_PRE ? 0 : 4); ++i) {
+    for (int i = 0; i < (A_PRE ? 0 : NA); ++i) {
       bf16x4 hi, mid, lo;
       const float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
 #pragma unroll
@@ -128,8 +136,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
       }
       __bf16* dst = As + (lr + 32 * i) * PITCH + lc;
       *reinterpret_cast<bf16x4*>(dst) = hi;
-      *reinterpret_cast<bf16x4*>(dst + PLANE) = mid;
-      *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = lo;
+      *reinterpret_cast<bf16x4*>(dst + APLANE) = mid;
+      *reinterpret_cast<bf16x4*>(dst + 2 * APLANE) = lo;
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -140,9 +148,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   const int li = lane & 31;
   const int lh = lane >> 5;
   // lane (row li, half lh) holds k = 8*lh + j (j = 0..7) of a 16-deep MFMA step for both operands
-  const __bf16* a_base = As + (64 * wm + li) * PITCH + 8 * lh;
+  const __bf16* a_base = As + (WM * wm + li) * PITCH + 8 * lh;
   const __bf16* b_base = Bs + (64 * wn + li) * PITCH + 8 * lh;
 
   const int nk_all = (g.k + BK - 1) / BK;
@@ -164,16 +172,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     if (kt + 1 < nk) load_tile((kt + 1) * BK);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 af[2][3], bf[2][3];
+      bf16x8 af[TI][3], bf[2][3];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          af[t][p] = *reinterpret_cast<const bf16x8*>(a_base + p * PLANE + 32 * t * PITCH + 16 * ks);
+          if (t < TI) af[t][p] = *reinterpret_cast<const bf16x8*>(a_base + p * APLANE + 32 * t * PITCH + 16 * ks);
           bf[t][p] = *reinterpret_cast<const bf16x8*>(b_base + p * PLANE + 32 * t * PITCH + 16 * ks);
         }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           // smallest terms first
@@ -192,21 +200,21 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   if (g.split_k > 1) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
     float* S = g.splitk_ws + (int64_t)blockIdx.z * g.m * g.n;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int col = n0 + 64 * wn + 32 * j + li;
         if (col >= g.n) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int row = m0 + WM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (row < g.m) S[(int64_t)row * g.n + col] = acc[i][j][r];
         }
       }
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + 64 * wn + 32 * j + li;
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
       const float bv = HAS_BIAS ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = m0 + WM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < g.m) {
           float v = acc[i][j][r] + bv;
           if (HAS_RES) v += R[(int64_t)row * g.ldc + col];
@@ -243,34 +251,52 @@ bool gemm_bf16x3_supported(const GemmArgs& g) {
          ((g.sW1 | g.sW2) & 7) == 0 && ((g.sA1 | g.sA2) & 3) == 0 && (g.w3_plane & 7) == 0;
 }
 
+template <bool A_PRE, int BM>
+static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+  const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
+  dim3 block(256);
+  if (hb && hr)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, A_PRE, BM>), grid, block, 0, stream, g);
+  else if (hb)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, A_PRE, BM>), grid, block, 0, stream, g);
+  else if (hr)
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, A_PRE, BM>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, A_PRE, BM>), grid, block, 0, stream, g);
+}
+
 void launch_gemm_bf16x3(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
   const int S = gemm_choose_split_k(g);
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
   LRAM_REQUIRE(gemm_bf16x3_supported(g), "gemm bf16x3: K, ldw and W strides must be multiples of 8");
-  const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
+  const int tiles_n = (g.n + BN - 1) / BN;
+  const int tiles128 = ((g.m + 127) / 128) * tiles_n;
+  // Outputs with at most four 128-wide column tiles and fewer 128-row tiles than two per CU (16M proj_down / ffn_down:
+  // 192 tiles): 64-row tiles give twice the workgroups.  Measured standalone 67 -> 62 us (proj_down), 141 -> 101 us
+  // (206M proj_down), 131 -> 117 us (Mamba out_proj); inside the two-slice pipelines, where the other slice fills the
+  // chip anyway, only the narrow 16M shapes gain (+1 % end to end) while Mamba-48M and 206M lose 2.5 % to the smaller
+  // tile's lower reuse -- hence the tiles_n limit.  LRAM_GEMM_BM=64 / 128 forces one tile (measurement knob).
+  static const int force_bm = [] {
+    const char* v = std::getenv("LRAM_GEMM_BM");
+    return v ? std::atoi(v) : 0;
+  }();
+  const bool small = force_bm == 64 || (force_bm == 0 && S == 1 && g.nb1 * g.nb2 == 1 && tiles128 < 512 && tiles_n <= 4 &&
+                                        g.m > 64);
+  const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;
   dim3 grid(tiles, g.nb1 * g.nb2, S);
-  dim3 block(256);
-  const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
   if (g.a3 != nullptr) {
     LRAM_REQUIRE((g.lda & 7) == 0 && (g.a3_plane & 7) == 0 && ((g.sA1 | g.sA2) & 7) == 0,
                  "gemm bf16x3: pre-split A needs lda / plane stride / batch strides in multiples of 8");
-    if (hb && hr)
-      hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, true>), grid, block, 0, stream, g);
-    else if (hb)
-      hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, true>), grid, block, 0, stream, g);
-    else if (hr)
-      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, true>), grid, block, 0, stream, g);
+    if (small)
+      launch_bm<true, 64>(g, grid, stream);
     else
-      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, true>), grid, block, 0, stream, g);
-  } else if (hb && hr)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, false>), grid, block, 0, stream, g);
-  else if (hb)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, false>), grid, block, 0, stream, g);
-  else if (hr)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, false>), grid, block, 0, stream, g);
-  else
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, false>), grid, block, 0, stream, g);
+      launch_bm<true, 128>(g, grid, stream);
+  } else if (small) {
+    launch_bm<false, 64>(g, grid, stream);
+  } else {
+    launch_bm<false, 128>(g, grid, stream);
+  }
   LRAM_HIP_CHECK(hipGetLastError());
   if (S > 1) launch_splitk_reduce(g, stream);
 }
