@@ -113,6 +113,9 @@ struct lram_engine {
   bool lazy_ready = false;  // buffers allocated for the current batch
   int lazy_period = 13;
   bool split_up = true;     // LRAM_SPLIT_UP=0: proj_up as one GEMM ahead of the front end
+  int fold_bubbles = 2;     // LRAM_FOLD_BUBBLES=k: k folds before the first read pass, the rest behind the sLSTM block, all
+                            // on the state-pass stream (0 = folds on their own stream, one block ahead); measured on one
+                            // box: k = 0 364k, 1 367k, 2 368k, 3 367k, 4 366k env-steps/s
   bool fold_ahead = false;  // LRAM_FOLD_AHEAD=1: every fold queued at the step start (measured: no gain over one block ahead)
   int64_t lazy_step = 0;    // steps taken in lazy mode: fold phase and ping-pong parity
   std::vector<int> lazy_bound;  // host-side upper bound of pending tokens per fold class (b % period)
@@ -965,8 +968,24 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   // stream through HBM while the state pass has nothing to do -- the first front end of the step and the sLSTM
   // blocks -- instead of one block ahead of the cells, beside them.
   const bool fold_ahead = lazy && fs != hbm && e->fold_ahead;
+  // fold_bubbles: the folds go onto the state-pass stream itself, into the two stretches of a step where that stream has
+  // nothing to run -- before the first read pass (the step's front end and block 0's projections are still under way) and
+  // while both slices are inside an sLSTM block -- instead of beside the read passes, which they slow down.
+  const int fold_bubbles = (lazy && fs != hbm && !fold_ahead) ? e->fold_bubbles : 0;
+  std::vector<char> folded(c.n_blocks, 0);
+  auto launch_folds_on_hbm = [&](int i) {
+    MlstmLazyArgs la = lazy_args(e, i, T, reset, 0, e->B);
+    la.compact = e->lazy_compact ? 1 : 0;
+    prof_record(e, hbm, true, true);
+    launch_mlstm_lazy_fold(la, hbm);
+    prof_record(e, hbm, false, true);
+    folded[i] = 1;
+  };
   std::vector<hipEvent_t> fold_done(c.n_blocks, nullptr);
-  if (fold_ahead) {
+  if (fold_bubbles > 0) {
+    int k = 0;
+    for (int i = next_mlstm(-1); i >= 0 && k < fold_bubbles; i = next_mlstm(i), ++k) launch_folds_on_hbm(i);
+  } else if (fold_ahead) {
     for (int i = next_mlstm(-1); i >= 0; i = next_mlstm(i)) {
       launch_folds(i);
       fold_done[i] = record_on(e, fs);
@@ -977,9 +996,14 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   for (int i = 0; i < c.n_blocks; ++i) {
     if (c.block_is_slstm[i]) {
       for (const Slice& x : sl) slstm_block(e, i, T, reset, x);
+      if (fold_bubbles > 0)  // every fold still outstanding runs now, behind the previous block's read passes
+        for (int k = next_mlstm(i); k >= 0; k = next_mlstm(k))
+          if (!folded[k]) launch_folds_on_hbm(k);
       continue;
     }
-    if (fold_ahead) {
+    if (fold_bubbles > 0) {
+      if (!folded[i]) launch_folds_on_hbm(i);  // (stacks without an sLSTM block: one fold ahead of its read passes)
+    } else if (fold_ahead) {
       LRAM_HIP_CHECK(hipStreamWaitEvent(hbm, fold_done[i], 0));  // fold(i) done before cell(i)
     } else if (lazy) {
       stream_after(e, hbm, fs);  // fold(i) done before cell(i)
@@ -1398,6 +1422,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_GEMM_A3")) e->use_a3 = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SPLIT_UP")) e->split_up = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_FOLD_BUBBLES")) e->fold_bubbles = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
     *out = e.release();
   });
