@@ -129,6 +129,7 @@ struct MlstmPreArgs {
   float* scal;           // [B*T, NH, 4] out  (f_t, i_t, denom_t, m_t)
   const uint8_t* reset;  // [B] or null
   int B, T, inner, NH, K;
+  int lean = 0;          // 1: q, k, v are not written (the lazy read pass rebuilds them from xa / u); T <= 4 kernel only
   // chunkwise prefill (T > kMaxTokens) only, see mlstm_chunk.hip
   float* gates = nullptr;  // [B*T, NH, 2] out  raw (i~, f~) gate pre-activations
   float* amat = nullptr;   // [B, NH, 64, 64] out  intra-chunk weights A[t][s]
@@ -177,6 +178,9 @@ struct MlstmLazyArgs {
   const float* v;
   const float* scal;      // [B*T, NH, 4] (f_t, i_t, denom_t, m_t) from mlstm_pre_kernel
   float* h;               // [B*T, inner] out
+  // lean front end (fused-score geometries): q, k, v rebuilt here from xa (conv branch) and u's x half with the
+  // block-diagonal 4 x 4 weights, instead of being read back from HBM
+  const float *lean_xa = nullptr, *lean_u = nullptr, *lean_wq = nullptr, *lean_wk = nullptr, *lean_wv = nullptr;
   float* pw = nullptr;    // [B, NH, T, kLazyWT] window scores: only for geometries with several column slices per head
   const uint8_t* reset;   // [B] or null
   int B, T, NH, DH;

@@ -112,6 +112,7 @@ struct lram_engine {
   bool lazy = false;        // effective choice for the current batch (decided in state_alloc / set_state_mode)
   bool lazy_ready = false;  // buffers allocated for the current batch
   int lazy_period = 13;
+  bool lean_front = true;   // LRAM_LEAN_FRONT=0
   bool split_up = true;     // LRAM_SPLIT_UP=0: proj_up as one GEMM ahead of the front end
   int fold_bubbles = 2;     // LRAM_FOLD_BUBBLES=k: k folds before the first read pass, the rest behind the sLSTM block, all
                             // on the state-pass stream (0 = folds on their own stream, one block ahead); measured on one
@@ -768,6 +769,12 @@ void join_slices(lram_engine* e, const std::vector<Slice>& sl, hipStream_t hbm, 
 // ---- mLSTM block, split at the cell kernel -----------------------------------------------------------
 // proj_up in two halves pays from 2048 env slots (measured at 16M: 4096 slots 370k -> 374k env-steps/s, 1024 slots 292k
 // -> 287k, 32 slots 45.4k -> 40.0k: below that the extra launch costs more than the shorter critical path gives)
+// lean front end: the lazy read pass of the fused-score geometries rebuilds q, k, v itself (LRAM_LEAN_FRONT=0 keeps the
+// q / k / v round trip through HBM)
+bool lean_front(const lram_engine* e, int T) {
+  return e->lean_front && lazy_active(e, T) && mlstm_lazy_fused_scores(e->cfg.inner / e->cfg.n_heads);
+}
+
 bool split_up_now(const lram_engine* e) { return e->split_up && e->B >= 2048 && !e->graph_mode; }
 
 void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl) {
@@ -795,6 +802,7 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   pa.xa = e->XA.p + r0 * e->icols;
   pa.scal = e->SCAL.p + r0 * NH * 4, pa.reset = reset ? reset + b0 : nullptr;
   pa.B = sl.nb, pa.T = T, pa.inner = inner, pa.NH = NH, pa.K = c.conv_k;
+  pa.lean = lean_front(e, T) ? 1 : 0;
   if (T > kMaxTokens) {
     LRAM_REQUIRE(T <= e->tok_cap && e->AMAT.p != nullptr, "chunkwise prefill workspace not allocated");
     pa.gates = e->GATES.p + r0 * NH * 2;
@@ -1023,6 +1031,11 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
         // stream; 362k vs 308k env-steps/s at B = 4096 against the single-workgroup cap the read-modify-write kernel likes)
         la.min_lds_bytes = e->cell_lds_pad >= 0 ? e->cell_lds_pad : 0;
         if (!mlstm_lazy_fused_scores(la.DH)) launch_mlstm_lazy_book(la, x.s);  // scores beside the front end
+        if (lean_front(e, T)) {
+          const BlockWeights& w = e->bw[i];
+          la.lean_xa = e->XA.p + r0 * e->icols, la.lean_u = e->U.p + r0 * e->ucols;
+          la.lean_wq = w.wq, la.lean_wk = w.wk, la.lean_wv = w.wv;
+        }
         stream_after(e, hbm, x.s);
         prof_record(e, hbm, true);
         launch_mlstm_lazy_cell(la, hbm);
@@ -1419,6 +1432,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     }
     if (const char* v = std::getenv("LRAM_PERSISTENT")) e->persist_mode = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_PERSIST_WGS")) e->persist_wgs = std::max(8, std::min(256, std::atoi(v)));
+    if (const char* v = std::getenv("LRAM_LEAN_FRONT")) e->lean_front = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_A3")) e->use_a3 = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SPLIT_UP")) e->split_up = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;

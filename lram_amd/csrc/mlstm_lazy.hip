@@ -316,12 +316,21 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
     }
   }
   const float sqrt_dh = sqrtf((float)DH);
+  const bool lean = KPL >= 0 && a.lean_wq != nullptr;
+  auto bd_row = [](const float* w, const float4& x) { return w[0] * x.x + w[1] * x.y + w[2] * x.z + w[3] * x.w; };
   for (int r = tid; r < DH; r += 256) {
+    const int ch = h * DH + r;  // channel; its 4 x 4 block is ch / 4, its row in the block ch % 4
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r;
-      qs[t * DH + r] = a.q[off];
-      ks[t * DH + r] = a.k[off] / sqrt_dh;
+      const int64_t off = ((int64_t)b * T + t) * inner + ch;
+      if (lean) {
+        const float4 xa = *reinterpret_cast<const float4*>(a.lean_xa + ((int64_t)b * T + t) * inner + (ch & ~3));
+        qs[t * DH + r] = bd_row(a.lean_wq + (int64_t)ch * 4, xa);
+        ks[t * DH + r] = bd_row(a.lean_wk + (int64_t)ch * 4, xa) / sqrt_dh;
+      } else {
+        qs[t * DH + r] = a.q[off];
+        ks[t * DH + r] = a.k[off] / sqrt_dh;
+      }
     }
   }
   const int64_t base = ((int64_t)b * NH + h) * W;
@@ -339,8 +348,17 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   for (int j = 0; j < W; ++j) vw[j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
   float vcur[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t)
-    vcur[t] = tid < CW ? a.v[((int64_t)b * T + t) * inner + (int64_t)h * DH + slice * CW + tid] : 0.f;
+  for (int t = 0; t < T; ++t) {
+    const int ch = h * DH + slice * CW + tid;
+    if (tid >= CW) {
+      vcur[t] = 0.f;
+    } else if (lean) {  // v from the pre-conv branch (x half of u)
+      const float4 xm = *reinterpret_cast<const float4*>(a.lean_u + ((int64_t)b * T + t) * 2 * inner + (ch & ~3));
+      vcur[t] = bd_row(a.lean_wv + (int64_t)ch * 4, xm);
+    } else {
+      vcur[t] = a.v[((int64_t)b * T + t) * inner + ch];
+    }
+  }
   // window khat rows of this wave (rows wave, wave + 4, ...), KPL values per lane and row
   const float* wkb = a.wk + base * DH;
   float kreg[KPL > 0 ? kRowsPerWave : 1][KPL > 0 ? KPL : 1];

@@ -97,9 +97,11 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
       qt[t] = bd(wq, xa);
       kt[t] = bd(wk, xa);
       vt[t] = bd(wv, xm);
-      *reinterpret_cast<float4*>(a.q + row * inner + c0) = qt[t];
-      *reinterpret_cast<float4*>(a.k + row * inner + c0) = kt[t];
-      *reinterpret_cast<float4*>(a.v + row * inner + c0) = vt[t];
+      if (!a.lean) {  // lean: the consumer (lazy read pass) rebuilds q, k, v from xa and the x half of u
+        *reinterpret_cast<float4*>(a.q + row * inner + c0) = qt[t];
+        *reinterpret_cast<float4*>(a.k + row * inner + c0) = kt[t];
+        *reinterpret_cast<float4*>(a.v + row * inner + c0) = vt[t];
+      }
       *reinterpret_cast<float4*>(a.xa + row * inner + c0) = xa;
     }
     // conv state after the T tokens (reference layout [B, K, inner], newest tap last)
@@ -178,8 +180,23 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int64_t row = (int64_t)b * T + t;
-      const float4 qv = *reinterpret_cast<const float4*>(a.q + row * inner + c0);
-      const float4 kv = *reinterpret_cast<const float4*>(a.k + row * inner + c0);
+      float4 qv, kv;
+      if (a.lean) {  // same 4 x 4 block products as phase 1 (this thread's own xa rows)
+        const float4 xa = *reinterpret_cast<const float4*>(a.xa + row * inner + c0);
+        const float* wq = a.wq + (int64_t)cg * 16;
+        const float* wk = a.wk + (int64_t)cg * 16;
+        qv.x = wq[0] * xa.x + wq[1] * xa.y + wq[2] * xa.z + wq[3] * xa.w;
+        qv.y = wq[4] * xa.x + wq[5] * xa.y + wq[6] * xa.z + wq[7] * xa.w;
+        qv.z = wq[8] * xa.x + wq[9] * xa.y + wq[10] * xa.z + wq[11] * xa.w;
+        qv.w = wq[12] * xa.x + wq[13] * xa.y + wq[14] * xa.z + wq[15] * xa.w;
+        kv.x = wk[0] * xa.x + wk[1] * xa.y + wk[2] * xa.z + wk[3] * xa.w;
+        kv.y = wk[4] * xa.x + wk[5] * xa.y + wk[6] * xa.z + wk[7] * xa.w;
+        kv.z = wk[8] * xa.x + wk[9] * xa.y + wk[10] * xa.z + wk[11] * xa.w;
+        kv.w = wk[12] * xa.x + wk[13] * xa.y + wk[14] * xa.z + wk[15] * xa.w;
+      } else {
+        qv = *reinterpret_cast<const float4*>(a.q + row * inner + c0);
+        kv = *reinterpret_cast<const float4*>(a.k + row * inner + c0);
+      }
       float f = 0.f, i = 0.f;
 #pragma unroll
       for (int h = 0; h < NH; ++h)
