@@ -1,0 +1,29 @@
+"""GPU: bench.py's own line -- the contract keys, the physical roofline (fractions <= 1), the host-inclusive leg -- on a
+reduced batch so that it runs in seconds."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_line_contract_and_physical_roofline(hip_lib, capsys):
+    import bench
+    out = bench.main(["--config", "xlstm_16m", "--batch", "512", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                      "--no-stream-ceilings", "--host-io-steps", "3"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["metric"].startswith("env-steps/sec") and out["unit"] == "env-steps/s" and out["dtype"] == "f32"
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["vs_baseline"] is None
+    assert out["config"]["state_mode"] == "lazy" and "bf16x3" in out["config"]["workload"]
+    assert abs(out["value"] - 512 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert 0.0 < r["standalone"]["frac"] <= 1.0
+    assert r["launches_per_step"] == 14 and r["fold_launches_timed"] == 7 * 4      # 7 mLSTM blocks x 2 slices; 7 folds
+    assert r["effective_8d_GBps"] > r["achieved"]                                   # the 8d figure prices more bytes
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)                  # a replayed constant is labelled
+    h = out["host_io"]
+    assert h["steps"] == 3 and h["value"] > 0 and h["bytes_h2d_per_step"] == 512 * (204 * 4 + 4 + 1)
+    assert "cpu_baseline" not in out
+    capsys.readouterr()
