@@ -225,6 +225,13 @@ def load_agent_params(config_dir: str, name: str = "multi_domain", overrides: Se
                 dst[k] = copy.deepcopy(v)
     merge(composed, own)
     root = {"agent_params": composed, "run_params": {"total_timesteps": 0}}
+    # top-level scalars of the primary config (configs/config.yaml: SSD_DATA_DIR, seed, device, ...) are interpolation
+    # targets of the group files (data_paths: ${SSD_DATA_DIR}/...)
+    top = os.path.join(config_dir, "config.yaml")
+    if os.path.exists(top):
+        for k, v in (_load_yaml(top) or {}).items():
+            if k not in ("defaults", "hydra", "agent_params") and not isinstance(v, (dict, list)):
+                root.setdefault(k, v)
     for key, val in value_overrides:
         create = key.startswith("+")
         key = key.lstrip("+")
@@ -316,6 +323,37 @@ def spec_from_agent_params(ap: Dict[str, Any]) -> ModelSpec:
             dt_rank=hf.get("dt_rank", "auto") if hf.get("dt_rank", "auto") != "auto" else 0,
             norm_eps=float(hf.get("norm_epsilon", 1e-5)), **common)
     raise ValueError(f"agent kind {kind!r} is not a recurrent LRAM kind; expected one of {XLSTM_KINDS + MAMBA_KINDS}")
+
+
+def engine_limits(spec: ModelSpec) -> List[str]:
+    """Reasons why `lram_create` would refuse this geometry (the mirror of `validate_config` in csrc/engine.hip); empty when
+    the engine runs it.  Every preset of the reference's configs/agent_params/huggingface passes as an mLSTM-only stack;
+    sLSTM blocks additionally need d_model / num_heads to be a multiple of 4, which `xlstm_mediumplus_half` (266) and
+    `xlstm_large_half` (358) do not meet."""
+    why: List[str] = []
+    if spec.d_model % 4 or spec.d_model > 2048:
+        why.append(f"d_model {spec.d_model} must be a multiple of 4 and <= 2048")
+    if spec.state_dim % 4:
+        why.append(f"state_dim {spec.state_dim} must be a multiple of 4")
+    if spec.backbone == "xlstm":
+        if spec.n_heads not in (1, 2, 4, 8):
+            why.append(f"num_heads {spec.n_heads} must be 1, 2, 4 or 8")
+        elif spec.inner % (16 * spec.n_heads):
+            why.append(f"mLSTM head dim {spec.inner / spec.n_heads:g} must be a multiple of 16")
+        if spec.inner > 4096:
+            why.append(f"mLSTM inner dim {spec.inner} must be <= 4096")
+        if spec.n_heads and spec.inner // spec.n_heads > 1024:
+            why.append(f"mLSTM head dim {spec.inner // spec.n_heads} must be <= 1024")
+        if spec.d_model % spec.n_heads:
+            why.append(f"d_model {spec.d_model} must be a multiple of num_heads")
+        if spec.slstm_at and spec.d_model % (4 * spec.n_heads):
+            why.append(f"sLSTM blocks need d_model {spec.d_model} to be a multiple of 4 * num_heads")
+        if spec.conv_k != 4 or spec.qkv_blocksize != 4:
+            why.append("conv1d_kernel_size and qkv_proj_blocksize must be 4")
+    else:
+        if spec.d_inner % 4 or spec.d_conv != 4:
+            why.append("Mamba d_inner must be a multiple of 4 and d_conv 4")
+    return why
 
 
 # ----------------------------------------------------------------------------------------------

@@ -264,22 +264,26 @@ void validate_config(const lram_config& c) {
                    c.action_channels > 0,
                "bad action head dimensions");
   if (c.backbone == LRAM_BACKBONE_XLSTM) {
-    LRAM_REQUIRE(c.n_heads > 0 && c.inner > 0 && c.inner % (c.n_heads * 64) == 0,
-                 "xLSTM inner dim must be a multiple of 64 * n_heads");
-    LRAM_REQUIRE(c.d_model % (4 * c.n_heads) == 0, "d_model must be a multiple of 4 * n_heads");
+    LRAM_REQUIRE(c.n_heads > 0 && c.inner > 0 && c.inner % (c.n_heads * 16) == 0,
+                 "xLSTM inner dim must be a multiple of 16 * n_heads");
+    LRAM_REQUIRE(c.d_model % c.n_heads == 0, "d_model must be a multiple of n_heads");
     // limits of the step kernels (xlstm_kernels.hip: kMaxGroups, kGnMaxV, the NH template instances), checked here so
-    // that lram_create fails up front instead of a launch throwing in the middle of a step.  Of the reference's
-    // configs/agent_params/huggingface/xlstm_*.yaml this excludes xlstm_medium_half (head dim 352), xlstm_large_half
-    // (720: not multiples of 64) and xlstm_huge_half (inner 3584, head dim 896); see DESIGN.md section 8.
+    // that lram_create fails up front instead of a launch throwing in the middle of a step.  Every preset of the
+    // reference's configs/agent_params/huggingface/xlstm_*.yaml passes (head dims 256 .. 896, inner <= 3584); head dims
+    // that are not multiples of 64 (the *_half presets: 352, 544, 720) take 16-column cell slices and no lazy / chunkwise
+    // path.  sLSTM blocks additionally need d_model / num_heads to be a multiple of 4 (checked below where they occur).
     LRAM_REQUIRE(c.n_heads == 1 || c.n_heads == 2 || c.n_heads == 4 || c.n_heads == 8, "xLSTM num_heads must be 1, 2, 4 or 8");
-    LRAM_REQUIRE(c.inner <= 3072, "xLSTM inner dim (proj_factor * embedding_dim, rounded up to 64) must be <= 3072");
-    LRAM_REQUIRE(c.inner / c.n_heads <= 768, "mLSTM head dim must be <= 768");
-    LRAM_REQUIRE(c.d_model / c.n_heads <= 768, "sLSTM head dim must be <= 768");
+    LRAM_REQUIRE(c.inner <= 4096, "xLSTM inner dim (proj_factor * embedding_dim, rounded up to 64) must be <= 4096");
+    LRAM_REQUIRE(c.inner / c.n_heads <= 1024, "mLSTM head dim must be <= 1024");
+    LRAM_REQUIRE(c.d_model / c.n_heads <= 1024, "sLSTM head dim must be <= 1024");
     LRAM_REQUIRE(c.conv_k == 4, "conv1d_kernel_size must be 4");
     LRAM_REQUIRE(c.qkv_blocksize == 4, "qkv_proj_blocksize must be 4");
     bool any_s = false;
     for (int i = 0; i < c.n_blocks; ++i) any_s |= c.block_is_slstm[i] != 0;
-    if (any_s) LRAM_REQUIRE(c.ffn_dim > 0 && c.ffn_dim % 4 == 0, "ffn_dim must be a positive multiple of 4");
+    if (any_s) {
+      LRAM_REQUIRE(c.ffn_dim > 0 && c.ffn_dim % 4 == 0, "ffn_dim must be a positive multiple of 4");
+      LRAM_REQUIRE(c.d_model % (4 * c.n_heads) == 0, "sLSTM blocks need d_model to be a multiple of 4 * n_heads");
+    }
   } else {
     LRAM_REQUIRE(c.d_inner > 0 && c.d_inner % 4 == 0 && c.d_conv == 4 && c.d_state > 0 && c.dt_rank > 0,
                  "bad Mamba dimensions");

@@ -22,7 +22,7 @@ namespace lram {
 namespace {
 
 constexpr int kPreThreads = 256;
-constexpr int kMaxGroups = 3;  // channel groups (of 4) per thread: inner <= 3072
+constexpr int kMaxGroups = 4;  // channel groups (of 4) per thread: inner <= 4096
 
 // (body as a device function of the env index: the launch-per-kernel path calls it with blockIdx.x, the whole-step
 // kernel of persistent_step.inl with the env slots it loops over)
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kCellThreads) void mlstm_cell_kernel(MlstmCellArgs 
 // MultiHeadLayerNorm (group norm over DH per head) + mLSTM output gating, or + residual (sLSTM).
 // One wave per (row, head); DH <= 768.
 // =============================================================================================
-constexpr int kGnMaxV = 3;
+constexpr int kGnMaxV = 4;  // float4 per lane: head dim <= 1024
 
 __global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
   const int row = blockIdx.x, h = blockIdx.y;
@@ -779,8 +779,10 @@ static void launch_cell_t(const MlstmCellArgs& a, hipStream_t s) {
     launch_cell_tl<T, 32>(a, s);
   else if (a.DH % 64 == 0)
     launch_cell_tl<T, 16>(a, s);
+  else if (a.DH % 16 == 0)  // the reference's *_half presets (head dims 352, 544, 720): 16-column slices
+    launch_cell_tl<T, 4>(a, s);
   else
-    throw Error("lram: mLSTM head dim must be a multiple of 64");
+    throw Error("lram: mLSTM head dim must be a multiple of 16");
 }
 
 void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream) {
@@ -867,7 +869,7 @@ void launch_xlstm_small_batch_step(const PersistArgs& a, int T, const int32_t* b
 }
 
 void launch_group_norm(const GroupNormArgs& a, hipStream_t stream) {
-  LRAM_REQUIRE(a.DH % 4 == 0 && a.DH <= 4 * 64 * kGnMaxV, "group norm: head dim must be a multiple of 4 and <= 768");
+  LRAM_REQUIRE(a.DH % 4 == 0 && a.DH <= 4 * 64 * kGnMaxV, "group norm: head dim must be a multiple of 4 and <= 1024");
   hipLaunchKernelGGL(group_norm_kernel, dim3(a.rows, a.NH), dim3(64), 0, stream, a);
   LRAM_HIP_CHECK(hipGetLastError());
 }

@@ -427,6 +427,27 @@ def checkpoint_key_names():
     return out
 
 
+def reference_presets():
+    """Every recurrent model preset of the reference's Hydra tree, parsed and resolved BY THE PACKAGE'S OWN LOADER from the
+    reference's YAML files (configs/agent_params/multi_domain.yaml + huggingface/{xlstm,mamba}_*.yaml, the `${...}`
+    interpolations included): the resolved `agent_params` dict of each preset is stored, so that
+    tests/test_config_weights.py can check `spec_from_agent_params` (and the engine's geometry limits) against every
+    configuration the reference ships -- without the reference tree at test time.  Values only, no YAML text."""
+    import glob
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from lram_amd.config import load_agent_params
+    cfg_dir = os.path.join(REF, "configs")
+    out = {}
+    for path in sorted(glob.glob(os.path.join(cfg_dir, "agent_params", "huggingface", "*.yaml"))):
+        name = os.path.splitext(os.path.basename(path))[0]
+        if not (name.startswith("xlstm_") or name.startswith("mamba_")):
+            continue
+        kind = "MDDXLSTM" if name.startswith("xlstm_") else "MDDMamba"
+        ap = load_agent_params(cfg_dir, "multi_domain", [f"agent_params/huggingface={name}", f"agent_params.kind={kind}"])
+        out[name] = {k: ap.get(k) for k in ("kind", "huggingface", "model_kwargs", "replay_buffer_kwargs")}
+    return json.loads(json.dumps(out, default=lambda o: list(o) if isinstance(o, (tuple, set)) else str(o)))
+
+
 def main():
     sys.path.insert(0, REF)
     from src.tokenizers_custom import make_tokenizer  # reference code, executed not copied
@@ -467,6 +488,7 @@ def main():
     out["mamba_agent_trace"] = mamba_agent_trace()
     out["load_model_weights_trace"] = load_model_weights_trace()
     out["checkpoint_key_names"] = checkpoint_key_names()
+    out["reference_presets"] = reference_presets()
 
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as fh:
         json.dump(out, fh)

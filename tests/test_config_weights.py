@@ -1,6 +1,8 @@
 """Host logic: Hydra-style agent_params composition, strictness, model sizes, weight layout, checkpoints."""
 import os
 
+import dataclasses
+
 import pytest
 import torch
 import yaml
@@ -149,6 +151,38 @@ def test_checkpoint_key_names_come_from_reference_code():
                 assert parts[1] in enc, key
     for k in ("embed_state.weight", "embed_return.bias", "embed_ln.weight"):
         assert k in names["hf_DecisionTransformerModel_params"]
+
+
+def test_every_reference_preset_resolves_and_engine_limits_are_stated():
+    """`reference_presets` = the resolved agent_params of all 16 recurrent presets of the reference's Hydra tree (composed
+    by this package's loader from the reference's own YAML files, values only): each becomes a ModelSpec with the sizes
+    the [3P] packages derive (inner = ceil64(2 D), ffn = ceil64(1.3 D), dt_rank = ceil(D / 16)), and the engine's geometry
+    limits admit every one of them as an mLSTM-only stack; with sLSTM blocks two of the *_half presets drop out."""
+    import math
+    from lram_amd.config import engine_limits, spec_from_agent_params
+    presets = _ref_vectors()["reference_presets"]
+    assert len(presets) == 16
+    unsupported = set()
+    for name, ap in presets.items():
+        spec = spec_from_agent_params(ap)
+        hf = ap["huggingface"]
+        if name.startswith("xlstm_"):
+            D = hf["hidden_size"]
+            assert spec.backbone == "xlstm" and spec.d_model == D and spec.n_blocks == hf["n_layer"] and spec.n_heads == 4
+            assert spec.inner == math.ceil(2 * D / 64) * 64 and spec.ffn_dim == math.ceil(1.3 * D / 64) * 64
+            assert spec.conv_k == 4 and spec.qkv_blocksize == 4 and spec.context_length == 150
+        else:
+            D = hf["d_model"]
+            assert spec.backbone == "mamba" and spec.d_model == D and spec.n_blocks == hf["n_layer"]
+            assert spec.d_inner == 2 * D and spec.d_state == 16 and spec.dt_rank == math.ceil(D / 16)
+        assert spec.state_dim == 204 and spec.act_dim == 8 and spec.n_vocab == 274 and spec.max_length == hf["max_length"]
+        assert engine_limits(spec) == [], (name, engine_limits(spec))
+        if spec.backbone == "xlstm" and engine_limits(dataclasses.replace(spec, slstm_at=[1])):
+            unsupported.add(name)
+    assert unsupported == {"xlstm_mediumplus_half", "xlstm_large_half"}     # sLSTM head dims 266 / 358
+    # the configurations BASELINE.json names
+    for name in ("xlstm_medium", "xlstm_huge", "mamba_mediumplus"):
+        assert engine_limits(spec_from_agent_params(presets[name])) == []
 
 
 def test_sb3_zip_roundtrip_and_prefix_strip(tmp_path):

@@ -163,6 +163,31 @@ def test_xlstm_206m_shapes_two_blocks(hip_lib):
     assert _run_parity("xlstm_206m_cut", B=3, steps=4, spec=spec) == 0
 
 
+@pytest.mark.parametrize("d_model,slstm_at", [(704, [1]), (1064, []), (1432, []), (1792, [1])])
+def test_reference_half_presets_geometry(hip_lib, d_model, slstm_at):
+    """The widths of the reference's xlstm_*_half presets (configs/agent_params/huggingface): head dims 352 / 544 / 720
+    (not multiples of 64: 16-column cell slices) and 896 with inner 3584; two blocks each, with an sLSTM block where
+    d_model / 4 is a multiple of 4."""
+    from lram_amd.config import ModelSpec
+    spec = ModelSpec(backbone="xlstm", d_model=d_model, n_blocks=2, slstm_at=slstm_at)
+    assert spec.head_dim in (352, 544, 720, 896)
+    assert _run_parity(f"half_{d_model}", B=3, steps=4, spec=spec) == 0
+    # stored contexts fall back to the token-sequential kernels on these head dims
+    sd = init_state_dict(spec, seed=0)
+    eng = _engine(spec, sd, 2)
+    ora = dt_ref.OraclePolicy(spec, sd)
+    seq = make_inputs(spec, 2, 6, seed=3, reset_prob=0.0)
+    obs = torch.stack([x[0] for x in seq], 1).cuda()
+    rtg = torch.stack([x[1] for x in seq], 1).cuda()
+    act, _ = eng.prefill(obs.contiguous(), rtg.contiguous(), torch.zeros(2, 6, device="cuda"),
+                         torch.ones(2, dtype=torch.uint8, device="cuda"))
+    for t, x in enumerate(seq):
+        ref, dbg = ora.step(x[0], x[1], x[2], x[3] if t == 0 else None, return_debug=True)
+    torch.cuda.synchronize()
+    assert assert_actions_match(act, ref, dbg["logits"], spec, what=f"half_{d_model} prefill") == 0
+    eng.close()
+
+
 def test_mamba_tiny_trajectory(hip_lib):
     assert _run_parity("mamba_tiny", B=8, steps=12) == 0
 
