@@ -188,6 +188,14 @@ def test_reference_half_presets_geometry(hip_lib, d_model, slstm_at):
     eng.close()
 
 
+@pytest.mark.parametrize("d_model", [512, 1792])
+def test_reference_mamba_preset_widths(hip_lib, d_model):
+    """mamba_medium (d_model 512, dt_rank 32) and mamba_huge_half (1792, d_inner 3584, dt_rank 112), two layers each."""
+    from lram_amd.config import ModelSpec
+    spec = ModelSpec(backbone="mamba", kind="MDDMamba", d_model=d_model, n_blocks=2)
+    assert _run_parity(f"mamba_{d_model}", B=3, steps=4, spec=spec) == 0
+
+
 def test_mamba_tiny_trajectory(hip_lib):
     assert _run_parity("mamba_tiny", B=8, steps=12) == 0
 
