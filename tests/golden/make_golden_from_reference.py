@@ -448,6 +448,119 @@ def reference_presets():
     return json.loads(json.dumps(out, default=lambda o: list(o) if isinstance(o, (tuple, set)) else str(o)))
 
 
+def evaluate_policy_trace(g):
+    """`custom_evaluate_policy` (src/callbacks/evaluation.py:14-271) EXECUTED over three episodes of a scripted
+    single-env VecEnv, with stand-ins for what its module imports (gym.spaces, the SB3 VecEnv helpers, extract_env_name)
+    and a recording stand-in for the agent.  Stored: the scripted observations / rewards / episode ends, and per
+    `model.predict` call what the loop handed over (the last observation, the last return-to-go, the timestep, how many
+    states the context held), when the loop dropped the inference cache, and the function's results -- the contract
+    lram_amd.rollout.evaluate_policy_batched keeps for vector envs of any width."""
+    import ast
+    import time as _time
+    import warnings as _warnings
+    from types import SimpleNamespace
+    import numpy as np
+    path = os.path.join(REF, "src/callbacks/evaluation.py")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "custom_evaluate_policy"]
+
+    class Discrete:  # gym.spaces.Discrete
+        pass
+
+    class VecEnv:
+        pass
+
+    obs_dim, act_dim, ep_lens, reward_scale, target = 6, 3, (4, 2, 3), 50.0, 90.0
+    n_steps = sum(ep_lens)
+    obs_all = (torch.rand(n_steps + 1, obs_dim, generator=g) * 2 - 1).numpy().astype(np.float32)
+    rew_all = torch.rand(n_steps, generator=g).numpy().astype(np.float32) * 10
+    ends = set(np.cumsum(ep_lens) - 1)
+
+    class Env(VecEnv):
+        num_envs = 1
+        observation_space = SimpleNamespace(shape=(obs_dim,))
+        action_space = SimpleNamespace(shape=(act_dim,))
+
+        def __init__(self):
+            self.t, self.ep_r, self.ep_l = 0, 0.0, 0
+
+        def env_is_wrapped(self, _cls):
+            return [True]
+
+        def reset(self):
+            return obs_all[:1].copy()
+
+        def step(self, action):
+            r = rew_all[self.t]
+            self.ep_r += float(r)
+            self.ep_l += 1
+            done = self.t in ends
+            info = {}
+            if done:  # what Monitor adds at a true episode end
+                info["episode"] = {"r": self.ep_r, "l": self.ep_l}
+                self.ep_r, self.ep_l = 0.0, 0
+            self.t += 1
+            return obs_all[self.t: self.t + 1].copy(), np.array([r], dtype=np.float32), np.array([done]), [info]
+
+    calls, cache_drops = [], []
+    canned = torch.rand(n_steps, act_dim, generator=g) * 2 - 1
+
+    class Model:
+        device = torch.device("cpu")
+        eval_context_len, use_inference_cache, persist_context, compile = 5, True, False, False
+        target_return_type = "predefined"
+        replay_buffer = SimpleNamespace(seqs_per_sample=1)
+        policy = None
+
+        def __init__(self):
+            self.inference_params = SimpleNamespace(reset=lambda: cache_drops.append(("inference_params.reset", len(calls))))
+
+        def __setattr__(self, k, v):
+            if k == "past_key_values" and v is None:
+                cache_drops.append(("past_key_values=None", len(calls)))
+            object.__setattr__(self, k, v)
+
+        def compute_target_return_val(self, env=None, task_id=0):
+            return target / reward_scale
+
+        def get_reward_scale_for_env(self, envid=None):
+            return reward_scale
+
+        def predict(self, policy, states, actions, rewards, returns_to_go, timesteps, state=None, episode_start=None,
+                    deterministic=True, context_len=5, prompt=None, task_id=None, is_eval=False, env_act_dim=None):
+            calls.append({"obs_last": states[-1].tolist(), "rtg_last": float(returns_to_go[0, -1]),
+                          "timestep_last": int(timesteps[0, -1]), "n_states": int(states.shape[0]),
+                          "context_len": int(context_len), "env_act_dim": int(env_act_dim),
+                          "reward_last": float(rewards[-1]), "n_actions": int(actions.shape[0])})
+            return canned[len(calls) - 1].clone(), None
+
+    ns = {"gym": SimpleNamespace(Env=object, spaces=SimpleNamespace(Discrete=Discrete)), "np": np, "torch": torch,
+          "time": _time, "warnings": _warnings, "VecEnv": VecEnv, "VecMonitor": object, "VecTransposeImage": None,
+          "is_vecenv_wrapped": lambda env, cls: True, "get_action_dim": lambda sp: act_dim,
+          "get_obs_shape": lambda sp: (obs_dim,), "is_image_space": lambda sp: False,
+          "is_image_space_channels_first": lambda sp: True, "extract_env_name": lambda env, task_id=0: "Scripted-v0",
+          "discount_cumsum_torch": None}
+    from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+    ns.update(Any=Any, Callable=Callable, Dict=Dict, List=List, Optional=Optional, Tuple=Tuple, Union=Union)
+    import sys as _sys
+    mon = SimpleNamespace(Monitor=object)
+    _sys.modules.setdefault("stable_baselines3", SimpleNamespace())
+    _sys.modules.setdefault("stable_baselines3.common", SimpleNamespace())
+    _sys.modules["stable_baselines3.common.monitor"] = mon   # the function's local `from ... import Monitor`
+    try:
+        exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+        rewards_out, lengths_out, _times = ns["custom_evaluate_policy"](Model(), Env(), n_eval_episodes=len(ep_lens),
+                                                                        return_episode_rewards=True, warn=False)
+    finally:
+        for k in ("stable_baselines3.common.monitor", "stable_baselines3.common", "stable_baselines3"):
+            if isinstance(_sys.modules.get(k), SimpleNamespace):
+                del _sys.modules[k]
+    return {"obs": obs_all.tolist(), "rewards": rew_all.tolist(), "episode_lengths_scripted": list(ep_lens),
+            "reward_scale": reward_scale, "target_return": target, "act_dim": act_dim, "predict_calls": calls,
+            "cache_drops": [[k, int(i)] for k, i in cache_drops],
+            "episode_rewards": [float(x) for x in rewards_out], "episode_lengths": [int(x) for x in lengths_out]}
+
+
 def main():
     sys.path.insert(0, REF)
     from src.tokenizers_custom import make_tokenizer  # reference code, executed not copied
@@ -489,6 +602,7 @@ def main():
     out["load_model_weights_trace"] = load_model_weights_trace()
     out["checkpoint_key_names"] = checkpoint_key_names()
     out["reference_presets"] = reference_presets()
+    out["evaluate_policy_trace"] = evaluate_policy_trace(g)
 
     with open(os.path.join(HERE, "reference_vectors.json"), "w") as fh:
         json.dump(out, fh)

@@ -276,3 +276,59 @@ def test_agent_predict_follows_the_reference_trace():
         states = torch.cat([states, obs_all[t + 1: t + 2]])
         rtg = torch.cat([rtg, (rtg[0, -1] - env_r[t] / scale).reshape(1, 1)], dim=1)
         ts = torch.cat([ts, torch.full((1, 1), t + 1)], dim=1)
+
+
+def test_batched_evaluator_follows_the_executed_reference_loop():
+    """`evaluate_policy_trace` = custom_evaluate_policy (src/callbacks/evaluation.py:14-271) executed over three scripted
+    episodes of one env (make_golden_from_reference.py).  The batched driver, given the same env as a 1-wide vector env
+    and a recording agent, hands the agent the same observation and return-to-go at every step, resets the cache exactly
+    where the reference drops it, and returns the same episode returns and lengths."""
+    import json
+    from lram_amd.rollout import evaluate_policy_batched
+    v = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))["evaluate_policy_trace"]
+    obs_all, rew_all = torch.tensor(v["obs"]), torch.tensor(v["rewards"])
+    ends = set(int(x) for x in torch.tensor(v["episode_lengths_scripted"]).cumsum(0) - 1)
+
+    class ScriptedEnv:
+        n_envs, device, last_info = 1, torch.device("cpu"), {}
+
+        def __init__(self):
+            self.t = 0
+
+        def reset(self):
+            return obs_all[:1].clone()
+
+        def step(self, actions):
+            r, done = rew_all[self.t: self.t + 1].clone(), torch.tensor([self.t in ends])
+            self.t += 1
+            return obs_all[self.t: self.t + 1].clone(), r, done
+
+    calls, final_resets = [], []
+
+    class Agent:
+        persist_context = False
+        inference_params = type("IP", (), {"reset": staticmethod(lambda: final_resets.append(len(calls)))})()
+
+        def compute_target_return_val(self, env=None, task_id=0):
+            return v["target_return"] / v["reward_scale"]
+
+        def get_reward_scale_for_env(self, envid=None):
+            return v["reward_scale"]
+
+        def predict_batch(self, obs, rtg, rewards, reset_mask, env_act_dim):
+            calls.append((obs.clone(), float(rtg[0]), int(reset_mask[0]), env_act_dim))
+            return torch.zeros(1, env_act_dim)
+
+    rewards, lengths, _ = evaluate_policy_batched(Agent(), ScriptedEnv(), n_eval_episodes=3, env_act_dim=v["act_dim"],
+                                                  return_episode_rewards=True)
+    ref_calls = v["predict_calls"]
+    assert len(calls) == len(ref_calls) == 9
+    drops_before = {i for k, i in v["cache_drops"] if k == "past_key_values=None"}
+    for k, ((obs, rtg, mask, ead), ref) in enumerate(zip(calls, ref_calls)):
+        assert torch.allclose(obs[0], torch.tensor(ref["obs_last"]), atol=0), k
+        assert abs(rtg - ref["rtg_last"]) < 1e-5, (k, rtg, ref["rtg_last"])
+        assert mask == int(k in drops_before), k          # cache reset <=> the reference dropped it before this call
+        assert ead == ref["env_act_dim"] and ref["reward_last"] == 0.0      # reward token 0 (SURVEY 3.5 Q3)
+    assert lengths == v["episode_lengths"]
+    assert all(abs(a - b) < 1e-4 for a, b in zip(rewards, v["episode_rewards"]))
+    assert final_resets == [9] and 9 in drops_before     # and once more when the evaluation ends (evaluation.py:258-261)
