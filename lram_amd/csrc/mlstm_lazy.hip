@@ -279,10 +279,14 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
 // Column slice 0 also appends the step's T tokens to the window and writes the bookkeeping of the next step
 // (coefficients, scale, pending count) into the "out" side.
 // =============================================================================================
-constexpr int kRowsPerWave = (W + 4 + 3) / 4;
-
-template <int T, int LPR, int UNR, int KPL>
+// WP: window rows the register prefetch covers (W, or fewer when the fold period bounds the pending count: with the
+// default period of 13 and 3 tokens per step at most 36 rows are pending when a read pass starts, and the 24 registers
+// saved keep the kernel at 144 VGPRs -- three of its waves then leave room for a projection GEMM's wave on the SIMD).
+// SF: the window scores are reduced BEFORE the pass over C_base (the khat registers are dead while it runs and hold
+// its rows in flight instead) rather than after it.
+template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false>
 __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
+  constexpr int kRowsPerWave = (WP + T + 3) / 4;
   constexpr int CW = 4 * LPR;
   constexpr int RP = 256 / LPR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -343,9 +347,9 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   }
   // window V column of this thread (threads >= CW idle here): in flight during the pass over C_base
   const float* wvb = a.wv + (base * DH) + slice * CW + (tid < CW ? tid : 0);
-  float vw[W];
+  float vw[WP];
 #pragma unroll
-  for (int j = 0; j < W; ++j) vw[j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
+  for (int j = 0; j < WP; ++j) vw[j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
   float vcur[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -373,32 +377,6 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   }
   __syncthreads();
 
-  const int col0 = slice * CW + 4 * cl;
-  v4f acc[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) acc[t] = (v4f)(0.f);
-  const float* Cb = a.C + (((int64_t)b * NH + h) * DH) * DH + col0;
-  if (!lv.zero) {  // (after a restart C_base holds nothing until the env's next fold)
-    for (int r0 = rg; r0 < DH; r0 += RP * UNR) {
-      v4f c[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int r = r0 + u * RP;
-        c[u] = r < DH ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(Cb + (int64_t)r * DH)) : (v4f)(0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int r = r0 + u * RP;
-        if (r < DH) {
-#pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] += qs[t * DH + r] * c[u];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < T; ++t) *reinterpret_cast<v4f*>(red + ((rg * T + t) * CW) + 4 * cl) = acc[t];
-
   // ---- window scores p[t][j] = c_{t,j} (q_t . khat_j), j over the pending window and this step's own tokens ----
   auto coefficient = [&](int j, int t) -> float {
     if (j < n) return s_coef[j] * F[t];
@@ -412,6 +390,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
     }
     return c;
   };
+  auto window_scores = [&]() {
   if (KPL < 0) {
   } else if (KPL > 0) {
 #pragma unroll
@@ -425,6 +404,23 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
         for (int c = 0; c < KPL; ++c) {
           const int r = lane + 64 * c;
           const float kv = j < n ? kreg[i][c] : ks[(j - n) * DH + r];
+#pragma unroll
+          for (int t = 0; t < T; ++t) p[t] += qs[t * DH + r] * kv;
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float sm = wave_sum(p[t]);
+          if (lane == 0) pw[t * WT + j] = coefficient(j, t) * sm;
+        }
+      }
+    }
+    if (WP < W) {  // rows beyond the register prefetch (only when more than WP tokens are pending)
+      for (int j = wave + 4 * kRowsPerWave; j < n + T; j += 4) {
+        float p[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) p[t] = 0.f;
+        for (int r = lane; r < DH; r += 64) {
+          const float kv = j < n ? wkb[(int64_t)j * DH + r] : ks[(j - n) * DH + r];
 #pragma unroll
           for (int t = 0; t < T; ++t) p[t] += qs[t * DH + r] * kv;
         }
@@ -465,6 +461,35 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       }
     }
   }
+  };
+  if (SF) window_scores();
+  const int col0 = slice * CW + 4 * cl;
+  v4f acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = (v4f)(0.f);
+  const float* Cb = a.C + (((int64_t)b * NH + h) * DH) * DH + col0;
+  if (!lv.zero) {  // (after a restart C_base holds nothing until the env's next fold)
+    for (int r0 = rg; r0 < DH; r0 += RP * UNR) {
+      v4f c[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int r = r0 + u * RP;
+        c[u] = r < DH ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(Cb + (int64_t)r * DH)) : (v4f)(0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int r = r0 + u * RP;
+        if (r < DH) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) acc[t] += qs[t * DH + r] * c[u];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) *reinterpret_cast<v4f*>(red + ((rg * T + t) * CW) + 4 * cl) = acc[t];
+
+  if (!SF) window_scores();
   __syncthreads();
   if (tid < CW) {
     const int c = tid;
@@ -477,9 +502,16 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       hn[t] = G[t] * y;
     }
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
+    for (int j = 0; j < WP; ++j) {
 #pragma unroll
       for (int t = 0; t < T; ++t) hn[t] += pw[t * WT + j] * vw[j];  // vw == 0 beyond the window, pw zero-filled
+    }
+    if (WP < W) {
+      for (int j = WP; j < n; ++j) {
+        const float vj = wvb[(int64_t)j * DH];
+#pragma unroll
+        for (int t = 0; t < T; ++t) hn[t] += pw[t * WT + j] * vj;
+      }
     }
 #pragma unroll
     for (int u = 0; u < T; ++u)
@@ -525,20 +557,24 @@ __global__ __launch_bounds__(256) void mlstm_lazy_clear_kernel(int32_t* count, f
   if (gid == b * NH) count[b] = 0;
 }
 
-template <int T, int LPR, int UNR, int KPL>
+template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false>
 void launch_cell_tluk(const MlstmLazyArgs& a, hipStream_t s) {
   constexpr int CW = 4 * LPR, RP = 256 / LPR;
   dim3 grid(a.DH / CW, a.NH, a.B), block(256);
   size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW + T * kLazyWT + W);
   shmem = std::max(shmem, (size_t)a.min_lds_bytes);
+  // 116 VGPRs would let four workgroups share a CU; three (41 KB of LDS each) leave 152 registers per SIMD lane free,
+  // so the slice streams' front-end and 64-row GEMM workgroups start beside them at once and a 128-row GEMM
+  // workgroup (224 registers) after ONE read-pass workgroup retires: 386k vs 381k env-steps/s (two: 56 KB, 381k)
+  if (SF && a.min_lds_bytes == 0) shmem = std::max(shmem, (size_t)41 * 1024);
   if (shmem > 48 * 1024) {
     static uint64_t raised = 0;
     if (first_use_on_device(raised)) {
-      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR, KPL>),
+      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
   }
-  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR, KPL>), grid, block, shmem, s, a);
+  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF>), grid, block, shmem, s, a);
 }
 
 template <int T>
@@ -546,13 +582,35 @@ void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
   // LRAM_LAZY_UNROLL (measurement knob, T == 3 on the 256-wide geometry only): C_base rows in flight per lane
   static const int unroll = [] {
     const char* v = std::getenv("LRAM_LAZY_UNROLL");
-    return v ? std::atoi(v) : 4;  // measured at 4096 env slots: 4 rows in flight 377k env-steps/s, 8: 371k, 16: 362k
+    // measured at 4096 env slots.  Scores after the pass (165 / 189 / 251 VGPRs): 4 rows in flight 377k env-steps/s,
+    // 8: 371k, 16: 362k.  Scores first (116 VGPRs for 4 and 8 rows, 177 for 16): 4: 381k, 8: 386k, 16: 363k.
+    return v ? std::atoi(v) : 8;
   }();
   static const bool prefetch = [] {
     const char* v = std::getenv("LRAM_LAZY_KPREFETCH");
     return v ? std::atoi(v) != 0 : true;
   }();
+  static const bool narrow = [] {
+    const char* v = std::getenv("LRAM_LAZY_NARROW");
+    return v ? std::atoi(v) != 0 : true;
+  }();
   if (a.DH == 256 && prefetch) {
+    // pending rows when a read pass starts: (period - 1) * T = 36 at most with the default period (the env's fold
+    // empties the window first); longer windows (other periods, calls with other token counts) take the kernel's
+    // late-load path for the rows beyond the prefetch
+    static const int scores_first = [] {
+      const char* v = std::getenv("LRAM_LAZY_SCORES_FIRST");
+      return v ? std::atoi(v) : 1;
+    }();
+    if (T == 3 && narrow && scores_first) {
+      if (unroll == 16) return launch_cell_tluk<T, 64, 16, 4, 36, true>(a, s);
+      if (unroll == 8) return launch_cell_tluk<T, 64, 8, 4, 36, true>(a, s);
+      if (unroll == 4) return launch_cell_tluk<T, 64, 4, 4, 36, true>(a, s);
+    }
+    if (T == 3 && narrow) {
+      if (unroll == 8) return launch_cell_tluk<T, 64, 8, 4, 36>(a, s);
+      if (unroll == 4) return launch_cell_tluk<T, 64, 4, 4, 36>(a, s);
+    }
     if (T == 3 && unroll == 4) return launch_cell_tluk<T, 64, 4, 4>(a, s);
     if (T == 3 && unroll == 8) return launch_cell_tluk<T, 64, 8, 4>(a, s);
     return launch_cell_tluk<T, 64, 16, 4>(a, s);
