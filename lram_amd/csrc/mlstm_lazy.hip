@@ -618,6 +618,22 @@ void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
   if (a.DH == 128) return launch_cell_tluk<T, 32, 16, 0>(a, s);  // one column slice per head: fused scores
   // several column slices per head: scores from mlstm_lazy_score_kernel (launch_mlstm_lazy_book)
   LRAM_REQUIRE(a.pw != nullptr, "lazy mLSTM: missing score buffer");
+  // LRAM_LAZY_EXT_VARIANT (measurement knob, 206M at 512 env slots): 0 = 48-row window prefetch, 16 rows in flight
+  // (185 VGPRs) 27.5k env-steps/s; 1 = 36-row prefetch, 8 rows (113 VGPRs, read pass 0.41 -> 0.31 ms) 27.1k -- the
+  // projections of this model are the longer side of the pipeline and lose what the pass gains; 2 = 36-row prefetch,
+  // 16 rows (174 VGPRs) 27.7k
+  static const int ext_variant = [] {
+    const char* v = std::getenv("LRAM_LAZY_EXT_VARIANT");
+    return v ? std::atoi(v) : 2;
+  }();
+  if (T == 3 && ext_variant == 1) {
+    if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 8, -1, 36>(a, s);
+    return launch_cell_tluk<T, 32, 8, -1, 36>(a, s);
+  }
+  if (T == 3 && ext_variant == 2) {
+    if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 16, -1, 36>(a, s);
+    return launch_cell_tluk<T, 32, 16, -1, 36>(a, s);
+  }
   if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 16, -1>(a, s);
   launch_cell_tluk<T, 32, 16, -1>(a, s);
 }
