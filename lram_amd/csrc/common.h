@@ -61,6 +61,12 @@ struct GemmArgs {
   // apart (bf16x3 kernel only; `a` may then be null)
   const uint16_t* a3 = nullptr;
   int64_t a3_plane = 0;
+  // optional (bf16x3 kernel, fp32 A, no batch, no split-K): A[r][k] is multiplied by gate[r * ldg + k] while it is staged
+  // (the mLSTM output gate: gate holds silu(z), written by proj_up's epilogue via act_silu_from)
+  const float* gate = nullptr;
+  int64_t ldg = 0;
+  // optional (bf16x3 kernel, no split-K): output columns >= act_silu_from are stored as silu(value); -1 = none
+  int act_silu_from = -1;
   // optional split-K workspace (un-batched GEMMs with few output tiles: skinny N or small M): partial [S][M][N]
   // slabs are written by S x tiles workgroups and summed, in fixed order, by a second tiny kernel (deterministic)
   float* splitk_ws = nullptr;
@@ -181,6 +187,10 @@ struct MlstmLazyArgs {
   // lean front end (fused-score geometries): q, k, v rebuilt here from xa (conv branch) and u's x half with the
   // block-diagonal 4 x 4 weights, instead of being read back from HBM
   const float *lean_xa = nullptr, *lean_u = nullptr, *lean_wq = nullptr, *lean_wk = nullptr, *lean_wv = nullptr;
+  // output group norm + learnable skip in the read pass's epilogue (one column slice per head only): h is then stored as
+  // GN(h) * gn_g (+ gn_b) + gn_skip * xa, the output gate silu(z) is applied by proj_down while it stages its operand
+  const float *gn_g = nullptr, *gn_b = nullptr, *gn_skip = nullptr;
+  float gn_eps = 0.f;
   float* pw = nullptr;    // [B, NH, T, kLazyWT] window scores: only for geometries with several column slices per head
   const uint8_t* reset;   // [B] or null
   int B, T, NH, DH;

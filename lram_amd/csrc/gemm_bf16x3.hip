@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "device_math.h"
 
 namespace lram {
 
@@ -41,7 +42,8 @@ __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16&
 // BM = 128: 64 x 64 per wave (2 x 2 MFMA tiles).  BM = 64: 32 x 64 per wave -- twice the workgroups for outputs with few
 // 128-wide column tiles (proj_down, out_proj, ffn_down: N = 512 .. 1280 gives 192 .. 290 tiles of 128 x 128 for 512
 // workgroup slots), 46 KB of LDS instead of 61 KB.
-template <bool HAS_BIAS, bool HAS_RES, bool A_PRE, int BM>
+// GATE: the fp32 A operand is multiplied element-wise by g.gate while it is staged (mLSTM output gate).
+template <bool HAS_BIAS, bool HAS_RES, bool A_PRE, int BM, bool GATE = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   constexpr int WM = BM / 2;          // rows per wave
   constexpr int TI = WM / 32;         // MFMA row tiles per wave
@@ -79,6 +81,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   constexpr int NA = BM / 32;          // fp32 A: float4 per thread and K tile
   constexpr int NAP = 3 * BM * 4 / 256;  // pre-split A: 16-byte chunks per thread and K tile
   float4 ra[A_PRE ? 1 : NA];
+  float4 rz[GATE ? NA : 1];
+  (void)rz;
   uint4 rap[A_PRE ? NAP : 1];
   uint4 rw[6];
   auto load_tile = [&](int k0) {
@@ -99,6 +103,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         const int gm = m0 + lr + 32 * i, kk = k0 + lc;
         ra[i] = (gm < g.m && kk < g.k) ? *reinterpret_cast<const float4*>(A + (int64_t)gm * g.lda + kk)
                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (GATE)
+          rz[i] = (gm < g.m && kk < g.k) ? *reinterpret_cast<const float4*>(g.gate + (int64_t)gm * g.ldg + kk)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
@@ -125,7 +132,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < (A_PRE ? 0 : NA); ++i) {
       bf16x4 hi, mid, lo;
-      const float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      if (GATE) xs[0] *= rz[i].x, xs[1] *= rz[i].y, xs[2] *= rz[i].z, xs[3] *= rz[i].w;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         __bf16 h, m, l;
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         if (row < g.m) {
           float v = acc[i][j][r] + bv;
           if (HAS_RES) v += R[(int64_t)row * g.ldc + col];
+          if (g.act_silu_from >= 0 && col >= g.act_silu_from) v = silu_f(v);
           C[(int64_t)row * g.ldc + col] = v;
         }
       }
@@ -267,7 +276,11 @@ static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 
 void launch_gemm_bf16x3(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
-  const int S = gemm_choose_split_k(g);
+  int S = 1;
+  if (g.act_silu_from >= 0)
+    g.split_k = 1, g.k_tiles_per_split = 0;  // the output activation is applied by this kernel's epilogue: K unsplit
+  else
+    S = gemm_choose_split_k(g);
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
   LRAM_REQUIRE(gemm_bf16x3_supported(g), "gemm bf16x3: K, ldw and W strides must be multiples of 8");
   const int tiles_n = (g.n + BN - 1) / BN;
@@ -285,7 +298,14 @@ void launch_gemm_bf16x3(const GemmArgs& g_in, hipStream_t stream) {
                                         g.m > 64);
   const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;
   dim3 grid(tiles, g.nb1 * g.nb2, S);
-  if (g.a3 != nullptr) {
+  if (g.gate != nullptr) {
+    LRAM_REQUIRE(g.a3 == nullptr && g.nb1 * g.nb2 == 1 && (g.ldg & 3) == 0 && g.residual != nullptr && g.bias == nullptr,
+                 "gemm bf16x3: the gated operand form is the un-batched fp32-A residual GEMM (proj_down)");
+    if (small)
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, false, 64, true>), grid, dim3(256), 0, stream, g);
+    else
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, false, 128, true>), grid, dim3(256), 0, stream, g);
+  } else if (g.a3 != nullptr) {
     LRAM_REQUIRE((g.lda & 7) == 0 && (g.a3_plane & 7) == 0 && ((g.sA1 | g.sA2) & 7) == 0,
                  "gemm bf16x3: pre-split A needs lda / plane stride / batch strides in multiples of 8");
     if (small)

@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   float* red = ks + T * DH;         // [RP][T][CW]
   float* pw = red + RP * T * CW;    // [T][WT]
   float* s_coef = pw + T * WT;      // [W]
+  float* gnred = s_coef + W;        // [2][4][T] group-norm partial sums (mean, then variance) per wave
 
   const int b = blockIdx.z, h = blockIdx.y, slice = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -491,6 +492,10 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
 
   if (!SF) window_scores();
   __syncthreads();
+  const bool gn = a.gn_g != nullptr && CW == DH;  // the workgroup holds the head's whole output row
+  float hv[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) hv[t] = 0.f;
   if (tid < CW) {
     const int c = tid;
     float hn[T];
@@ -518,12 +523,44 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
 #pragma unroll
       for (int t = u; t < T; ++t) hn[t] += pw[t * WT + n + u] * vcur[u];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
-      a.h[((int64_t)b * T + t) * inner + (int64_t)h * DH + slice * CW + c] = hn[t] / den[t];
+    for (int t = 0; t < T; ++t) hv[t] = hn[t] / den[t];
+    if (!gn) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) a.h[((int64_t)b * T + t) * inner + (int64_t)h * DH + slice * CW + c] = hv[t];
+    }
     // append this step's v rows; khat rows and the bookkeeping are written by slice 0 below
     float* wvo = a.wv + (base + n) * DH + slice * CW + c;
 #pragma unroll
     for (int t = 0; t < T; ++t) wvo[(int64_t)t * DH] = vcur[t];
+  }
+  if (gn) {  // (uniform over the workgroup) two-pass group norm over the head's DH outputs, + skip * xa
+    float mean[T], dv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float sm = wave_sum(hv[t]);
+      if (lane == 0) gnred[wave * T + t] = sm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      mean[t] = (gnred[t] + gnred[T + t] + gnred[2 * T + t] + gnred[3 * T + t]) / (float)DH;
+      dv[t] = tid < CW ? hv[t] - mean[t] : 0.f;
+      const float sq = wave_sum(dv[t] * dv[t]);
+      if (lane == 0) gnred[4 * T + wave * T + t] = sq;
+    }
+    __syncthreads();
+    if (tid < CW) {
+      const int ch = h * DH + tid;
+      const float gg = a.gn_g[ch], bb = a.gn_b != nullptr ? a.gn_b[ch] : 0.f, sk = a.gn_skip[ch];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float* q4 = gnred + 4 * T;
+        const float var = (q4[t] + q4[T + t] + q4[2 * T + t] + q4[3 * T + t]) / (float)DH;
+        const float rstd = 1.f / sqrtf(var + a.gn_eps);
+        const int64_t off = ((int64_t)b * T + t) * inner + ch;
+        a.h[off] = dv[t] * rstd * gg + bb + sk * a.lean_xa[off];
+      }
+    }
   }
   if (slice == 0) {
     float* wko = a.wk + (base + n) * DH;
@@ -561,7 +598,7 @@ template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false>
 void launch_cell_tluk(const MlstmLazyArgs& a, hipStream_t s) {
   constexpr int CW = 4 * LPR, RP = 256 / LPR;
   dim3 grid(a.DH / CW, a.NH, a.B), block(256);
-  size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW + T * kLazyWT + W);
+  size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW + T * kLazyWT + W + 8 * T);
   shmem = std::max(shmem, (size_t)a.min_lds_bytes);
   // 116 VGPRs would let four workgroups share a CU; three (41 KB of LDS each) leave 152 registers per SIMD lane free,
   // so the slice streams' front-end and 64-row GEMM workgroups start beside them at once and a 128-row GEMM

@@ -9,7 +9,8 @@ run --config xlstm_c1 --batch 32 --steps 200 --warmup 20
 run --config xlstm_c1 --batch 32 --steps 200 --warmup 20 --graph
 run --config xlstm_16m --batch 32 --steps 100 --warmup 10
 run --config xlstm_16m --batch 32 --steps 100 --warmup 10 --graph
-run --config xlstm_16m --batch 1 --steps 100 --warmup 10 --graph
+run --config xlstm_16m --batch 1 --steps 400 --warmup 40
+run --config xlstm_16m --batch 1 --steps 400 --warmup 40 --graph
 run --config mamba_48m --batch 2048 --steps 32 --warmup 4
 run --config mamba_48m --batch 1 --steps 100 --warmup 10 --graph
 run --config xlstm_206m --batch 512 --steps 16 --warmup 2

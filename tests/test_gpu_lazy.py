@@ -162,3 +162,29 @@ def test_lazy_encoder_step_token_counts(hip_lib, period):
         assert rel_err(pkv["block_0"]["mlstm_state"][i], state["block_0"]["mlstm_state"][i]) < 2e-4, i
     assert rel_err(pkv["block_2"]["mlstm_state"][0], state["block_2"]["mlstm_state"][0]) < 2e-4
     eng.close()
+
+
+def test_lazy_fused_group_norm_variant(hip_lib, monkeypatch):
+    """LRAM_GN_FUSE=1 (opt-in): output group norm + skip in the read pass's epilogue, silu(z) from proj_up's epilogue,
+    the gate applied while proj_down stages its operand.  Same trajectory as the default lazy engine and the oracle."""
+    from lram_amd.engine import Engine
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=57)
+    B, steps = 64, 30
+    seq = make_inputs(spec, B, steps, seed=27, reset_prob=0.05)
+    base = Engine(spec, sd, B, device="cuda:0")
+    base.set_state_mode(True)
+    monkeypatch.setenv("LRAM_GN_FUSE", "1")
+    fused = Engine(spec, sd, B, device="cuda:0")
+    monkeypatch.delenv("LRAM_GN_FUSE")
+    fused.set_state_mode(True)
+    a_b, a_f = _run(base, seq), _run(fused, seq)
+    assert float((a_b - a_f).abs().max()) <= 1e-4
+    ora = dt_ref.OraclePolicy(spec, sd)
+    sample = [0, 17, 63]
+    for t, (obs, rtg, rew, mask) in enumerate(seq):
+        ref, dbg = ora.step(obs[sample], rtg[sample], rew[sample], mask[sample], return_debug=True)
+        assert_actions_match(a_f[t][sample], ref, dbg["logits"], spec, what=f"fused group norm step {t}")
+    for blk in (0, 2, 7):
+        assert rel_err(fused.export_state_tensor(blk, 0), base.export_state_tensor(blk, 0)) < 2e-4
+    base.close(), fused.close()
