@@ -21,6 +21,7 @@ f=$(find $OUT/prof_headline -name "*kernel_stats.csv" | head -1); cp $f profiles
 python scripts/summarize_state_pass.py $OUT/prof_headline > profiles/${RND}_state_pass_rocprof_vs_live.json; cat profiles/${RND}_state_pass_rocprof_vs_live.json | head -40
 t=$(find $OUT/prof_headline -name "*kernel_trace.csv" | head -1); python scripts/timeline.py $t -3 30 > profiles/${RND}_step_timeline_xlstm16m_b4096.txt
 rm -rf $OUT/pmc; PMC_ROUND=$RND bash scripts/pmc_pass.sh 2>&1 | grep -E "rc=|hbm_bytes_per_env|state_mode"
+python scripts/parse_pmc_step.py $OUT/pmc $(python -c "import json; print(json.load(open('$OUT/bench.json'))['ms_per_step'])") > profiles/${RND}_whole_step_hbm_traffic.json 2>/dev/null
 if [ "${FULL:-0}" = "1" ]; then
   bash scripts/gpu_prof.sh mamba --config mamba_48m --batch 2048 --steps 16 --warmup 4 | head -8
   f=$(find $OUT/prof_mamba -name "*kernel_stats.csv" | head -1); cp $f profiles/${RND}_kernel_stats_mamba48m_b2048.csv
