@@ -7,6 +7,8 @@
 // read once and written once per env-step instead of once per token.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "device_math.h"
 
@@ -26,7 +28,7 @@ constexpr int kMaxGroups = 4;  // channel groups (of 4) per thread: inner <= 409
 
 // (body as a device function of the env index: the launch-per-kernel path calls it with blockIdx.x, the whole-step
 // kernel of persistent_step.inl with the env slots it loops over)
-template <int T, int NH>
+template <int T, int NH, bool SINGLE = false>
 __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int b) {
   constexpr int NRED = 2 * T * NH;
   __shared__ float red[4][NRED];
@@ -45,6 +47,14 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int h = 0; h < NH; ++h) pi[t][h] = pf[t][h] = 0.f;
+  // One channel group per thread (inner <= 4 * kPreThreads, e.g. the 16M geometry): q and k stay in registers for
+  // phase 3 and the recurrent scalars / the normaliser state are requested before the block reductions instead of after
+  // them -- one dependent memory round trip per workgroup instead of three (beside a read pass each costs microseconds).
+  constexpr bool single = SINGLE;  // the launcher guarantees ngroups <= kPreThreads
+  const float m_pre = (single && tid < NH && !rs) ? a.m_state[(int64_t)b * NH + tid] : 0.f;
+  float4 q_keep[T], k_keep[T], n_pre = f4_zero();
+#pragma unroll
+  for (int t = 0; t < T; ++t) q_keep[t] = k_keep[t] = f4_zero();
 
   // ---- phase 1: conv, qkv, gate partial sums -------------------------------------------------
   for (int cg = tid; cg < ngroups; cg += kPreThreads) {
@@ -97,6 +107,7 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
       qt[t] = bd(wq, xa);
       kt[t] = bd(wk, xa);
       vt[t] = bd(wv, xm);
+      q_keep[t] = qt[t], k_keep[t] = kt[t];
       if (!a.lean) {  // lean: the consumer (lazy read pass) rebuilds q, k, v from xa and the x half of u
         *reinterpret_cast<float4*>(a.q + row * inner + c0) = qt[t];
         *reinterpret_cast<float4*>(a.k + row * inner + c0) = kt[t];
@@ -108,6 +119,7 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (k < a.K) *reinterpret_cast<float4*>(a.conv_state + ((int64_t)b * a.K + k) * inner + c0) = win[k];
+    if (single && !rs) n_pre = *reinterpret_cast<const float4*>(a.n_state + (int64_t)b * inner + c0);
     // gate partial sums over this thread's 4 channels of q, k and v
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -153,7 +165,7 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
   // ---- phase 2: stabilised gate scalars (sequential over the T tokens, one thread per head) --
   if (tid < NH) {
     const int h = tid;
-    float m = rs ? 0.f : a.m_state[(int64_t)b * NH + h];
+    float m = single ? m_pre : (rs ? 0.f : a.m_state[(int64_t)b * NH + h]);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const float lf = log_sigmoid(gate_f[t][h]);
@@ -176,12 +188,14 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
   for (int cg = tid; cg < ngroups; cg += kPreThreads) {
     const int c0 = cg << 2;
     const int hh = c0 / DH;
-    float4 n = rs ? f4_zero() : *reinterpret_cast<const float4*>(a.n_state + (int64_t)b * inner + c0);
+    float4 n = single ? n_pre : (rs ? f4_zero() : *reinterpret_cast<const float4*>(a.n_state + (int64_t)b * inner + c0));
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int64_t row = (int64_t)b * T + t;
       float4 qv, kv;
-      if (a.lean) {  // same 4 x 4 block products as phase 1 (this thread's own xa rows)
+      if (single) {
+        qv = q_keep[t], kv = k_keep[t];
+      } else if (a.lean) {  // same 4 x 4 block products as phase 1 (this thread's own xa rows)
         const float4 xa = *reinterpret_cast<const float4*>(a.xa + row * inner + c0);
         const float* wq = a.wq + (int64_t)cg * 16;
         const float* wk = a.wk + (int64_t)cg * 16;
@@ -231,9 +245,9 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
   }
 }
 
-template <int T, int NH>
+template <int T, int NH, bool SINGLE = false>
 __global__ __launch_bounds__(kPreThreads) void mlstm_pre_kernel(MlstmPreArgs a) {
-  mlstm_pre_body<T, NH>(a, blockIdx.x);
+  mlstm_pre_body<T, NH, SINGLE>(a, blockIdx.x);
 }
 
 // Large-T variant of the front end (context prefill: T = 3 x timesteps-per-chunk, up to kMaxTokens): the same
@@ -704,10 +718,21 @@ __global__ __launch_bounds__(256) void gelu_gate_kernel(const float* p, float* o
 template <int T>
 static void launch_pre_t(const MlstmPreArgs& a, hipStream_t s) {
   dim3 grid(a.B), block(kPreThreads);
+  // one channel group per thread: the variant with one dependent memory round trip (LRAM_PRE_SINGLE=0: three, as before)
+  static const bool allow_single = [] {
+    const char* v = std::getenv("LRAM_PRE_SINGLE");
+    return v ? std::atoi(v) != 0 : true;
+  }();
+  const bool single = allow_single && (a.inner >> 2) <= kPreThreads;
   switch (a.NH) {
     case 1: hipLaunchKernelGGL((mlstm_pre_kernel<T, 1>), grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL((mlstm_pre_kernel<T, 2>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((mlstm_pre_kernel<T, 4>), grid, block, 0, s, a); break;
+    case 4:
+      if (single)
+        hipLaunchKernelGGL((mlstm_pre_kernel<T, 4, true>), grid, block, 0, s, a);
+      else
+        hipLaunchKernelGGL((mlstm_pre_kernel<T, 4>), grid, block, 0, s, a);
+      break;
     case 8: hipLaunchKernelGGL((mlstm_pre_kernel<T, 8>), grid, block, 0, s, a); break;
     default: throw Error("lram: mLSTM num_heads must be 1, 2, 4 or 8");
   }
