@@ -181,6 +181,17 @@ __global__ __launch_bounds__(256) void gemv_small_m_kernel(GemmArgs g) {
   for (int m = 0; m < kGemvMaxM; ++m)
 #pragma unroll
     for (int c = 0; c < kGemvCols; ++c) acc[m][c] = 0.f;
+  // bias and residual are requested with the first weight rows, not after the reduction; lane 0 is the only one that
+  // uses them
+  float bv[kGemvCols], rv[kGemvMaxM][kGemvCols];
+#pragma unroll
+  for (int c = 0; c < kGemvCols; ++c) {
+    const bool ok = lane == 0 && n0 + c < g.n;
+    bv[c] = (ok && bias) ? bias[n0 + c] : 0.f;
+#pragma unroll
+    for (int m = 0; m < kGemvMaxM; ++m) rv[m][c] = (ok && R && m < g.m) ? R[(int64_t)m * g.ldc + n0 + c] : 0.f;
+  }
+#pragma unroll 4
   for (int k = lane * 4; k < g.k; k += 256) {
     float4 w[kGemvCols];
 #pragma unroll
@@ -209,11 +220,7 @@ __global__ __launch_bounds__(256) void gemv_small_m_kernel(GemmArgs g) {
         float v = acc[m][c];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0 && n0 + c < g.n) {
-          if (bias) v += bias[n0 + c];
-          if (R) v += R[(int64_t)m * g.ldc + n0 + c];
-          C[(int64_t)m * g.ldc + n0 + c] = v;
-        }
+        if (lane == 0 && n0 + c < g.n) C[(int64_t)m * g.ldc + n0 + c] = (v + bv[c]) + rv[m][c];
       }
     }
   }
