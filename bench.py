@@ -140,7 +140,7 @@ def parse_args(argv=None):
                     help="Mamba: the reference agent's trajectory (one forward per action dim, layer-0-only resets; "
                          "lram_set_compat_mode) instead of one state advance per env-step")
     ap.add_argument("--env-act-dim", type=int, default=0, help="action dims the env uses (compat forwards per step)")
-    ap.add_argument("--host-io-steps", type=int, default=16, help="steps of the host-inclusive leg (0 = skip)")
+    ap.add_argument("--host-io-steps", type=int, default=48, help="steps of the host-inclusive leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-timing", action="store_true", help="keep the live state-pass timing below 256 env slots")
@@ -328,7 +328,7 @@ def main(argv=None, engine_factory=None, device=None):
             torch.cuda.current_stream(dev).synchronize()   # the caller needs the actions before it can step its envs
             return h_act
 
-        for _ in range(2):
+        for _ in range(4):
             host_step()
         wall_h, _ = timed_region(host_step, 0, n_h, sync, ldist, dev)
         out["host_io"] = {"value": global_batch * n_h / wall_h, "unit": "env-steps/s", "ms_per_step": wall_h / n_h * 1e3,
