@@ -71,6 +71,7 @@ struct GemmArgs {
   // slabs are written by S x tiles workgroups and summed, in fixed order, by a second tiny kernel (deterministic)
   float* splitk_ws = nullptr;
   int64_t splitk_ws_elems = 0;
+  int mfma_prio = 0;      // set by the launcher (LRAM_GEMM_PRIO): raise the wave's issue priority around the MFMA block
   int split_k = 1;        // set by the launcher
   int k_tiles_per_split = 0;
 };

@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     store_tile();
     __syncthreads();
     if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    if (g.mfma_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[TI][3], bf[2][3];
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);  // hi * hi
         }
     }
+    if (g.mfma_prio) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
   }
 
@@ -276,6 +278,13 @@ static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 
 void launch_gemm_bf16x3(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
+  // waves inside their MFMA block issue ahead of the co-resident workgroup's staging code (s_setprio 1): Mamba-48M
+  // 319.1k -> 322.5k env-steps/s, 16M 403.8k -> 404.4k (LRAM_GEMM_PRIO=0 switches it off)
+  static const int prio = [] {
+    const char* v = std::getenv("LRAM_GEMM_PRIO");
+    return v ? std::atoi(v) : 1;
+  }();
+  g.mfma_prio = prio;
   int S = 1;
   if (g.act_silu_from >= 0)
     g.split_k = 1, g.k_tiles_per_split = 0;  // the output activation is applied by this kernel's epilogue: K unsplit

@@ -10,6 +10,7 @@
 // (row pitch 36 floats: ds_read_b128 of 16 consecutive rows hits 16 distinct 4-bank slots), next
 // K-tile's global loads are issued before the MFMAs of the current one.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -246,7 +247,12 @@ int gemm_choose_split_k(GemmArgs& g) {
   if (g.splitk_ws == nullptr || g.nb1 * g.nb2 != 1) return 1;
   const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
   const int nk = (g.k + BK - 1) / BK;
-  if (tiles >= 128 || nk < 4) return 1;
+  // LRAM_SPLITK_TILES (measurement knob): outputs with fewer 128 x 128 tiles than this are split along K
+  static const int min_tiles = [] {
+    const char* v = std::getenv("LRAM_SPLITK_TILES");
+    return v ? std::atoi(v) : 128;
+  }();
+  if (tiles >= min_tiles || nk < 4) return 1;
   int S = std::min(std::min(nk / 2, 16), (256 + tiles - 1) / tiles);
   while (S > 1 && (int64_t)S * g.m * g.n > g.splitk_ws_elems) --S;
   if (S < 2) return 1;
