@@ -5,6 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms run N ranks.  Started WITHOUT a torchrun environment (no WORLD_SIZE) and with --gpus N > 1, this process
+never touches the GPU: it starts N fresh child processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+rendezvous on 127.0.0.1), relays rank 0's JSON line and exits non-zero if any rank does (`launch_ranks`).  Started
+WITH WORLD_SIZE set, WORLD_SIZE must equal --gpus; a mismatch is refused, not papered over.  The line carries
+`ranks_seen` = an all-reduce of one 1 per rank, so a mislabelled single-rank run cannot pass for N GPUs.
+
 A "step" is one pass of the hot path over one batch of synthetic env inputs: B env slots per GPU each advance one
 timestep (embed (s, rtg, r) -> 3 recurrent token steps through the block stack -> action head -> argmax ->
 de-tokenise), plus, for N > 1, the all-gather of the action tensor (RCCL).  Workload = BASELINE.json's metric
@@ -145,7 +151,87 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-timing", action="store_true", help="keep the live state-pass timing below 256 env slots")
     ap.add_argument("--no-stream-ceilings", action="store_true")
+    ap.add_argument("--engine-factory", default="",
+                    help="test hook: 'file.py:attr' or 'module:attr' of a stand-in engine factory(spec, batch, device); the "
+                         "run then stays on the CPU over gloo (tests/test_dist_rollout.py).  Never used on the product path")
     return ap.parse_args(argv)
+
+
+def _resolve_factory(ref):
+    mod, _, attr = ref.rpartition(":")
+    if mod.endswith(".py"):
+        import importlib.util
+        sp = importlib.util.spec_from_file_location("_bench_engine_factory", mod)
+        m = importlib.util.module_from_spec(sp)
+        sp.loader.exec_module(m)
+    else:
+        import importlib
+        m = importlib.import_module(mod)
+    return getattr(m, attr)
+
+
+def launch_ranks(args, argv, timeout_s=3600.0):
+    """--gpus N > 1 from a plain process: start N ranks of this script, one per GPU, and relay rank 0's line.
+
+    The parent does not call into torch.cuda / HIP at all (the children are fork+exec'd from it; a process that has
+    initialised the GPU must not exec).  Children get the torchrun variables; stdout of rank 0 is captured and
+    re-printed, every other stream is inherited.  The first rank that exits non-zero ends the job: the remaining
+    children are terminated by PID and the parent exits with that code.  Returns rank 0's parsed JSON line."""
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = os.path.abspath(__file__)
+    cmd = [sys.executable, script] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    log(f"[bench] launcher: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+    captured = []
+    reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    t0, failed = time.time(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > timeout_s:
+            failed = (-1, 124)
+            break
+        time.sleep(0.1)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        raise SystemExit(f"[bench] rank {failed[0]} exited with code {failed[1]}; job aborted")
+    reader.join(10)
+    text = captured[0] if captured else ""
+    line = None
+    for ln in text.splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None:
+        raise SystemExit("[bench] rank 0 printed no JSON line")
+    out = json.loads(line)
+    if out.get("n_gpus") != n or out.get("ranks_seen") != n:
+        raise SystemExit(f"[bench] asked for {n} ranks, line says n_gpus={out.get('n_gpus')} ranks_seen={out.get('ranks_seen')}")
+    print(line, flush=True)
+    return out
 
 
 def timed_region(step_fn, first, K, sync, ldist, dev):
@@ -167,13 +253,28 @@ def main(argv=None, engine_factory=None, device=None):
     """engine_factory / device: test hooks (tests/test_dist_rollout.py drives this function on CPU over gloo with a
     stand-in engine so that the N > 1 code path -- shard, step, all-gather, max over ranks -- is executed without GPUs)."""
     args = parse_args(argv)
+    cli_stub = engine_factory is None and bool(args.engine_factory)
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            if engine_factory is not None:
+                raise SystemExit("bench.main: a callable engine_factory cannot cross into child ranks; pass --engine-factory")
+            return launch_ranks(args, sys.argv[1:] if argv is None else argv)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to run a "
+                         "mislabelled job (launch with --nproc-per-node equal to --gpus)")
+    if cli_stub:
+        engine_factory = _resolve_factory(args.engine_factory)
     from lram_amd import dist as ldist, init_state_dict, preset
     stub = engine_factory is not None
+    if not stub:
+        _, _, lr = ldist.dist_env()
+        if torch.cuda.device_count() <= lr:      # before any rendezvous: a missing GPU must not leave the others waiting
+            raise SystemExit(f"bench.py: rank with LOCAL_RANK={lr} has no HIP device ({torch.cuda.device_count()} visible); "
+                             "the engine has no CPU fallback")
     if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the engine has no CPU fallback")
     rank, world, local_rank = ldist.init_distributed("gloo" if stub else None)
-    if world != args.gpus:
-        log(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    assert world == args.gpus
     if stub:
         dev = torch.device("cpu") if device is None else torch.device(device)
     else:
@@ -279,10 +380,11 @@ def main(argv=None, engine_factory=None, device=None):
     else:
         kern_ms, kern_n, fold_ms, fold_n = 0.0, 0, 0.0, 0
     value = global_batch * K / wall
+    ranks_seen = ldist.count_ranks(dev)
 
     out = {
         "metric": "env-steps/sec (action-inference)", "value": value, "unit": "env-steps/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3, "higher_is_better": True,
+        "n_gpus": world, "ranks_seen": ranks_seen, "steps": K, "warmup": W, "ms_per_step": wall / K * 1e3, "higher_is_better": True,
         "scaling": "strong" if args.global_batch > 0 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"{args.config}: xLSTM[7:1] 16M rollout, {B} env slots per GPU, 3 tokens/timestep, "
                                 "cheetah-run-shaped obs (17 of 204 dims), continuous 8x274 head; fp32 state and "
@@ -300,6 +402,8 @@ def main(argv=None, engine_factory=None, device=None):
         "inputs": "resident in HBM before the timed region (obs ring, per-step rtg and reset masks)",
     }
     if stub:
+        if cli_stub and rank == 0:
+            print(json.dumps(dict(out, last_actions=last.tolist())), flush=True)
         out["last_actions"] = last
         if world > 1:
             torch.distributed.destroy_process_group()

@@ -211,8 +211,12 @@ int32_t lram_get_compat_mode(const lram_engine* e, int32_t* mamba_repeat, int32_
  *           gate projections in one launch, each token's recurrent GEMV with its pointwise cell -- 40 launches per
  *           env-step of the 16M stack;
  *   mode 1  whole-step kernel: the same phases as ONE cooperative launch whose workgroups meet at device-wide barriers
- *           (agent-scope release / acquire).  A barrier that cannot complete times out (bounded spin): that call's results
- *           are invalid, the next lram_step reports it and leaves the mode.
+ *           (agent-scope release / acquire).  A barrier that cannot complete times out (bounded spin, wall-clock: a
+ *           co-tenant kernel that delays co-residency of the grid can trip it): that call -- and any call already
+ *           enqueued behind it -- writes NaN actions and token -1 instead of results, the NEXT lram_step returns the
+ *           error and leaves the mode, so an asynchronous caller of mode 1 must check the following call's return code
+ *           (or the actions for NaN).  lram_set_persistent_mode(e, 1) drains the device and clears the barrier counter
+ *           and error words, so the mode can be entered again.
  * Both are parity-tested against the oracle, and both measure SLOWER than the generic path on MI355X (16M stack, one
  * env: 0.374 ms generic, 0.410 ms fused, 0.76 ms whole-step): the step is a chain of ~70 dependent
  * memory round trips, fusing them into fewer launches does not shorten the chain, and a device-wide barrier costs an

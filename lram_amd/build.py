@@ -9,7 +9,12 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["engine.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "xlstm_kernels.hip", "mlstm_chunk.hip", "mlstm_lazy.hip", "impala_cnn.hip", "misc_kernels.hip", "mamba_kernels.hip",
            "selftest.hip"]
-HEADERS = ["common.h", "device_math.h", os.path.join("..", "..", "include", "lram_hip.h")]
+import glob
+
+# every header / include fragment of csrc counts as a dependency of every object (a stale .so on the GPU box would run
+# old kernels without a word): *.h and *.inl are globbed, so a new fragment cannot be forgotten here
+HEADERS = sorted(os.path.basename(f) for f in glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inl"))) \
+    + [os.path.join("..", "..", "include", "lram_hip.h")]
 LIB = os.path.join(CSRC, "liblram_hip.so")
 
 

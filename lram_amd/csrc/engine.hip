@@ -146,7 +146,8 @@ struct lram_engine {
   size_t ucols = 0, icols = 0;  // allocated row pitch of U and of Q/K/V/XA/H/G (slice offsets use these)
   // whole-step cooperative kernel for small batches (persistent_step.inl)
   int persist_mode = 2;                      // small-batch path: 0 generic launches, 1 whole-step cooperative kernel,
-                                             // 2 auto (= 3 where supported), 3 fused phase kernels (LRAM_PERSISTENT)
+                                             // 2 auto (= 0: the generic launches measured fastest), 3 fused phase kernels
+                                             // (LRAM_PERSISTENT)
   int persist_wgs = 128;                     // workgroups of the cooperative launch (LRAM_PERSIST_WGS)
   PersistBlock* persist_blocks = nullptr;    // device array, one entry per block
   unsigned long long* persist_counter = nullptr;  // device: [0] barrier arrivals, [1] abort word
@@ -1243,10 +1244,17 @@ void embed_images(lram_engine* e, const uint8_t* images, int C, int H, int W, fl
 }
 
 // ---- whole-step cooperative kernel (small batches) ---------------------------------------------------------
-bool persist_supported(const lram_engine* e) {
+// mode: 1 whole-step cooperative kernel, 3 fused phase kernels.  The sLSTM head dim only matters for stacks that have
+// sLSTM blocks: the whole-step kernel walks it in 4-element lane groups, the fused per-token recurrent phase in
+// 16-element chunks (launch_xlstm_small_batch_step) -- a geometry accepted here must not throw in lram_step.
+bool persist_supported(const lram_engine* e, int mode) {
   const lram_config& c = e->cfg;
   if (c.backbone != LRAM_BACKBONE_XLSTM || c.tokens_per_step != 3 || e->B < 1 || e->B > kPersistMaxBatch) return false;
-  if ((c.inner / c.n_heads) % 64 != 0 || (c.d_model / c.n_heads) % 4 != 0) return false;
+  if ((c.inner / c.n_heads) % 64 != 0 || c.d_model % 4 != 0 || c.ffn_dim % 4 != 0) return false;
+  bool has_slstm = false;
+  for (int i = 0; i < c.n_blocks; ++i) has_slstm = has_slstm || c.block_is_slstm[i] != 0;
+  const int sdh = c.d_model / c.n_heads;
+  if (has_slstm && sdh % (mode == 3 ? 16 : 4) != 0) return false;
   PersistArgs a{};
   a.B = e->B, a.D = c.d_model, a.inner = c.inner, a.DH = c.inner / c.n_heads, a.SDH = c.d_model / c.n_heads, a.F = c.ffn_dim;
   return xlstm_persistent_lds_bytes(a, 3) <= 120 * 1024;
@@ -1255,7 +1263,8 @@ bool persist_supported(const lram_engine* e) {
 // 0: generic launch-per-kernel path, 1: whole-step cooperative kernel, 3: fused phase kernels
 int persist_path(const lram_engine* e) {
   if (e->persist_mode == 0 || e->graph_mode || (e->lazy && e->lazy_ready) || e->prof_on) return 0;
-  if (e->persist_blocks == nullptr || !persist_supported(e)) return 0;
+  if (e->persist_mode != 1 && e->persist_mode != 3) return 0;
+  if (e->persist_blocks == nullptr || !persist_supported(e, e->persist_mode)) return 0;
   if (e->persist_mode == 1) return (e->persist_err != nullptr && *e->persist_err != 0) ? 0 : 1;
   // auto keeps the generic launches: measured on MI355X at one env of the 16M stack 0.374 ms per env-step against
   // 0.410 ms for the fused phase kernels and 0.76 ms for the whole-step kernel (8 envs: 0.54 / 1.17 / 1.74 ms)
@@ -1266,7 +1275,7 @@ int persist_path(const lram_engine* e) {
 void persist_prepare(lram_engine* e) {
   if (e->persist_blocks) (void)hipFree(e->persist_blocks);
   e->persist_blocks = nullptr;
-  if (!persist_supported(e)) return;
+  if (!persist_supported(e, 1) && !persist_supported(e, 3)) return;
   const lram_config& c = e->cfg;
   std::vector<PersistBlock> host(c.n_blocks);
   for (int i = 0; i < c.n_blocks; ++i) {
@@ -1770,9 +1779,18 @@ int32_t lram_set_persistent_mode(lram_engine* e, int32_t mode) {
     LRAM_REQUIRE(e != nullptr && mode >= 0 && mode <= 3,
                  "lram_set_persistent_mode: mode must be 0 (generic launches), 1 (whole-step kernel), 2 (auto) or 3 (fused "
                  "phase kernels)");
-    LRAM_REQUIRE((mode != 1 && mode != 3) || e->B == 0 || persist_supported(e),
+    LRAM_REQUIRE((mode != 1 && mode != 3) || e->B == 0 || persist_supported(e, mode),
                  "lram_set_persistent_mode: the small-batch paths cover xLSTM stacks with 3 tokens per timestep and at most "
-                 "8 env slots");
+                 "8 env slots (sLSTM head dim a multiple of 4 for mode 1, of 16 for mode 3)");
+    if (mode == 1 && e->persist_counter != nullptr) {
+      // (re-)enabling the whole-step kernel starts from a clean barrier: counter, abort word and the host-mapped error
+      // word are cleared once everything enqueued so far has drained (a timed-out call leaves all three set)
+      LRAM_HIP_CHECK(hipSetDevice(e->device));
+      LRAM_HIP_CHECK(hipDeviceSynchronize());
+      LRAM_HIP_CHECK(hipMemset(e->persist_counter, 0, 2 * sizeof(unsigned long long)));
+      e->persist_base = 0;
+      if (e->persist_err) *e->persist_err = 0;
+    }
     e->persist_mode = mode;
   });
 }

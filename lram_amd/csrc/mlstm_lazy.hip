@@ -652,7 +652,11 @@ void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
     if (T == 3 && unroll == 8) return launch_cell_tluk<T, 64, 8, 4>(a, s);
     return launch_cell_tluk<T, 64, 16, 4>(a, s);
   }
-  if (a.DH == 128) return launch_cell_tluk<T, 32, 16, 0>(a, s);  // one column slice per head: fused scores
+  // one column slice per head: fused scores (mlstm_lazy_fused_scores: the engine allocates no score buffer and runs the
+  // lean front end for these head dims, so every branch for them must be a fused-score instance -- DH 256 with the
+  // k-hat register prefetch switched off takes the late-load form DH 128 uses)
+  if (a.DH == 256) return launch_cell_tluk<T, 64, 16, 0>(a, s);
+  if (a.DH == 128) return launch_cell_tluk<T, 32, 16, 0>(a, s);
   // several column slices per head: scores from mlstm_lazy_score_kernel (launch_mlstm_lazy_book)
   LRAM_REQUIRE(a.pw != nullptr, "lazy mLSTM: missing score buffer");
   // LRAM_LAZY_EXT_VARIANT (measurement knob, 206M at 512 env slots): 0 = 48-row window prefetch, 16 rows in flight

@@ -567,8 +567,19 @@ __device__ __forceinline__ void ps_argmax(const PersistArgs& p, const PersistBlo
 // ================= argmax / de-tokenise: one wave per (env, action dim) =================
 {
   const int ndim = p.discrete ? 1 : p.act_dim;
+  // a device-wide barrier of the whole-step kernel timed out somewhere before this phase: the logits are not to be
+  // trusted, and callers enqueue asynchronously (the error code only reaches them with the NEXT lram_step) -- poison
+  // what this call hands back (NaN actions, token -1) so that nothing downstream can consume it as a result
+  const bool aborted = p.abort_dev != nullptr && __hip_atomic_load(p.abort_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
   for (int item = wg * 4 + wave; item < B * ndim; item += nwg * 4) {
     const int b = item / ndim, j = item - b * ndim;
+    if (aborted) {
+      if (lane == 0) {
+        if (p.tokens != nullptr) p.tokens[(int64_t)b * p.act_dim + j] = -1;
+        p.actions[(int64_t)b * p.act_dim + j] = __builtin_nanf("");
+      }
+      continue;
+    }
     const float* lg = p.LOGITS + (int64_t)b * p.act_dim * p.n_vocab + (int64_t)j * p.n_vocab;
     const int n = p.discrete ? p.n_discrete : p.n_vocab;
     float best = -INFINITY;

@@ -29,9 +29,11 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local_rank)   # binds the communicator; barrier() need not guess
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
 
 
@@ -66,6 +68,15 @@ def all_gather_actions(local_actions: torch.Tensor, total: Optional[int] = None)
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def count_ranks(device) -> int:
+    """Number of ranks that actually take part: an all-reduce of one 1 per rank (1 without a process group)."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
 
 
 def max_over_ranks(value: float, device) -> float:

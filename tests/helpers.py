@@ -49,8 +49,17 @@ def _as_double(x):
 
 
 def rel_err(a, b):
+    """max |a - b| / max |b|: one number for the whole tensor (a large element sets the scale for all)."""
     a, b = _as_double(a), _as_double(b)
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def elem_rel_err(a, b, floor=1e-3):
+    """Per-element relative error max_i |a_i - b_i| / (|b_i| + floor * max|b|): for state tensors whose entries span
+    orders of magnitude (matrix memory C, normaliser n), where rel_err lets one large element hide relative error
+    everywhere else.  The floor keeps entries that are cancellation noise (< floor * max) from dominating."""
+    a, b = _as_double(a), _as_double(b)
+    return float(((a - b).abs() / (b.abs() + floor * b.abs().max() + 1e-30)).max())
 
 
 class Fp64Oracle:
@@ -80,15 +89,34 @@ class Fp64Oracle:
             torch.set_default_dtype(self._prev)
 
 
-def assert_close_or_as_close_as_fp32_oracle(got, ref32, ref64, tol=2e-4, factor=8.0, what=""):
+RELAXED_ROWS = {"rows": 0, "relaxed": 0}   # running count over a test (reset with relaxed_rows_reset)
+
+
+def relaxed_rows_reset():
+    RELAXED_ROWS["rows"] = RELAXED_ROWS["relaxed"] = 0
+
+
+def relaxed_rows_fraction():
+    return RELAXED_ROWS["relaxed"] / max(1, RELAXED_ROWS["rows"])
+
+
+def assert_close_or_as_close_as_fp32_oracle(got, ref32, ref64, tol=2e-4, factor=8.0, cap=5e-3, what=""):
     """|got - ref32| <= tol * scale, or -- per row of the last axis -- got is within `factor` x the fp32 oracle's own
-    distance from the fp64 result."""
+    distance from the fp64 result AND within `cap` * scale of it in absolute terms (the escape hatch is for
+    ill-conditioned rows, not for regressions: however far the fp32 oracle itself drifts, the engine may not be further
+    than `cap` from the exact result).  Rows that needed the relaxed branch are counted in RELAXED_ROWS so callers can
+    bound their share (`relaxed_rows_fraction`)."""
     got, ref32, ref64 = _as_double(got), _as_double(ref32), _as_double(ref64)
     scale = float(ref64.abs().max()) + 1e-12
     err_engine = (got - ref64).abs().amax(dim=-1)
     err_oracle = (ref32 - ref64).abs().amax(dim=-1)
     direct = (got - ref32).abs().amax(dim=-1)
-    ok = (direct <= tol * scale) | (err_engine <= factor * err_oracle)
+    strict = direct <= tol * scale
+    relaxed = (err_engine <= torch.clamp(factor * err_oracle, max=cap * scale)) & ~strict
+    RELAXED_ROWS["rows"] += strict.numel()
+    RELAXED_ROWS["relaxed"] += int(relaxed.sum())
+    ok = strict | relaxed
     assert bool(ok.all()), (f"{what}: engine vs fp32 oracle {float(direct.max() / scale):.2e}, engine vs fp64 "
-                            f"{float(err_engine.max() / scale):.2e}, fp32 oracle vs fp64 {float(err_oracle.max() / scale):.2e}")
-    return float((err_engine / (err_oracle + 1e-30))[direct > tol * scale].max()) if bool((direct > tol * scale).any()) else 0.0
+                            f"{float(err_engine.max() / scale):.2e}, fp32 oracle vs fp64 {float(err_oracle.max() / scale):.2e} "
+                            f"(cap {cap:.0e})")
+    return float((err_engine / (err_oracle + 1e-30))[~strict].max()) if bool((~strict).any()) else 0.0

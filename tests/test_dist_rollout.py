@@ -69,25 +69,7 @@ def test_env_sharded_rollout_equals_single_process(total):
     assert mx == 2.0
 
 
-class _StubEngine:
-    """Stands in for lram_amd.engine.Engine inside bench.main on CPU: actions are a fixed function of the inputs, so
-    the sharded + gathered result can be compared with a single-process run."""
-
-    def __init__(self, spec, batch, device):
-        self.spec, self.batch, self.device = spec, batch, device
-        self.state_mode = "materialised"
-        self.steps = 0
-
-    def set_micro_batches(self, n):
-        pass
-
-    def set_graph_mode(self, on):
-        pass
-
-    def step(self, obs, rtg, reward, reset_mask=None, **kw):
-        self.steps += 1
-        a = obs[:, :self.spec.act_dim] * 0.5 + rtg.view(-1, 1) + reset_mask.float().view(-1, 1)
-        return a, None
+from tests.stub_engine import StubEngine as _StubEngine  # noqa: E402
 
 
 def _bench_worker(rank, world, port, argv, q):
@@ -135,6 +117,62 @@ def test_bench_multi_rank_code_path_on_gloo(argv, total):
     assert abs(line0["value"] - total * 3 / (line0["ms_per_step"] * 3e-3)) < 1e-6 * line0["value"]
     a0, a1 = torch.tensor(act0), torch.tensor(act1)
     assert a0.shape == (total, 4) and torch.equal(a0, a1)     # every rank holds the full gathered action tensor
+
+
+def test_bench_starts_its_own_ranks_from_a_plain_process(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun environment must run TWO ranks (round-2 review: it ran one and said
+    so only in a warning).  The parent starts the children itself and relays rank 0's line; n_gpus and ranks_seen (an
+    all-reduce of ones) both say 2.  Stand-in engine over gloo, through the same entry point the driver uses."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    factory = os.path.join(root, "tests", "stub_engine.py") + ":factory"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--config",
+           "xlstm_tiny", "--batch", "6", "--engine-factory", factory]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                     # ONE JSON line, rank 0's, relayed by the parent
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["config"]["global_batch"] == 12 and line["config"]["batch_per_gpu"] == 6
+    assert torch.tensor(line["last_actions"]).shape == (12, 4)
+    # same through bench.main from a plain process (no WORLD_SIZE): the parsed line comes back
+    import bench
+    saved = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}
+    try:
+        out = bench.main(cmd[2:])
+    finally:
+        os.environ.update(saved)
+    assert out["n_gpus"] == 2 == out["ranks_seen"]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "xlstm_tiny",
+                          "--engine-factory", os.path.join(root, "tests", "stub_engine.py") + ":factory"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "WORLD_SIZE" in res.stderr
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """A rank that dies takes the job down with a non-zero exit instead of leaving the others in the rendezvous."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "xlstm_tiny",
+                          "--steps", "2", "--warmup", "1", "--batch", "4",
+                          "--engine-factory", os.path.join(root, "tests", "stub_engine.py") + ":factory_rank1_dies"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "job aborted" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
 
 
 class _FakeAgent:

@@ -7,8 +7,8 @@ import torch
 
 from lram_amd import init_state_dict, preset
 from oracle import dt_ref
-from tests.helpers import (Fp64Oracle, assert_actions_match, assert_close_or_as_close_as_fp32_oracle, make_inputs,
-                           rel_err)
+from tests.helpers import (Fp64Oracle, assert_actions_match, assert_close_or_as_close_as_fp32_oracle, elem_rel_err,
+                           make_inputs, rel_err, relaxed_rows_fraction, relaxed_rows_reset)
 
 pytestmark = pytest.mark.gpu
 
@@ -94,6 +94,8 @@ def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=
     ora = dt_ref.OraclePolicy(spec, sd)
     o64 = Fp64Oracle(spec, sd) if cond_aware else None
     ties = 0
+    relaxed_rows_reset()
+    worst_elem = 0.0
     # fixed device buffers so that graph mode sees stable pointers
     d_obs = torch.empty(B, spec.state_dim, device="cuda:0")
     d_rtg = torch.empty(B, device="cuda:0")
@@ -135,11 +137,27 @@ def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=
             if "mlstm_state" in blk:
                 for j in range(3):
                     close(blk["mlstm_state"][j], ref["mlstm_state"][j], r64["mlstm_state"][j], f"mlstm state {i}.{j}")
+                if not cond_aware:
+                    # C and n entries span orders of magnitude: besides max-error / max-value, every entry must be right
+                    # relative to ITSELF (entries below 1e-3 of the largest are measured against that floor)
+                    for j in range(2):
+                        e = elem_rel_err(blk["mlstm_state"][j], ref["mlstm_state"][j])
+                        worst_elem = max(worst_elem, e)
+                        assert e < ELEM_STATE_TOL, f"mlstm state {i}.{j}: per-element relative error {e:.2e}"
             else:   # [4, B, D] -> env-major
                 close(blk["slstm_state"].transpose(0, 1), ref["slstm_state"].transpose(0, 1),
                       r64["slstm_state"].transpose(0, 1), f"slstm state {i}")
     eng.close()
+    # the fp64-aware escape hatch must stay the exception: at most 5 % of the compared rows may need it
+    assert relaxed_rows_fraction() <= 0.05, f"{name}: {relaxed_rows_fraction():.1%} of the rows needed the fp64 rule"
+    import os
+    if os.environ.get("LRAM_TEST_REPORT"):
+        print(f"[report] {name} B={B}: worst per-element state error {worst_elem:.2e}, relaxed rows "
+              f"{relaxed_rows_fraction():.2%}")
     return ties
+
+
+ELEM_STATE_TOL = 2e-2   # per-element |err| / (|ref| + 1e-3 max|ref|) of C / n after a trajectory (fp32 both sides)
 
 
 def test_xlstm_tiny_trajectory(hip_lib):
