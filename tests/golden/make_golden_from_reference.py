@@ -561,6 +561,191 @@ def evaluate_policy_trace(g):
             "episode_rewards": [float(x) for x in rewards_out], "episode_lengths": [int(x) for x in lengths_out]}
 
 
+def _exec_classes(path, names, ns):
+    """Execute whole class definitions of a reference file (every method, the real inheritance chain, zero-argument
+    `super()` intact) in a namespace that supplies stand-ins for the bases / imports the file cannot get here."""
+    import ast
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+    assert len(keep) == len(names), (path, names)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def xlstm_model_trace():
+    """The reference's xLSTM inference wrapper, executed end to end around a stand-in block stack.
+
+    Reference classes executed WHOLE (AST class definitions, their own inheritance chain):
+      OnlineDecisionTransformerOutput, OnlineDecisionTransformerModel   (online_decision_transformer_model.py:15-760:
+          forward :326-390, compute_hidden_states :392-460 incl. the `x[:, -seq_length*len(inputs):]` slice and the
+          [B, tokens, seq, D] permute, compute_inputs / embed_inputs / prepare_inputs_and_masks :463-612)
+      DiscreteDTModel            (discrete_decision_transformer_model.py: construct_inputs_and_masks :236-316,
+          action_log_prob_logits :318-347, get_predictions :368-383 -- action read at tok_to_pred_pos["a"])
+      MultiDomainDiscreteDTModel (multi_domain_discrete_dt_model.py:83-108 head post-processing)
+      xLSTMEncoder, DecisionXLSTMModel, MultiDomainDiscreteDecisionXLSTMModel (decision_xlstm.py: xLSTMEncoder.forward
+          :138-169 -- one `self.layers.step` per token, hidden states concatenated; handle_inference_cache :222-234)
+    and, as plain methods on a stand-in agent, DecisionTransformerSb3.predict (decision_transformer_sb3.py:621-667),
+    DecisionXLSTM.pad_inputs (algos/decision_xlstm.py:11-28), DiscreteDecisionTransformerSb3.get_action_pred
+    (discrete_decision_transformer_sb3.py:13-72).  Stand-ins: the transformers / xlstm base classes are empty classes
+    (no __init__ is run; the instance gets plain nn modules carrying the seeded test weights), and `encoder.layers` is an
+    object whose `.step(x, state)` is the oracle's `xlstm_ref.stack_step` -- the xlstm package is absent, so the vector
+    pins everything AROUND the block stack (what is embedded when, which tokens reach the stack, how the state is handed
+    over and dropped, where the action is read), not the block arithmetic.
+    Two envs, each rolled out on its own at batch 1 as the reference does (evaluation.py:80), context_len 5,
+    reset_inf_cache_freq 3 (cache drops), one episode end for env 1 (evaluation.py:238-251 sets past_key_values None)."""
+    from dataclasses import dataclass
+    from types import SimpleNamespace
+    from typing import Optional, Tuple, Union
+    import torch.nn as nn
+    from transformers.modeling_outputs import BaseModelOutputWithPastAndCrossAttentions
+    from transformers.models.decision_transformer.modeling_decision_transformer import DecisionTransformerOutput
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    sys.path.insert(0, REF)
+    from lram_amd import init_state_dict, preset
+    from oracle import xlstm_ref
+    from src.tokenizers_custom import make_tokenizer
+
+    class _Base:   # stands in for transformers' DecisionTransformerModel / PreTrainedModel: no behaviour at all
+        pass
+
+    rms = importlib.util.spec_from_file_location("ref_rms_norm", os.path.join(REF, "src/algos/models/rms_norm.py"))
+    rms_mod = importlib.util.module_from_spec(rms)
+    rms.loader.exec_module(rms_mod)
+    ns = {"torch": torch, "nn": nn, "dataclass": dataclass, "DecisionTransformerModel": _Base, "PreTrainedModel": _Base,
+          "DecisionTransformerOutput": DecisionTransformerOutput, "Optional": Optional, "Tuple": Tuple, "Union": Union,
+          "BaseModelOutputWithPastAndCrossAttentions": BaseModelOutputWithPastAndCrossAttentions,
+          "LlamaRMSNorm": rms_mod.LlamaRMSNorm, "DecisionTransformerConfig": object,
+          "xLSTMLayerNorm": type(None), "MultiHeadLayerNorm": type(None), "LinearHeadwiseExpand": type(None)}
+    models = os.path.join(REF, "src/algos/models")
+    _exec_classes(os.path.join(models, "online_decision_transformer_model.py"),
+                  ["OnlineDecisionTransformerOutput", "OnlineDecisionTransformerModel"], ns)
+    _exec_classes(os.path.join(models, "discrete_decision_transformer_model.py"), ["DiscreteDTModel"], ns)
+    _exec_classes(os.path.join(models, "multi_domain_discrete_dt_model.py"), ["MultiDomainDiscreteDTModel"], ns)
+    _exec_classes(os.path.join(models, "decision_xlstm.py"),
+                  ["xLSTMEncoder", "DecisionXLSTMModel", "MultiDomainDiscreteDecisionXLSTMModel"], ns)
+    Model, Encoder = ns["MultiDomainDiscreteDecisionXLSTMModel"], ns["xLSTMEncoder"]
+
+    seed = 5
+    spec = preset("xlstm_tiny")
+    sd = init_state_dict(spec, seed=seed)
+    D = spec.d_model
+
+    def linear(w, b):
+        m = nn.Linear(sd[w].shape[1], sd[w].shape[0])
+        with torch.no_grad():
+            m.weight.copy_(sd[w]), m.bias.copy_(sd[b])
+        return m
+
+    def build_model():
+        me = object.__new__(Model)
+        me.config = SimpleNamespace(use_return_dict=True, output_attentions=False, output_hidden_states=False,
+                                    add_cross_attention=False, hidden_size=D, act_dim=spec.act_dim, chunkwise_step=False)
+        me.hidden_size, me.is_discrete, me.training = D, False, False
+        me.embed_state = linear("embed_state.weight", "embed_state.bias")
+        me.embed_return = linear("embed_return.weight", "embed_return.bias")
+        me.embed_rewards = linear("embed_rewards.weight", "embed_rewards.bias")
+        me.embed_ln = nn.LayerNorm(D)
+        with torch.no_grad():
+            me.embed_ln.weight.copy_(sd["embed_ln.weight"]), me.embed_ln.bias.copy_(sd["embed_ln.bias"])
+        me.action_net = Model.make_head(D, spec.n_vocab * spec.act_dim, 1)     # the reference's own head factory
+        with torch.no_grad():
+            me.action_net[0].weight.copy_(sd["action_net.0.weight"]), me.action_net[0].bias.copy_(sd["action_net.0.bias"])
+        torch.manual_seed(3)   # modules whose outputs the rollout never reads (they are evaluated all the same)
+        me.predict_state, me.predict_return, me.predict_reward = nn.Linear(D, spec.state_dim), nn.Linear(D, 1), nn.Linear(D, 1)
+        me.embed_action_disc = nn.Embedding(spec.n_vocab + 1, D, padding_idx=spec.n_vocab)
+        me.action_pad_token, me.a_pos_embds = None, False
+        me.action_tokenizer = make_tokenizer("minmax", {"vocab_size": spec.action_channels, "shift": spec.n_discrete})
+        me.rtg_condition, me.reward_condition, me.action_condition = True, True, False
+        me.use_time_embds, me.symlog_transform, me.img_is_encoded, me.separate_ln = False, False, False, False
+        me.tokenize_s, me.tokenize_rtg, me.tokenize_r, me.tokenize_a = False, False, False, True
+        me.tok_a_target_only, me.tok_rtg_target_only, me.shared_a_head, me.stochastic_policy = False, False, True, False
+        me.patch_size, me.discrete_actions, me.num_actions = None, spec.n_discrete, spec.n_vocab
+        me.action_channels, me.num_task_heads, me.global_pos_embds, me.inf_dummy_batch_size = spec.action_channels, 1, False, None
+        me.p_mask, me.p_token_drop = 0, 0
+        enc = object.__new__(Encoder)
+        enc.config = me.config
+        calls = []
+
+        class Layers:   # [3P] xLSTMBlockStack stand-in: `.step` is the oracle's restatement
+            def step(self, x, state=None):
+                calls.append((tuple(x.shape), state is None))
+                return xlstm_ref.stack_step(spec, sd, x, state)
+        enc.layers = Layers()
+        me.encoder = lambda **kw: enc.forward(**kw)
+        return me, calls
+
+    fns = {}
+    fns.update(_exec_methods(os.path.join(REF, "src/algos/decision_transformer_sb3.py"), "DecisionTransformerSb3", ["predict"]))
+    fns.update(_exec_methods(os.path.join(REF, "src/algos/decision_xlstm.py"), "DecisionXLSTM", ["pad_inputs"]))
+    fns.update(_exec_methods(os.path.join(REF, "src/algos/discrete_decision_transformer_sb3.py"),
+                             "DiscreteDecisionTransformerSb3", ["get_action_pred"]))
+    Agent = type("Agent", (), {k: fns[k] for k in ("predict", "pad_inputs", "get_action_pred")})
+
+    steps, freq, ctx = 9, 3, 5
+    env_act_dims, obs_dims = [4, 3], [20, 13]
+    episode_end_after = [set(), {4}]
+    g = torch.Generator().manual_seed(2024)
+    out_envs = []
+    for e in range(2):
+        model, calls = build_model()
+        ag = Agent()
+        ag.transforms, ag.s_proj_dim, ag.a_proj_dim, ag.s_proj_raw = None, None, None, False
+        ag.state_mean = ag.state_std = None
+        ag.reset_inf_cache_freq, ag.past_key_values, ag.use_inference_cache = freq, None, True
+        ag.ddp_kwargs, ag.target_return_type, ag.a_sample_kwargs = {}, "predefined", None
+        ag.use_amp, ag.amp_dtype, ag.device = False, torch.bfloat16, torch.device("cpu")
+        ag.replay_buffer = SimpleNamespace(max_state_dim=spec.state_dim, max_act_dim=spec.act_dim)
+        ag.policy = model
+        ad, od = env_act_dims[e], obs_dims[e]
+        obs_all = torch.rand(steps + 1, od, generator=g) * 2 - 1
+        env_rewards = torch.rand(steps, generator=g)
+        reward_scale, rtg0 = 10.0, 3.5
+        # the rollout bookkeeping of custom_evaluate_policy (evaluation.py:104-177, :238-251 at an episode end)
+        states, actions, rewards = obs_all[:1].clone(), torch.zeros((0, ad)), torch.zeros(0)
+        target_return, timesteps, t_ep = torch.tensor(rtg0).reshape(1, 1), torch.tensor(0).reshape(1, 1), 0
+        rec = {"returned": [], "hidden": [], "logits": [], "rtg_in": [], "cache_is_none": [], "stack_calls": []}
+        with torch.no_grad():
+            for t in range(steps):
+                actions = torch.cat([actions, torch.zeros((1, ad))], dim=0)
+                rewards = torch.cat([rewards, torch.zeros(1)])
+                rec["cache_is_none"].append(ag.past_key_values is None)
+                rec["rtg_in"].append(float(target_return[0, -1]))
+                n0 = len(calls)
+                seen = {}
+
+                def policy(**inputs):
+                    o = model.forward(**inputs)
+                    seen["hidden"], seen["logits"] = o.last_encoder_output, o.action_logits
+                    return o
+                a, _ = ag.predict(policy, states, actions, rewards, target_return, timesteps, state=None, episode_start=None,
+                                  deterministic=True, context_len=ctx, prompt=None, task_id=None, is_eval=True, env_act_dim=ad)
+                rec["returned"].append(a.tolist())
+                rec["hidden"].append(seen["hidden"][0, :, 0].tolist())      # [tokens, D]: x[:, tok, t] of the reference
+                rec["logits"].append(seen["logits"][0, -1].tolist())        # [act_dim, n_vocab]
+                rec["stack_calls"].append([[list(sh), fresh] for sh, fresh in calls[n0:]])
+                actions[-1] = a
+                rewards[-1] = env_rewards[t] / reward_scale
+                t_ep += 1
+                if t in episode_end_after[e]:
+                    states, actions, rewards = obs_all[t + 1: t + 2].clone(), torch.zeros((0, ad)), torch.zeros(0)
+                    target_return, timesteps, t_ep = torch.tensor(rtg0).reshape(1, 1), torch.tensor(0).reshape(1, 1), 0
+                    ag.past_key_values = None
+                    continue
+                states = torch.cat([states, obs_all[t + 1: t + 2]], dim=0)
+                target_return = torch.cat([target_return, (target_return[0, -1] - env_rewards[t] / reward_scale).reshape(1, 1)], dim=1)
+                timesteps = torch.cat([timesteps, torch.ones((1, 1), dtype=torch.long) * t_ep], dim=1)
+        final = ag.past_key_values
+        rec["final_state_is_none"] = final is None
+        if final is not None:
+            rec["final_mlstm_n_block0"] = final["block_0"]["mlstm_state"][1].reshape(-1).tolist()
+            rec["final_slstm_block1"] = final["block_1"]["slstm_state"].reshape(-1).tolist()
+        out_envs.append({"obs": obs_all.tolist(), "env_rewards": env_rewards.tolist(), "env_act_dim": ad, "obs_dim": od,
+                         "episode_end_after_step": sorted(episode_end_after[e]), **rec})
+    return {"preset": "xlstm_tiny", "weight_seed": seed, "reset_inf_cache_freq": freq, "context_len": ctx,
+            "reward_scale": 10.0, "target_return0": 3.5, "tok_to_pred_pos_a": int(model.tok_to_pred_pos["a"]),
+            "tok_to_pos": {k: (v if isinstance(v, int) else list(v)) for k, v in model.tok_to_pos.items()}, "envs": out_envs}
+
+
 def main():
     sys.path.insert(0, REF)
     from src.tokenizers_custom import make_tokenizer  # reference code, executed not copied
@@ -599,6 +784,7 @@ def main():
     impala_cnn_vectors(g)
     out["agent_predict_trace"] = agent_predict_trace(g)
     out["mamba_agent_trace"] = mamba_agent_trace()
+    out["xlstm_model_trace"] = xlstm_model_trace()
     out["load_model_weights_trace"] = load_model_weights_trace()
     out["checkpoint_key_names"] = checkpoint_key_names()
     out["reference_presets"] = reference_presets()

@@ -166,3 +166,127 @@ def test_oracle_mamba_compat_modes_follow_the_executed_reference_control_flow(re
         for t in range(obs.shape[0]):
             d += int((o.step(obs[t], rtg[t], torch.zeros(obs.shape[1]), masks[t])[:, :R] != want[t]).sum())
         assert d > 0, kw
+
+
+# ---- the reference's xLSTM inference wrapper, executed (make_golden_from_reference.py::xlstm_model_trace) ------------
+def _xlstm_trace_env(v, e):
+    import torch.nn.functional as Fn
+    spec = preset(v["preset"])
+    sd = init_state_dict(spec, seed=v["weight_seed"])
+    env = v["envs"][e]
+    obs = torch.tensor(env["obs"])
+    obs = Fn.pad(obs, (0, spec.state_dim - obs.shape[1]))     # pad_inputs: zero-pad to max_state_dim
+    return spec, sd, env, obs
+
+
+def test_oracle_policy_equals_the_executed_xlstm_wrapper(ref_vectors):
+    """`xlstm_model_trace`: MultiDomainDiscreteDecisionXLSTMModel.forward -> compute_hidden_states ->
+    handle_inference_cache -> xLSTMEncoder.forward -> get_predictions, under the executed agent chain predict ->
+    pad_inputs -> get_action_pred, with `encoder.layers.step` = the oracle's block stack.  OraclePolicy (the checker
+    every GPU parity test uses) must reproduce it exactly: the hidden state of all three tokens, the logits, the actions,
+    with the cache emptied exactly where the reference's past_key_values is None."""
+    v = ref_vectors["xlstm_model_trace"]
+    assert v["tok_to_pred_pos_a"] == 1 and v["tok_to_pos"] == {"s": [0], "rtg": 1, "r": 2}
+    for e in range(len(v["envs"])):
+        spec, sd, env, obs = _xlstm_trace_env(v, e)
+        assert spec.pred_token == v["tok_to_pred_pos_a"] and spec.tokens_per_step == 3
+        ora = dt_ref.OraclePolicy(spec, sd)
+        A = env["env_act_dim"]
+        n_drops = 0
+        for t, want in enumerate(env["returned"]):
+            # what reaches the block stack: one [1, 1, D] step call per token, a fresh state exactly on a dropped cache
+            calls = env["stack_calls"][t]
+            assert [c[0] for c in calls] == [[1, 1, spec.d_model]] * 3
+            assert [c[1] for c in calls] == [env["cache_is_none"][t], False, False]
+            mask = torch.tensor([1 if env["cache_is_none"][t] else 0], dtype=torch.uint8)
+            n_drops += int(mask[0])
+            a, dbg = ora.step(obs[t:t + 1], torch.tensor([env["rtg_in"][t]]), torch.zeros(1), mask, return_debug=True)
+            # bit-exact, except on the step after a mid-episode cache drop: there the reference embeds the whole
+            # context_len-step context in one Linear call before cutting it down to the last 3 tokens, and a 5-row
+            # matrix product may round differently from a 1-row one (last bit); actions are exact everywhere
+            multi_row = env["cache_is_none"][t] and t > 0 and (t - 1) not in env["episode_end_after_step"]
+            if env["cache_is_none"][t]:
+                drifted = multi_row        # a fresh state forgets earlier last-bit differences
+            for got, ref in ((dbg["hidden"][0], torch.tensor(env["hidden"][t])), (dbg["logits"][0], torch.tensor(env["logits"][t]))):
+                if drifted:
+                    assert torch.allclose(got, ref, rtol=0, atol=1e-5 * float(ref.abs().max())), (e, t)
+                else:
+                    assert torch.equal(got, ref), (e, t)
+            assert torch.equal(a[0, :A], torch.tensor(want)), (e, t)
+        assert n_drops >= 3                                   # start + reset_inf_cache_freq drops (+ the episode end)
+        if env["final_state_is_none"]:     # the last step fell on a reset_inf_cache_freq boundary: cache dropped after it
+            assert e == 1
+            continue
+        for got, ref in ((ora.state["block_0"]["mlstm_state"][1], env["final_mlstm_n_block0"]),
+                         (ora.state["block_1"]["slstm_state"], env["final_slstm_block1"])):
+            ref = torch.tensor(ref)
+            assert torch.allclose(got.reshape(-1), ref, rtol=0, atol=1e-5 * float(ref.abs().max()))
+
+
+class _OracleBackedEngine:
+    """Engine stand-in for CPU tests of the agent surface: lram_step / lram_reset semantics on top of OraclePolicy."""
+
+    def __init__(self, spec, sd):
+        self.ora, self.device, self._pending = dt_ref.OraclePolicy(spec, sd), torch.device("cpu"), True
+
+    def step(self, obs, rtg, rew, reset_mask, discrete=False, obs_is_embedding=False):
+        mask = torch.tensor([1 if self._pending else 0], dtype=torch.uint8)
+        self._pending = False
+        return self.ora.step(obs, rtg, rew, mask, discrete=discrete), None
+
+    def reset(self, mask=None):
+        self._pending = True
+
+
+def run_agent_over_xlstm_trace(make_agent, v, e, atol=0.0):
+    """Drive an agent's reference surface (predict / past_key_values = None) through the rollout bookkeeping of
+    custom_evaluate_policy exactly as the trace generator did; returns the largest action difference."""
+    spec, sd, env, _ = _xlstm_trace_env(v, e)
+    agent = make_agent(spec, sd)
+    A, obs_all, env_r = env["env_act_dim"], torch.tensor(env["obs"]), torch.tensor(env["env_rewards"])
+    scale, rtg0, ends = v["reward_scale"], v["target_return0"], set(env["episode_end_after_step"])
+    states, actions, rewards = obs_all[:1].clone(), torch.zeros((0, A)), torch.zeros(0)
+    rtg, ts, t_ep = torch.tensor(rtg0).reshape(1, 1), torch.tensor(0).reshape(1, 1), 0
+    worst = 0.0
+    for t, want in enumerate(env["returned"]):
+        actions = torch.cat([actions, torch.zeros((1, A))])
+        rewards = torch.cat([rewards, torch.zeros(1)])
+        a, _ = agent.predict(agent.policy, states, actions, rewards, rtg, ts, deterministic=True,
+                             context_len=v["context_len"], is_eval=True, env_act_dim=A)
+        a = a.detach().cpu()
+        worst = max(worst, float((a - torch.tensor(want)).abs().max()))
+        assert worst <= atol, (e, t, a, want)
+        actions[-1] = a
+        rewards[-1] = env_r[t] / scale
+        t_ep += 1
+        if t in ends:
+            states, actions, rewards = obs_all[t + 1: t + 2].clone(), torch.zeros((0, A)), torch.zeros(0)
+            rtg, ts, t_ep = torch.tensor(rtg0).reshape(1, 1), torch.tensor(0).reshape(1, 1), 0
+            agent.past_key_values = None
+            continue
+        states = torch.cat([states, obs_all[t + 1: t + 2]])
+        rtg = torch.cat([rtg, (rtg[0, -1] - env_r[t] / scale).reshape(1, 1)], dim=1)
+        ts = torch.cat([ts, torch.full((1, 1), t_ep)], dim=1)
+    return worst
+
+
+def test_agent_surface_reproduces_the_executed_xlstm_wrapper(ref_vectors):
+    """RecurrentAgent.predict / get_action_pred / `past_key_values = None` on an oracle-backed engine stand-in: same
+    actions as the executed reference model + agent, bit for bit, over cache drops and an episode end."""
+    import dataclasses
+    from lram_amd.agent import RecurrentAgent, _InferenceParams
+    v = ref_vectors["xlstm_model_trace"]
+
+    def make(spec, sd):
+        agent = object.__new__(RecurrentAgent)
+        agent.spec = dataclasses.replace(spec, reset_inf_cache_freq=v["reset_inf_cache_freq"])
+        agent.engine, agent.device, agent.n_envs, agent.is_discrete = _OracleBackedEngine(spec, sd), torch.device("cpu"), 1, False
+        agent.policy, agent.image_encoder, agent.has_image_encoder = agent, None, False
+        agent.state_mean = agent.state_std = None
+        agent.eval_context_len, agent.reset_inf_cache_freq = v["context_len"], v["reset_inf_cache_freq"]
+        agent.reprime_context, agent._zero_reward = False, torch.zeros(1)
+        agent.inference_params = _InferenceParams(agent)
+        return agent
+
+    for e in range(len(v["envs"])):
+        assert run_agent_over_xlstm_trace(make, v, e) == 0.0
