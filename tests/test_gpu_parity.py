@@ -157,7 +157,7 @@ def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=
     return ties
 
 
-ELEM_STATE_TOL = 2e-2   # per-element |err| / (|ref| + 1e-3 max|ref|) of C / n after a trajectory (fp32 both sides)
+ELEM_STATE_TOL = 5e-3   # per-element |err| / (|ref| + 1e-3 max|ref|) of C / n after a trajectory; measured worst 8.9e-4 (16M, B = 12)
 
 
 def test_xlstm_tiny_trajectory(hip_lib):

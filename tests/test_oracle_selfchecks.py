@@ -229,3 +229,53 @@ def test_chunkwise_and_lazy_forms_equal_the_recurrent_step():
         assert torch.allclose(num / d, h_ref[t], rtol=1e-9, atol=1e-10), t
     final = g * base + sum(cj * torch.outer(kj, vj) for cj, kj, vj in zip(coef, win_k, win_v))
     assert torch.allclose(final, c.view(DH, DH), rtol=1e-9, atol=1e-10)
+
+
+def test_slstm_cell_equals_the_papers_unstabilised_recurrence():
+    """Independent cross-check of the sLSTM cell (the one oracle piece that had none): the xLSTM paper's equations
+    (Beck et al. 2024, section 2.2: c_t = f_t c_{t-1} + i_t z_t, n_t = f_t n_{t-1} + i_t, h_t = o_t c_t / n_t with
+    i = exp(i~), f = sigmoid(f~), z = tanh(z~), o = sigmoid(o~), pre-activations x~ + R h_{t-1} + b with a block-diagonal
+    (per-head) R) written as plain scalar loops in float64, WITHOUT the stabiliser state m -- which by the paper's own
+    argument cancels in c / n.  The oracle's stabilised cell (m_t = max(log f + m_{t-1}, i~), the package's first-step
+    rule) must give the same h, and its (c, n) must equal the unstabilised ones once multiplied by exp(m).  What this
+    cannot pin is the package's storage convention (gate order i, f, z, o; R as [head, in, gate, out]; bias
+    [head, gate, out]) -- that is what tests/test_backbone_golden.py is for."""
+    import math
+    NH, DH, B, T = 2, 4, 3, 9
+    H = NH * DH
+    g = torch.Generator().manual_seed(77)
+    gates = (torch.randn(T, B, 4 * H, generator=g, dtype=torch.float64) * 1.5)
+    R = torch.randn(NH, DH, 4, DH, generator=g, dtype=torch.float64) * 0.8
+    bias = torch.randn(NH, 4, DH, generator=g, dtype=torch.float64)
+    for dtype, tol in ((torch.float64, 1e-11), (torch.float32, 2e-5)):
+        states = torch.zeros(4, B, H, dtype=dtype)
+        ys = []
+        for t in range(T):
+            states = xlstm_ref.slstm_cell_step(gates[t].to(dtype), states, R.to(dtype), bias.to(dtype), NH)
+            ys.append(states[0].double())
+        for b in range(B):
+            h, c, n = [0.0] * H, [0.0] * H, [0.0] * H
+            for t in range(T):
+                h_new, c_new, n_new = [0.0] * H, [0.0] * H, [0.0] * H
+                for head in range(NH):
+                    for o in range(DH):
+                        u = head * DH + o
+                        pre = []
+                        for gi in range(4):     # gate order of the pre-activation layout: i, f, z, o
+                            acc = float(gates[t, b, gi * H + u]) + float(bias[head, gi, o])
+                            for i in range(DH):
+                                acc += h[head * DH + i] * float(R[head, i, gi, o])
+                            pre.append(acc)
+                        ig, fg = math.exp(pre[0]), 1.0 / (1.0 + math.exp(-pre[1]))
+                        zg, og = math.tanh(pre[2]), 1.0 / (1.0 + math.exp(-pre[3]))
+                        c_new[u] = fg * c[u] + ig * zg
+                        n_new[u] = fg * n[u] + ig
+                        h_new[u] = og * c_new[u] / n_new[u]
+                h, c, n = h_new, c_new, n_new
+                want = torch.tensor(h, dtype=torch.float64)
+                assert float((ys[t][b] - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (dtype, b, t)
+            # stabilised state x exp(m) = unstabilised state
+            m = states[3, b].double()
+            for got, want in ((states[1, b].double() * torch.exp(m), torch.tensor(c, dtype=torch.float64)),
+                              (states[2, b].double() * torch.exp(m), torch.tensor(n, dtype=torch.float64))):
+                assert float(((got - want).abs() / (want.abs() + 1e-9)).max()) <= 50 * tol, (dtype, b)
