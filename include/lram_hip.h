@@ -253,6 +253,13 @@ int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64
 int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                          int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                          int32_t k, void* stream);
+/* Same contract through the f16x2 kernel (each fp32 operand row scaled by a power of two and split into two binary16
+ * pieces, three f16 MFMA products accumulated in fp32, exact un-scaling: fp32-level accuracy at half the matrix-core
+ * work of bf16x3; gemm_f16x2.hip).  Splits W and computes A's row scales into temporaries, synchronises the stream:
+ * test / micro-benchmark entry. */
+int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
+                        int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
+                        int32_t k, void* stream);
 /* The same with the activation operand pre-split into three bf16 planes first (the form in which the engine's norm /
  * gate / state-update kernels hand their results to the big projections): bit-identical to lram_gemm_bf16x3. */
 int32_t lram_gemm_bf16x3_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,

@@ -67,6 +67,12 @@ struct GemmArgs {
   int64_t ldg = 0;
   // optional (bf16x3 kernel, no split-K): output columns >= act_silu_from are stored as silu(value); -1 = none
   int act_silu_from = -1;
+  // optional (f16x2 kernel): W pre-split into two f16 planes (hi, lo) of the row-scaled weight, `w2_plane` elements apart,
+  // with the exact inverse of each weight row's power-of-two scale; per-row scales of A (of the gated rows with `gate`)
+  const uint16_t* w2 = nullptr;
+  int64_t w2_plane = 0;
+  const float* w_inv = nullptr;
+  const float* a_scale = nullptr;
   // optional split-K workspace (un-batched GEMMs with few output tiles: skinny N or small M): partial [S][M][N]
   // slabs are written by S x tiles workgroups and summed, in fixed order, by a second tiny kernel (deterministic)
   float* splitk_ws = nullptr;
@@ -82,6 +88,13 @@ bool gemm_small_m(const GemmArgs& g);                             // M <= 8: lau
 bool gemm_bf16x3_supported(const GemmArgs& g);
 void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t stream);   // fp32-accurate, 3 x bf16 split operands
 void launch_split_bf16x3(const float* w, uint16_t* out, size_t n, hipStream_t stream);
+bool gemm_f16x2_supported(const GemmArgs& g);
+void launch_gemm_f16x2(const GemmArgs& g, hipStream_t stream);    // fp32-accurate, 2 x f16 split operands, row-scaled
+// scale[r] = the power of two that puts max_k |a[r][k] (* gate[r][k])| into [2^14, 2^15) (1 for an all-zero row)
+void launch_row_scale(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* scale,
+                      hipStream_t stream);
+// planes [2][rows][k] f16 (hi, lo of the row-scaled weight), inv[rows] = 1 / scale
+void launch_split_f16x2(const float* w, int rows, int k, uint16_t* planes, float* inv, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // normalisation / elementwise

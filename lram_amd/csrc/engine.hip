@@ -1891,6 +1891,35 @@ int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, in
   });
 }
 
+int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
+                        const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(ldw == k, "lram_gemm_f16x2: W must be contiguous [n, k]");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t numel = (size_t)n * k;
+    uint16_t* planes = nullptr;
+    float* scales = nullptr;  // [n] inverse weight scales, then [m] activation scales
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&planes), 2 * numel * sizeof(uint16_t)));
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scales), ((size_t)n + m) * sizeof(float)));
+    try {
+      launch_split_f16x2(dev_w, n, k, planes, scales, s);
+      launch_row_scale(dev_a, lda, nullptr, 0, m, k, scales + n, s);
+      GemmArgs g;
+      g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
+      g.residual = accumulate ? dev_c : nullptr;
+      g.m = m, g.n = n, g.k = k, g.w2 = planes, g.w2_plane = (int64_t)numel, g.w_inv = scales, g.a_scale = scales + n;
+      launch_gemm_f16x2(g, s);
+      LRAM_HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      (void)hipFree(planes);
+      (void)hipFree(scales);
+      throw;
+    }
+    (void)hipFree(planes);
+    (void)hipFree(scales);
+  });
+}
+
 int32_t lram_gemm_bf16x3_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
                                   const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
   return guarded([&] {

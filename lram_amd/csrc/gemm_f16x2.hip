@@ -1,0 +1,318 @@
+// fp32-accurate GEMM on the f16 matrix cores ("f16x2"):  C[M,N] = A[M,K] * W[N,K]^T (+ bias) (+ residual)
+//
+// Each fp32 operand row is scaled by a power of two so that its largest element lands in [2^14, 2^15) and every
+// scaled element is split exactly into two binary16 pieces  s x = hi + lo  (hi = rn16(s x), lo = rn16(s x - hi); the
+// residual s x - hi is exact in fp32).  hi carries 11 significand bits, lo the next 11: 22 of fp32's 24, with an
+// absolute error <= 2^-25 for elements so small that lo leaves the normal range -- 2^-39 of the row's largest element.
+// The product is accumulated in fp32 from the three largest piece products  hi*hi + hi*lo + lo*hi ; the dropped
+// lo*lo is <= 2^-22 relative, and random in sign.  Measured against fp64 the result is as close as the bf16x3 kernel's
+// and the exact fp32 fma chain's (tests/test_gpu_parity.py::test_gemm_f16x2_matches_fp64; the CPU emulation in
+// tests/test_oracle_selfchecks.py states the arithmetic), at HALF the matrix-core work of bf16x3 (3 products instead
+// of 6 at the same `v_mfma_f32_32x32x16_*` rate) and 2/3 of its LDS bytes (4 B per element instead of 6).
+//
+// Why that matters here (profiles/r03_gemm_*): the 128 x 128 x 32 bf16x3 kernel is not matrix-core bound.  Its loop
+// is [wait for the next tile's global loads] -> split + LDS write -> barrier -> issue loads -> 48 MFMAs -> barrier, the
+// loads have only the MFMA block (1.5-3 k cycles) to come back, and 61 KB of LDS + 240 VGPRs allow two workgroups per
+// CU: two waves per SIMD cannot cover an L2 / HBM round trip of that length, so the matrix pipe idles ~55 % of the
+// time (exact-fp32 MFMA kernel, 2.7 x the MFMA time per tile: 75 % busy).  This kernel's tile is 40 KB of LDS and
+// <= 168 VGPRs: THREE workgroups per CU, three waves per SIMD, while one waits for its tile two others compute.
+//
+// W is split once when the weights are finalised (two [N,K] f16 planes + the per-row inverse scale); A is split on
+// the fly while its fp32 tile is staged into LDS, with per-row scales computed by `launch_row_scale` (or handed over
+// by the kernel that produced A).  Scales are powers of two: un-scaling the accumulator is exact.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "device_math.h"
+
+namespace lram {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int BN = 128, BK = 32;
+constexpr int PITCH = 40;          // f16 elements per LDS row (80 B: conflict-free ds_read_b128)
+constexpr int PLANE = BN * PITCH;  // elements per 128-row plane
+
+// power-of-two scale that puts `mx` into [2^14, 2^15); 1 for an all-zero row
+__device__ __forceinline__ float pow2_scale(float mx) {
+  const unsigned bits = __float_as_uint(mx);
+  int e = (int)((bits >> 23) & 0xffu);  // biased exponent of the largest magnitude (0: zero / subnormal row)
+  if (mx == 0.f) return 1.f;
+  if (e == 0) e = 1;
+  int se = 268 - e;                     // biased exponent of 2^(14 - (e - 127))
+  se = se > 254 ? 254 : (se < 1 ? 1 : se);
+  return __uint_as_float((unsigned)se << 23);
+}
+
+// BM = 128: 64 x 64 per wave (2 x 2 MFMA tiles).  BM = 64: 32 x 64 per wave.  GATE: the fp32 A operand is multiplied
+// element-wise by g.gate while it is staged (mLSTM output gate); the row scales then are those of the gated rows.
+template <bool HAS_BIAS, bool HAS_RES, int BM, bool GATE>
+__global__ __launch_bounds__(256, 3) void gemm_f16x2_kernel(GemmArgs g) {
+  constexpr int WM = BM / 2;   // rows per wave
+  constexpr int TI = WM / 32;  // MFMA row tiles per wave
+  constexpr int APLANE = BM * PITCH;
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * APLANE + 2 * PLANE];
+  _Float16* As = lds;               // [2][BM][PITCH]   hi, lo
+  _Float16* Bs = lds + 2 * APLANE;  // [2][128][PITCH]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const float* A = g.a;
+  const _Float16* W2 = reinterpret_cast<const _Float16*>(g.w2);
+  float* C = g.c;
+
+  const int tiles_n = (g.n + BN - 1) / BN;
+  const int tiles_m = (g.m + BM - 1) / BM;
+  const int nwg = tiles_n * tiles_m;
+  int bid = blockIdx.x;
+  if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);  // XCD-aware tile order (see gemm_f32.hip)
+  const int tm_idx = bid / tiles_n;
+  const int tn_idx = bid - tm_idx * tiles_n;
+  const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+
+  const int lr = tid >> 3;        // A: row within a 32-row slab
+  const int lc = (tid & 7) << 2;  // A: k offset 0,4,..,28
+  constexpr int NA = BM / 32;     // float4 per thread and K tile
+  float4 ra[NA];
+  float4 rz[GATE ? NA : 1];
+  (void)rz;
+  uint4 rw[4];
+  float sa[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int gm = m0 + lr + 32 * i;
+    sa[i] = gm < g.m ? g.a_scale[gm] : 1.f;
+  }
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int gm = m0 + lr + 32 * i, kk = k0 + lc;
+      const bool ok = gm < g.m && kk < g.k;
+      ra[i] = ok ? *reinterpret_cast<const float4*>(A + (int64_t)gm * g.lda + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (GATE) rz[i] = ok ? *reinterpret_cast<const float4*>(g.gate + (int64_t)gm * g.ldg + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = tid + 256 * j;  // 16-byte chunk id: 2 planes x 128 rows x 4 chunks
+      const int plane = q >> 9, rem = q & 511;
+      const int r = rem >> 2, c = (rem & 3) << 3;
+      const int gn = n0 + r, kk = k0 + c;
+      rw[j] = (gn < g.n && kk < g.k)
+                  ? *reinterpret_cast<const uint4*>(W2 + (int64_t)plane * g.w2_plane + (int64_t)gn * g.ldw + kk)
+                  : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+      if (GATE) xs[0] *= rz[i].x, xs[1] *= rz[i].y, xs[2] *= rz[i].z, xs[3] *= rz[i].w;
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = xs[e] * sa[i];
+        const _Float16 h = (_Float16)v;
+        hi[e] = h;
+        lo[e] = (_Float16)(v - (float)h);
+      }
+      _Float16* dst = As + (lr + 32 * i) * PITCH + lc;
+      *reinterpret_cast<f16x4*>(dst) = hi;
+      *reinterpret_cast<f16x4*>(dst + APLANE) = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = tid + 256 * j;
+      const int plane = q >> 9, rem = q & 511;
+      const int r = rem >> 2, c = (rem & 3) << 3;
+      *reinterpret_cast<uint4*>(Bs + plane * PLANE + r * PITCH + c) = rw[j];
+    }
+  };
+
+  f32x16 acc[TI][2];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  // lane (row li, half lh) holds k = 8*lh + j (j = 0..7) of a 16-deep MFMA step for both operands
+  const _Float16* a_base = As + (WM * wm + li) * PITCH + 8 * lh;
+  const _Float16* b_base = Bs + (64 * wn + li) * PITCH + 8 * lh;
+
+  const int nk_all = (g.k + BK - 1) / BK;
+  const int kt0 = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
+  const int nk = g.split_k > 1 ? min(nk_all, kt0 + g.k_tiles_per_split) : nk_all;
+  load_tile(kt0 * BK);
+  for (int kt = kt0; kt < nk; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+    if (g.mfma_prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      f16x8 af[TI][2], bf[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          if (t < TI) af[t][p] = *reinterpret_cast<const f16x8*>(a_base + p * APLANE + 32 * t * PITCH + 16 * ks);
+          bf[t][p] = *reinterpret_cast<const f16x8*>(b_base + p * PLANE + 32 * t * PITCH + 16 * ks);
+        }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);  // lo * hi
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);  // hi * lo
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);  // hi * hi
+        }
+    }
+    if (g.mfma_prio) __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+  }
+
+  // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5));
+  // un-scale with the exact inverse powers of two of the row (A) and column (W) scales
+  float* S = g.split_k > 1 ? g.splitk_ws + (int64_t)blockIdx.z * g.m * g.n : nullptr;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + 64 * wn + 32 * j + li;
+      if (col >= g.n) continue;
+      const float wi = g.w_inv[col];
+      const float bv = HAS_BIAS ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + WM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < g.m) {
+          float v = acc[i][j][r] * (wi / g.a_scale[row]);
+          if (S != nullptr) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
+            S[(int64_t)row * g.n + col] = v;
+            continue;
+          }
+          v += bv;
+          if (HAS_RES) v += g.residual[(int64_t)row * g.ldc + col];
+          if (g.act_silu_from >= 0 && col >= g.act_silu_from) v = silu_f(v);
+          C[(int64_t)row * g.ldc + col] = v;
+        }
+      }
+    }
+}
+
+// One wave per row: scale[r] = power of two that puts max_k |a[r][k] (* gate[r][k])| into [2^14, 2^15).
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows,
+                                                        int k, float* scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* ar = a + (int64_t)row * lda;
+  const float* gr = gate != nullptr ? gate + (int64_t)row * ldg : nullptr;
+  float mx = 0.f;
+  for (int c = lane * 4; c < k; c += 256) {
+    float4 v = *reinterpret_cast<const float4*>(ar + c);
+    if (gr != nullptr) {
+      const float4 z = *reinterpret_cast<const float4*>(gr + c);
+      v.x *= z.x, v.y *= z.y, v.z *= z.z, v.w *= z.w;
+    }
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  if (lane == 0) scale[row] = pow2_scale(mx);
+}
+
+// One wave per weight row: planes[0][n][k] = hi, planes[1][n][k] = lo of scale * w[n][k]; inv[n] = 1 / scale.
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* w, int rows, int k, _Float16* planes, int64_t plane,
+                                                          float* inv) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* wr = w + (int64_t)row * k;
+  float mx = 0.f;
+  for (int c = lane; c < k; c += 64) mx = fmaxf(mx, fabsf(wr[c]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  const float s = pow2_scale(mx);
+  for (int c = lane; c < k; c += 64) {
+    const float v = wr[c] * s;
+    const _Float16 h = (_Float16)v;
+    planes[(int64_t)row * k + c] = h;
+    planes[plane + (int64_t)row * k + c] = (_Float16)(v - (float)h);
+  }
+  if (lane == 0) inv[row] = 1.f / s;
+}
+}  // namespace
+
+bool gemm_f16x2_supported(const GemmArgs& g) {
+  return g.w2 != nullptr && g.w_inv != nullptr && g.nb1 * g.nb2 == 1 && (g.k & 7) == 0 && (g.ldw & 7) == 0 &&
+         (g.lda & 3) == 0 && (g.w2_plane & 7) == 0 && g.a3 == nullptr && (g.gate == nullptr || (g.ldg & 3) == 0);
+}
+
+void launch_row_scale(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* scale,
+                      hipStream_t stream) {
+  LRAM_REQUIRE((k & 3) == 0 && (lda & 3) == 0 && (gate == nullptr || (ldg & 3) == 0), "row scale: K, lda must be multiples of 4");
+  hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a, lda, gate, ldg, rows, k, scale);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_split_f16x2(const float* w, int rows, int k, uint16_t* planes, float* inv, hipStream_t stream) {
+  hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w, rows, k,
+                     reinterpret_cast<_Float16*>(planes), (int64_t)rows * k, inv);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+template <int BM, bool GATE>
+static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+  const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
+  dim3 block(256);
+  if (hb && hr)
+    hipLaunchKernelGGL((gemm_f16x2_kernel<true, true, BM, GATE>), grid, block, 0, stream, g);
+  else if (hb)
+    hipLaunchKernelGGL((gemm_f16x2_kernel<true, false, BM, GATE>), grid, block, 0, stream, g);
+  else if (hr)
+    hipLaunchKernelGGL((gemm_f16x2_kernel<false, true, BM, GATE>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, BM, GATE>), grid, block, 0, stream, g);
+}
+
+// g.a_scale: per-row scales of A (of the gated rows when g.gate is set), from launch_row_scale or A's producer.
+void launch_gemm_f16x2(const GemmArgs& g_in, hipStream_t stream) {
+  GemmArgs g = g_in;
+  static const int prio = [] {
+    const char* v = std::getenv("LRAM_GEMM_PRIO");
+    return v ? std::atoi(v) : 1;
+  }();
+  g.mfma_prio = prio;
+  LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
+  LRAM_REQUIRE(gemm_f16x2_supported(g) && g.a_scale != nullptr, "gemm f16x2: unsupported operand layout");
+  int S = 1;
+  if (g.act_silu_from >= 0 || g.gate != nullptr)
+    g.split_k = 1, g.k_tiles_per_split = 0;  // output activation / gated operand: K unsplit
+  else
+    S = gemm_choose_split_k(g);
+  const int tiles_n = (g.n + BN - 1) / BN;
+  const int tiles128 = ((g.m + 127) / 128) * tiles_n;
+  // 64-row tiles where 128-row tiles leave workgroup slots empty (three workgroups per CU: 768 slots)
+  static const int force_bm = [] {
+    const char* v = std::getenv("LRAM_GEMM_BM");
+    return v ? std::atoi(v) : 0;
+  }();
+  const bool small = force_bm == 64 || (force_bm == 0 && S == 1 && tiles128 < 768 && tiles_n <= 6 && g.m > 64);
+  const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;
+  dim3 grid(tiles, 1, S);
+  if (g.gate != nullptr) {
+    if (small) launch_bm<64, true>(g, grid, stream); else launch_bm<128, true>(g, grid, stream);
+  } else {
+    if (small) launch_bm<64, false>(g, grid, stream); else launch_bm<128, false>(g, grid, stream);
+  }
+  LRAM_HIP_CHECK(hipGetLastError());
+  if (S > 1) launch_splitk_reduce(g, stream);
+}
+
+}  // namespace lram

@@ -9,7 +9,7 @@ order = json.loads(open(sys.argv[1] + "/order.json").readline())
 rows = collections.defaultdict(dict)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemm_bf16x3_kernel" in r["Kernel_Name"] or "gemm_f32_kernel" in r["Kernel_Name"]:
+        if "gemm_bf16x3_kernel" in r["Kernel_Name"] or "gemm_f32_kernel" in r["Kernel_Name"] or "gemm_f16x2_kernel" in r["Kernel_Name"]:
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(rows)
 i = 0

@@ -66,6 +66,43 @@ def test_gemm_bf16x3_matches_fp64(hip_lib, m, n, k):
     assert ((out2.cpu().double() - ref2).abs() / (scale + 1)).max().item() < 1.5 * e1 + 1e-7
 
 
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (96, 2192, 512), (300, 80, 1536), (1000, 1408, 512),
+                                   (4096, 512, 1024), (6144, 3072, 768), (65, 8, 8), (257, 129, 48)])
+@pytest.mark.parametrize("spread", ["rows", "elements", "tiny"])
+def test_gemm_f16x2_matches_fp64(hip_lib, m, n, k, spread):
+    """The f16x2 projection kernel (operand rows scaled by a power of two, split into two binary16 pieces, 3 MFMA
+    products, exact un-scaling) is fp32-accurate: its error against fp64 stays within 1.5 x the exact fp32-MFMA kernel's
+    on the same data -- for rows of varied scale, for elements spread over many binades inside a row (where the low
+    piece of small elements leaves binary16's normal range), and for rows far below binary16's range."""
+    from lram_amd.engine import gemm_f32
+    g = torch.Generator().manual_seed(m * 13 + n)
+    a = torch.randn(m, k, generator=g) * torch.exp(torch.randn(m, 1, generator=g))
+    w = torch.randn(n, k, generator=g) * torch.exp(torch.randn(n, 1, generator=g) * 0.5)
+    if spread == "elements":
+        a = a * torch.exp(torch.randn(m, k, generator=g) * 3.0)
+        w = w * torch.exp(torch.randn(n, k, generator=g) * 2.0)
+    if spread == "tiny":
+        a, w = a * 1e-9, w * 1e-7
+        a[0] = 0.0                                                                    # an all-zero row
+    bias = torch.randn(n, generator=g) * (1e-16 if spread == "tiny" else 1.0)
+    ref = a.double() @ w.double().t() + bias.double()
+    scale = (a.double().abs() @ w.double().abs().t()) + 1e-300
+    out2 = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="f16x2")
+    out1 = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="f32")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out2).all()
+    e2 = ((out2.cpu().double() - ref).abs() / scale)[1:].max().item()
+    e1 = ((out1.cpu().double() - ref).abs() / scale)[1:].max().item()
+    assert e2 < 1.5 * e1 + 1e-7, (m, n, k, spread, e2, e1)
+    if spread == "tiny":
+        assert torch.equal(out2[0].cpu(), bias)                                        # zero row: bias only, exactly
+    base = torch.randn(m, n, generator=g)
+    out3 = gemm_f32(a.cuda(), w.cuda(), None, out=base.clone().cuda(), accumulate=True, kernel="f16x2")
+    torch.cuda.synchronize()
+    ref3 = base.double() + a.double() @ w.double().t()
+    assert ((out3.cpu().double() - ref3).abs() / (scale + 1)).max().item() < 1.5 * e1 + 1e-7
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 80, 1536), (4096, 512, 1024), (257, 129, 48)])
 def test_gemm_bf16x3_presplit_operand_is_bit_identical(hip_lib, m, n, k):
     """The projection kernel fed with pre-split A planes (what the norm / gate / state-update kernels write) gives
