@@ -93,6 +93,17 @@ struct lram_engine {
   };
   std::map<const float*, Split> split;
   bool use_bf16x3 = true;  // LRAM_GEMM=f32 selects the exact fp32-MFMA kernel everywhere
+  // f16x2 projection kernel (gemm_f16x2.hip): un-batched weights also get two row-scaled f16 planes + inverse scales;
+  // LRAM_GEMM=bf16x3 keeps the three-plane bf16 kernel for them too
+  bool use_f16x2 = true;
+  struct Split16 {
+    uint16_t* planes;  // [2][rows][k] f16
+    float* inv;        // [rows] exact inverse of each weight row's power-of-two scale
+    size_t rows, k;
+  };
+  std::map<const float*, Split16> split16;
+  DevBuf ASCALE;  // per-row scales of a GEMM's A operand, one region per stream slot (like the split-K slabs)
+  size_t ascale_rows = 0;
   // front end / head
   const float *w_state = nullptr, *b_state = nullptr, *w_rtg = nullptr, *b_rtg = nullptr, *w_rew = nullptr,
               *b_rew = nullptr, *eln_g = nullptr, *eln_b = nullptr, *w_head = nullptr, *b_head = nullptr,
@@ -113,7 +124,9 @@ struct lram_engine {
   bool lazy_ready = false;  // buffers allocated for the current batch
   int lazy_period = 13;
   bool lean_front = true;   // LRAM_LEAN_FRONT=0
-  bool gn_fuse = false;     // LRAM_GN_FUSE=1: output group norm + skip in the read pass's epilogue, gate in proj_down's
+  int gn_fuse = 2;          // LRAM_GN_FUSE: output group norm + skip in the read pass's epilogue, gate in proj_down's
+                            // operand staging.  0 off, 1 on, 2 auto = on from 2048 env slots (round 3, same box, two
+                            // rounds: 391.1k / 393.5k off vs 395.8k / 397.5k on at 4096 slots; 1024 slots: -0.4 %)
                             // operand staging (measured: +0.7 % at 4096 env slots, -0.3 % at 1024: opt-in)
   bool split_up = true;     // LRAM_SPLIT_UP=0: proj_up as one GEMM ahead of the front end
   int fold_gaps = 0;        // LRAM_FOLD_GAPS=g: the last g mLSTM blocks' folds run just ahead of their own read passes
@@ -201,6 +214,8 @@ struct lram_engine {
   void drop_splits() {
     for (auto& kv : split) (void)hipFree(kv.second.p);
     split.clear();
+    for (auto& kv : split16) (void)hipFree(kv.second.planes), (void)hipFree(kv.second.inv);
+    split16.clear();
   }
   void drop_graph() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -399,7 +414,36 @@ void finalize(lram_engine* e) {
   }
   // bf16 split planes of every GEMM weight (LRAM_GEMM=f32 keeps the exact fp32-MFMA kernels instead)
   e->drop_splits();
-  if (const char* v = std::getenv("LRAM_GEMM")) e->use_bf16x3 = std::string(v) != "f32";
+  if (const char* v = std::getenv("LRAM_GEMM")) {
+    e->use_bf16x3 = std::string(v) != "f32";
+    e->use_f16x2 = std::string(v) != "f32" && std::string(v) != "bf16x3";
+  }
+  if (e->use_bf16x3 && e->use_f16x2) {
+    // the big un-batched projections: (weight, rows, K); the per-head / per-gate batched GEMMs of the sLSTM block keep
+    // bf16x3 (their operand rows would need one scale per head)
+    const int D = c.d_model;
+    auto rows_of = [&](const float* p, size_t k) -> size_t {
+      for (auto& kv : e->weights)
+        if (kv.second.p == p) return kv.second.n / k;
+      return 0;
+    };
+    auto add16 = [&](const float* p, size_t k) {
+      if (p == nullptr || k == 0 || (k & 7) != 0 || e->split16.count(p)) return;
+      const size_t rows = rows_of(p, k);
+      if (rows == 0) return;
+      lram_engine::Split16 sp{nullptr, nullptr, rows, k};
+      LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp.planes), 2 * rows * k * sizeof(uint16_t)));
+      LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp.inv), rows * sizeof(float)));
+      launch_split_f16x2(p, (int)rows, (int)k, sp.planes, sp.inv, nullptr);
+      e->split16[p] = sp;
+    };
+    add16(e->w_head, D);
+    if (e->img_lin_w != nullptr) add16(e->img_lin_w, (size_t)e->img_flat);
+    for (const BlockWeights& w : e->bw) {
+      add16(w.proj_up, D), add16(w.proj_down, c.inner), add16(w.ffn_up, D), add16(w.ffn_down, c.ffn_dim);
+      add16(w.in_proj, D), add16(w.x_proj, c.d_inner), add16(w.dt_proj, c.dt_rank), add16(w.out_proj, c.d_inner);
+    }
+  }
   if (e->use_bf16x3) {
     auto numel = [&](const float* p) -> size_t {
       for (auto& kv : e->weights)
@@ -432,6 +476,8 @@ void alloc_workspace(lram_engine* e, int tokens) {
   const lram_config& c = e->cfg;
   const size_t B = e->B, D = c.d_model, BT = B * (size_t)tokens;
   e->SK.alloc(lram_engine::kSplitKSlotElems * lram_engine::kSplitKSlots);
+  e->ascale_rows = BT;
+  e->ASCALE.alloc(BT * lram_engine::kSplitKSlots);
   e->X.alloc(BT * D);
   e->XN.alloc(BT * D);
   e->TOK.alloc(BT * D);
@@ -651,6 +697,29 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
     g.splitk_ws = e->SK.p + (size_t)slot * lram_engine::kSplitKSlotElems;
     g.splitk_ws_elems = (int64_t)lram_engine::kSplitKSlotElems;
   }
+  if (e->use_f16x2 && !gemm_small_m(g) && g.nb1 * g.nb2 == 1 && g.a3 == nullptr && e->ASCALE.p != nullptr &&
+      (size_t)g.m <= e->ascale_rows) {
+    auto it = e->split16.upper_bound(g.w);
+    if (it != e->split16.begin() && (--it, g.w < it->first + it->second.rows * it->second.k) && (int)it->second.k == g.ldw) {
+      const size_t row0 = (size_t)(g.w - it->first) / it->second.k;  // a GEMM may address a row range of a weight
+      g.w2 = it->second.planes + (g.w - it->first);
+      g.w2_plane = (int64_t)(it->second.rows * it->second.k);
+      g.w_inv = it->second.inv + row0;
+      if (gemm_f16x2_supported(g)) {
+        if (g.a_scale == nullptr) {  // no producer handed the row scales over: one small launch ahead of the GEMM
+          int slot = 0;
+          for (size_t i = 0; i < e->micro_streams.size() && i + 1 < (size_t)lram_engine::kSplitKSlots; ++i)
+            if (e->micro_streams[i] == s) slot = (int)i + 1;
+          float* sc = e->ASCALE.p + (size_t)slot * e->ascale_rows;
+          launch_row_scale(g.a, g.lda, g.gate, g.ldg, g.m, g.k, sc, s);
+          g.a_scale = sc;
+        }
+        launch_gemm_f16x2(g, s);
+        return;
+      }
+      g.w2 = nullptr, g.w_inv = nullptr;
+    }
+  }
   if (e->use_bf16x3 && !gemm_small_m(g)) {
     // planes of the weight tensor that contains g.w (a GEMM may address a row range of a weight: proj_up's halves)
     auto it = e->split.upper_bound(g.w);
@@ -792,7 +861,7 @@ bool split_up_now(const lram_engine* e) { return e->split_up && e->B >= 2048 && 
 // group-norm launch on the slice's chain, no [rows, inner] round trip for h.
 bool gn_fused(const lram_engine* e, int T) {
   const int dh = e->cfg.inner / e->cfg.n_heads;
-  return e->gn_fuse && lean_front(e, T) && e->use_bf16x3 && !e->use_a3 && (dh == 256 || dh == 128) && T <= 4 &&
+  return (e->gn_fuse == 1 || (e->gn_fuse == 2 && e->B >= 2048)) && lean_front(e, T) && e->use_bf16x3 && !e->use_a3 && (dh == 256 || dh == 128) && T <= 4 &&
          e->cfg.inner % 8 == 0 && e->cfg.d_model % 8 == 0 && e->B >= 64;  // (fewer rows take the GEMV path)
 }
 
@@ -1477,7 +1546,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     }
     if (const char* v = std::getenv("LRAM_PERSISTENT")) e->persist_mode = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_PERSIST_WGS")) e->persist_wgs = std::max(8, std::min(256, std::atoi(v)));
-    if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_LEAN_FRONT")) e->lean_front = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_A3")) e->use_a3 = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SPLIT_UP")) e->split_up = std::atoi(v) != 0;

@@ -50,8 +50,11 @@ __device__ __forceinline__ float pow2_scale(float mx) {
 
 // BM = 128: 64 x 64 per wave (2 x 2 MFMA tiles).  BM = 64: 32 x 64 per wave.  GATE: the fp32 A operand is multiplied
 // element-wise by g.gate while it is staged (mLSTM output gate); the row scales then are those of the gated rows.
-template <bool HAS_BIAS, bool HAS_RES, int BM, bool GATE>
-__global__ __launch_bounds__(256, 3) void gemm_f16x2_kernel(GemmArgs g) {
+// ABL (measurement only, results are wrong for ABL != 0): 1 no fp32 -> f16 conversion arithmetic, 2 no global loads in
+// the K loop, 3 no MFMA, 4 no LDS fragment reads in the loop, 5 no LDS writes, 6 no barriers -- the guide's "ablate before
+// optimising" (cdna_hip_programming.md section 7); LRAM_F16_ABL selects one for scripts/bench_gemm.py.
+template <bool HAS_BIAS, bool HAS_RES, int BM, bool GATE, int PF, int ABL = 0>
+__global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmArgs g) {
   constexpr int WM = BM / 2;   // rows per wave
   constexpr int TI = WM / 32;  // MFMA row tiles per wave
   constexpr int APLANE = BM * PITCH;
@@ -77,58 +80,98 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x2_kernel(GemmArgs g) {
   const int lr = tid >> 3;        // A: row within a 32-row slab
   const int lc = (tid & 7) << 2;  // A: k offset 0,4,..,28
   constexpr int NA = BM / 32;     // float4 per thread and K tile
-  float4 ra[NA];
-  float4 rz[GATE ? NA : 1];
+  // PF register sets: tile kt + PF is requested while tile kt is computed, so PF tiles of global loads are in flight
+  // per workgroup at any time (PF = 2 keeps the memory pipe fed across the split / LDS-write / barrier stretch)
+  float4 ra[PF][NA];
+  float4 rz[PF][GATE ? NA : 1];
   (void)rz;
-  uint4 rw[4];
+  uint4 rw[PF][4];
   float sa[NA];
+  const float* arow[NA];
+  const float* grow[GATE ? NA : 1];
+  (void)grow;
+  bool aok[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int gm = m0 + lr + 32 * i;
-    sa[i] = gm < g.m ? g.a_scale[gm] : 1.f;
+    aok[i] = gm < g.m;
+    const int gmc = aok[i] ? gm : g.m - 1;  // clamped: loads are unconditional (no branch around them), masked after
+    sa[i] = g.a_scale[gmc];
+    arow[i] = A + (int64_t)gmc * g.lda + lc;
+    if (GATE) grow[i] = g.gate + (int64_t)gmc * g.ldg + lc;
   }
-  auto load_tile = [&](int k0) {
+  const _Float16* wrow[4];
+  bool wok[4];
+  int wkc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = tid + 256 * j;  // 16-byte chunk id: 2 planes x 128 rows x 4 chunks
+    const int plane = q >> 9, rem = q & 511;
+    const int r = rem >> 2;
+    wkc[j] = (rem & 3) << 3;
+    const int gn = n0 + r;
+    wok[j] = gn < g.n;
+    wrow[j] = W2 + (int64_t)plane * g.w2_plane + (int64_t)(wok[j] ? gn : g.n - 1) * g.ldw + wkc[j];
+  }
+  // Loads are unconditional (clamped addresses, never a branch around a load: hipcc would otherwise wait for ALL
+  // outstanding loads at the next use and the second register set would buy nothing); what lies outside the problem is
+  // zeroed arithmetically -- rows beyond M carry scale 0, a K tail (K is a multiple of 8, not of 32) zeroes its columns
+  // through the scale of the tile / an AND mask on the weight chunks.
+  const bool k_tail = (g.k & (BK - 1)) != 0;
+  const int kt0_ = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+    if (!aok[i]) sa[i] = 0.f;
+  auto load_tile = [&](int set, int k0) {
+    if (ABL == 2 && k0 != kt0_ * BK) return;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int gm = m0 + lr + 32 * i, kk = k0 + lc;
-      const bool ok = gm < g.m && kk < g.k;
-      ra[i] = ok ? *reinterpret_cast<const float4*>(A + (int64_t)gm * g.lda + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (GATE) rz[i] = ok ? *reinterpret_cast<const float4*>(g.gate + (int64_t)gm * g.ldg + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ko = (!k_tail || k0 + lc < g.k) ? k0 : 0;
+      ra[set][i] = *reinterpret_cast<const float4*>(arow[i] + ko);
+      if (GATE) rz[set][i] = *reinterpret_cast<const float4*>(grow[i] + ko);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int q = tid + 256 * j;  // 16-byte chunk id: 2 planes x 128 rows x 4 chunks
-      const int plane = q >> 9, rem = q & 511;
-      const int r = rem >> 2, c = (rem & 3) << 3;
-      const int gn = n0 + r, kk = k0 + c;
-      rw[j] = (gn < g.n && kk < g.k)
-                  ? *reinterpret_cast<const uint4*>(W2 + (int64_t)plane * g.w2_plane + (int64_t)gn * g.ldw + kk)
-                  : make_uint4(0u, 0u, 0u, 0u);
+      const bool kin = !k_tail || k0 + wkc[j] < g.k;
+      rw[set][j] = *reinterpret_cast<const uint4*>(wrow[j] + (kin ? k0 : 0));
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int set, int k0) {
+    const float kmask = (!k_tail || k0 + lc < g.k) ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-      if (GATE) xs[0] *= rz[i].x, xs[1] *= rz[i].y, xs[2] *= rz[i].z, xs[3] *= rz[i].w;
+      float xs[4] = {ra[set][i].x, ra[set][i].y, ra[set][i].z, ra[set][i].w};
+      if (GATE) xs[0] *= rz[set][i].x, xs[1] *= rz[set][i].y, xs[2] *= rz[set][i].z, xs[3] *= rz[set][i].w;
+      const float se = sa[i] * kmask;
       f16x4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v = xs[e] * sa[i];
+        const float v = xs[e] * se;
         const _Float16 h = (_Float16)v;
         hi[e] = h;
         lo[e] = (_Float16)(v - (float)h);
       }
+      if (ABL == 1) {  // raw bits instead of the conversion
+        hi = *reinterpret_cast<const f16x4*>(&ra[set][i].x);
+        lo = *reinterpret_cast<const f16x4*>(&ra[set][i].z);
+      }
       _Float16* dst = As + (lr + 32 * i) * PITCH + lc;
-      *reinterpret_cast<f16x4*>(dst) = hi;
-      *reinterpret_cast<f16x4*>(dst + APLANE) = lo;
+      if (ABL != 5) {
+        *reinterpret_cast<f16x4*>(dst) = hi;
+        *reinterpret_cast<f16x4*>(dst + APLANE) = lo;
+      } else if (hi[0] == (_Float16)12345.f) {
+        *reinterpret_cast<f16x4*>(dst) = lo;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int q = tid + 256 * j;
       const int plane = q >> 9, rem = q & 511;
       const int r = rem >> 2, c = (rem & 3) << 3;
-      *reinterpret_cast<uint4*>(Bs + plane * PLANE + r * PITCH + c) = rw[j];
+      const unsigned msk = (wok[j] && (!k_tail || k0 + wkc[j] < g.k)) ? 0xffffffffu : 0u;
+      uint4 v = rw[set][j];
+      v.x &= msk, v.y &= msk, v.z &= msk, v.w &= msk;
+      if (ABL != 5 || v.x == 0x12345u) *reinterpret_cast<uint4*>(Bs + plane * PLANE + r * PITCH + c) = v;
     }
   };
 
@@ -148,11 +191,19 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x2_kernel(GemmArgs g) {
   const int nk_all = (g.k + BK - 1) / BK;
   const int kt0 = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
   const int nk = g.split_k > 1 ? min(nk_all, kt0 + g.k_tiles_per_split) : nk_all;
-  load_tile(kt0 * BK);
-  for (int kt = kt0; kt < nk; ++kt) {
-    store_tile();
-    __syncthreads();
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);
+  f16x8 af0[2][TI][2], bf0[2][2][2];  // ABL == 4: fragments read once
+  if (ABL == 4) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          if (t < TI) af0[ks][t][p] = *reinterpret_cast<const f16x8*>(a_base + p * APLANE + 32 * t * PITCH + 16 * ks);
+          bf0[ks][t][p] = *reinterpret_cast<const f16x8*>(b_base + p * PLANE + 32 * t * PITCH + 16 * ks);
+        }
+  }
+  auto mfma_tile = [&]() {
     if (g.mfma_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
@@ -161,9 +212,21 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x2_kernel(GemmArgs g) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
+          if (ABL == 4) {
+            if (t < TI) af[t][p] = af0[ks][t][p];
+            bf[t][p] = bf0[ks][t][p];
+            continue;
+          }
           if (t < TI) af[t][p] = *reinterpret_cast<const f16x8*>(a_base + p * APLANE + 32 * t * PITCH + 16 * ks);
           bf[t][p] = *reinterpret_cast<const f16x8*>(b_base + p * PLANE + 32 * t * PITCH + 16 * ks);
         }
+      if (ABL == 3) {  // keep the fragment reads alive without the matrix pipe
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j][0] += (float)af[i][0][0] + (float)af[i][1][1] + (float)bf[j][0][2] + (float)bf[j][1][3];
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -175,8 +238,28 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x2_kernel(GemmArgs g) {
         }
     }
     if (g.mfma_prio) __builtin_amdgcn_s_setprio(0);
-    __syncthreads();
+  };
+  // The prefetch of a half is unconditional (past the last tile it re-reads the last one; nothing consumes it) and the
+  // loop body always runs all PF halves: hipcc's wait counts are then exact -- a load behind a condition makes it
+  // assume the shorter queue on every path and wait for the NEWEST register set where the oldest is needed.
+  auto half = [&](int u, int kt) {
+    // (scheduling fence: hipcc otherwise hoists the NEXT register set's conversion above this half's barriers and
+    // with it the wait for that set's loads -- every load would again have to land before the first barrier)
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(u, kt * BK);
+    if (ABL != 6) __syncthreads();
+    load_tile(u, min(kt + PF, nk - 1) * BK);
+    mfma_tile();
+    if (ABL != 6) __syncthreads();
+  };
+  load_tile(0, kt0 * BK);
+  if (PF > 1) load_tile(PF - 1, min(kt0 + 1, nk - 1) * BK);
+  int kt = kt0;
+  for (; kt + PF <= nk; kt += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) half(u, kt + u);
   }
+  if (PF > 1 && kt < nk) half(0, kt);  // odd tile count: one half left
 
   // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5));
   // un-scale with the exact inverse powers of two of the row (A) and column (W) scales
@@ -267,18 +350,47 @@ void launch_split_f16x2(const float* w, int rows, int k, uint16_t* planes, float
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
-template <int BM, bool GATE>
-static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+template <int BM, bool GATE, int PF>
+static void launch_bm_pf(const GemmArgs& g, dim3 grid, hipStream_t stream) {
   const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
   dim3 block(256);
   if (hb && hr)
-    hipLaunchKernelGGL((gemm_f16x2_kernel<true, true, BM, GATE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<true, true, BM, GATE, PF>), grid, block, 0, stream, g);
   else if (hb)
-    hipLaunchKernelGGL((gemm_f16x2_kernel<true, false, BM, GATE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<true, false, BM, GATE, PF>), grid, block, 0, stream, g);
   else if (hr)
-    hipLaunchKernelGGL((gemm_f16x2_kernel<false, true, BM, GATE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<false, true, BM, GATE, PF>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, BM, GATE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, BM, GATE, PF>), grid, block, 0, stream, g);
+}
+
+template <int BM, bool GATE>
+static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+  // LRAM_F16_PF (measurement knob): K tiles of global loads in flight per workgroup (1: three workgroups per CU; 2: two)
+  static const int pf = [] {
+    const char* v = std::getenv("LRAM_F16_PF");
+    return v ? std::atoi(v) : 1;
+  }();
+  static const int abl = [] {
+    const char* v = std::getenv("LRAM_F16_ABL");
+    return v ? std::atoi(v) : 0;
+  }();
+  if (abl != 0 && BM == 128 && !GATE) {
+    dim3 block(256);
+    switch (abl) {
+      case 1: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 1>), grid, block, 0, stream, g); return;
+      case 2: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 2>), grid, block, 0, stream, g); return;
+      case 3: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 3>), grid, block, 0, stream, g); return;
+      case 4: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 4>), grid, block, 0, stream, g); return;
+      case 5: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 5>), grid, block, 0, stream, g); return;
+      case 6: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 6>), grid, block, 0, stream, g); return;
+      default: break;
+    }
+  }
+  if (pf == 2)
+    launch_bm_pf<BM, GATE, 2>(g, grid, stream);
+  else
+    launch_bm_pf<BM, GATE, 1>(g, grid, stream);
 }
 
 // g.a_scale: per-row scales of A (of the gated rows when g.gate is set), from launch_row_scale or A's producer.

@@ -1,6 +1,7 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT; cd $R
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "gemm" > $OUT/pytest_gemm.log 2>&1; echo "pytest rc=$?"; tail -15 $OUT/pytest_gemm.log
-bash scripts/gpu_gemm.sh f16x2 bf16x3 > $OUT/gemm_us.txt 2>&1; cat $OUT/gemm_us.txt
-bash scripts/pmc_gemm.sh f16x2 > $OUT/pmc_gemm.txt 2>&1; cat $OUT/pmc_gemm.txt
+for abl in 0 1 2 3 4 5 6; do
+export LRAM_F16_ABL=$abl LRAM_GEMM_BM=128
+bash scripts/gpu_gemm.sh f16x2 > $OUT/gemm_abl$abl.txt 2>&1; echo "ABL=$abl"; grep -E "16m_up |mamba_in|mamba_out|16m_down" $OUT/gemm_abl$abl.txt
+done
