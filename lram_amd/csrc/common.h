@@ -68,11 +68,13 @@ struct GemmArgs {
   // optional (bf16x3 kernel, no split-K): output columns >= act_silu_from are stored as silu(value); -1 = none
   int act_silu_from = -1;
   // optional (f16x2 kernel): W pre-split into two f16 planes (hi, lo) of the row-scaled weight, `w2_plane` elements apart,
-  // with the exact inverse of each weight row's power-of-two scale; per-row scales of A (of the gated rows with `gate`)
+  // with the exact inverse of each weight row's power-of-two scale; a_amax[r] = largest magnitude of A's row r (of the
+  // gated row with `gate`), or an upper bound of it, from which the kernel derives the row's power-of-two scale
   const uint16_t* w2 = nullptr;
   int64_t w2_plane = 0;
   const float* w_inv = nullptr;
-  const float* a_scale = nullptr;
+  const float* a_amax = nullptr;
+  int amax_parts = 1;  // row r's maximum = max of a_amax[r * amax_parts + 0 .. amax_parts - 1]
   // optional split-K workspace (un-batched GEMMs with few output tiles: skinny N or small M): partial [S][M][N]
   // slabs are written by S x tiles workgroups and summed, in fixed order, by a second tiny kernel (deterministic)
   float* splitk_ws = nullptr;
@@ -90,9 +92,9 @@ void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t stream);   // fp32-accura
 void launch_split_bf16x3(const float* w, uint16_t* out, size_t n, hipStream_t stream);
 bool gemm_f16x2_supported(const GemmArgs& g);
 void launch_gemm_f16x2(const GemmArgs& g, hipStream_t stream);    // fp32-accurate, 2 x f16 split operands, row-scaled
-// scale[r] = the power of two that puts max_k |a[r][k] (* gate[r][k])| into [2^14, 2^15) (1 for an all-zero row)
-void launch_row_scale(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* scale,
-                      hipStream_t stream);
+// amax[r] = max_k |a[r][k] (* gate[r][k])|
+void launch_row_amax(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* amax,
+                     hipStream_t stream);
 // planes [2][rows][k] f16 (hi, lo of the row-scaled weight), inv[rows] = 1 / scale
 void launch_split_f16x2(const float* w, int rows, int k, uint16_t* planes, float* inv, hipStream_t stream);
 
@@ -101,14 +103,16 @@ void launch_split_f16x2(const float* w, int rows, int k, uint16_t* planes, float
 // ---------------------------------------------------------------------------------------------
 // out[r, :] = norm(in[r, :]) * gamma (+ beta);  rms != 0 -> RMSNorm (no mean subtraction).
 // (out2: optional second copy of the result, same row stride as out)
+// (amax: optional [rows] largest output magnitude per row, the f16x2 GEMM's a_amax)
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2 = nullptr,
-                     uint16_t* planes = nullptr, int64_t plane_stride = 0);  // planes: bf16x3 GEMM operand (row stride
-                                                                             // out_stride); out may then be null
+                     uint16_t* planes = nullptr, int64_t plane_stride = 0,   // planes: bf16x3 GEMM operand (row stride
+                     float* amax = nullptr);                                 // out_stride); out may then be null
 // Mamba block entry: res_out = hidden (+ res_in);  normed = RMSNorm(res_out) * gamma.
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
                          const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes = nullptr,
-                         int64_t plane_stride = 0);  // planes: `normed` as a bf16x3 GEMM operand (normed may be null)
+                         int64_t plane_stride = 0,  // planes: `normed` as a bf16x3 GEMM operand (normed may be null)
+                         float* amax = nullptr);    // [rows] largest |normed| per row (f16x2 GEMM's a_amax)
 
 // ---------------------------------------------------------------------------------------------
 // front end / head
@@ -321,6 +325,7 @@ struct MambaConvArgs {
   float* xc;            // [B*T, d_inner] out silu(conv)
   const uint8_t* reset;
   int B, T, d_inner, K;
+  float* amax = nullptr;  // optional [B*T][d_inner / 64]: per-wave partial row maxima of xc (f16x2 GEMM's a_amax)
 };
 void launch_mamba_conv(const MambaConvArgs& a, hipStream_t stream);
 
@@ -338,6 +343,7 @@ struct MambaSsmArgs {
   int B, T, d_inner, N, R;
   uint16_t* y3 = nullptr;   // y as a bf16x3 GEMM operand: three planes [B*T, d_inner], y3_plane elements apart
   int64_t y3_plane = 0;
+  float* amax = nullptr;    // optional [B*T][d_inner / 64]: per-64-channel partial row maxima of y (f16x2 GEMM's a_amax)
 };
 void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream);
 

@@ -55,4 +55,20 @@ __device__ __forceinline__ void split3_store4(const float4& v, uint16_t* p, int6
   *reinterpret_cast<uint2*>(p + 2 * plane) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
 }
 
+// ---- row maxima for the f16x2 GEMM (gemm_f16x2.hip) ----
+// power-of-two scale that puts a row whose largest magnitude is `mx` into [2^14, 2^15); 1 for an all-zero row
+__device__ __forceinline__ float pow2_scale(float mx) {
+  if (!(mx > 0.f)) return 1.f;
+  int e = (int)((__float_as_uint(mx) >> 23) & 0xffu);  // biased exponent (0: subnormal)
+  if (e == 0) e = 1;
+  int se = 268 - e;                                    // biased exponent of 2^(14 - (e - 127))
+  se = se > 254 ? 254 : (se < 1 ? 1 : se);
+  return __uint_as_float((unsigned)se << 23);
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 }  // namespace lram

@@ -102,8 +102,11 @@ struct lram_engine {
     size_t rows, k;
   };
   std::map<const float*, Split16> split16;
-  DevBuf ASCALE;  // per-row scales of a GEMM's A operand, one region per stream slot (like the split-K slabs)
-  size_t ascale_rows = 0;
+  DevBuf ASCALE;  // per-row maxima of a GEMM's A operand computed by launch_row_amax, one region per stream slot (like
+  size_t ascale_rows = 0;  // the split-K slabs)
+  // row maxima handed over by the kernels that produce the projections' operands, indexed like the rows of X:
+  // XN (norm -> proj_up / ffn_up / in_proj), XA (Mamba conv -> x_proj), H (selective state update -> out_proj)
+  DevBuf AMX_XN, AMX_XA, AMX_H;
   // front end / head
   const float *w_state = nullptr, *b_state = nullptr, *w_rtg = nullptr, *b_rtg = nullptr, *w_rew = nullptr,
               *b_rew = nullptr, *eln_g = nullptr, *eln_b = nullptr, *w_head = nullptr, *b_head = nullptr,
@@ -441,7 +444,8 @@ void finalize(lram_engine* e) {
     if (e->img_lin_w != nullptr) add16(e->img_lin_w, (size_t)e->img_flat);
     for (const BlockWeights& w : e->bw) {
       add16(w.proj_up, D), add16(w.proj_down, c.inner), add16(w.ffn_up, D), add16(w.ffn_down, c.ffn_dim);
-      add16(w.in_proj, D), add16(w.x_proj, c.d_inner), add16(w.dt_proj, c.dt_rank), add16(w.out_proj, c.d_inner);
+      add16(w.in_proj, D), add16(w.x_proj, c.d_inner), add16(w.out_proj, c.d_inner);
+      // (dt_proj, K = dt_rank = 48: two K tiles, nothing to gain -- 24.8 us vs 20.8 us for bf16x3 at 6144 rows)
     }
   }
   if (e->use_bf16x3) {
@@ -478,6 +482,9 @@ void alloc_workspace(lram_engine* e, int tokens) {
   e->SK.alloc(lram_engine::kSplitKSlotElems * lram_engine::kSplitKSlots);
   e->ascale_rows = BT;
   e->ASCALE.alloc(BT * lram_engine::kSplitKSlots);
+  const size_t parts = c.backbone == LRAM_BACKBONE_MAMBA ? std::max<size_t>(1, c.d_inner / 64) : 0;
+  e->AMX_XN.alloc(BT);
+  if (parts) e->AMX_XA.alloc(BT * parts), e->AMX_H.alloc(BT * parts);
   e->X.alloc(BT * D);
   e->XN.alloc(BT * D);
   e->TOK.alloc(BT * D);
@@ -706,13 +713,13 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
       g.w2_plane = (int64_t)(it->second.rows * it->second.k);
       g.w_inv = it->second.inv + row0;
       if (gemm_f16x2_supported(g)) {
-        if (g.a_scale == nullptr) {  // no producer handed the row scales over: one small launch ahead of the GEMM
+        if (g.a_amax == nullptr) {  // no producer handed the row maxima over: one small launch ahead of the GEMM
           int slot = 0;
           for (size_t i = 0; i < e->micro_streams.size() && i + 1 < (size_t)lram_engine::kSplitKSlots; ++i)
             if (e->micro_streams[i] == s) slot = (int)i + 1;
           float* sc = e->ASCALE.p + (size_t)slot * e->ascale_rows;
-          launch_row_scale(g.a, g.lda, g.gate, g.ldg, g.m, g.k, sc, s);
-          g.a_scale = sc;
+          launch_row_amax(g.a, g.lda, g.gate, g.ldg, g.m, g.k, sc, s);
+          g.a_amax = sc, g.amax_parts = 1;
         }
         launch_gemm_f16x2(g, s);
         return;
@@ -872,13 +879,15 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   const BlockWeights& w = e->bw[i];
   BlockState& st = e->st[i];
   const bool a3 = a3_for(e, w.proj_up, rows, D, D);  // the norm then writes the GEMM's operand planes, no fp32 copy
+  float* amx = e->use_f16x2 ? e->AMX_XN.p + r0 : nullptr;  // the norm hands proj_up's operand row maxima over
   launch_row_norm(e->X.p + r0 * D, D, a3 ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
-                  c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane);
+                  c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, amx);
   // proj_up in two halves: the x_m half feeds the conv / q / k / v front end and is on the block's critical path; the
   // z half is only needed by the output gate after the state pass and is issued beside it (mlstm_up_z)
   GemmArgs up;
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p + r0 * e->ucols, up.ldc = 2 * inner;
   up.m = rows, up.n = split_up_now(e) ? inner : 2 * inner, up.k = D;
+  up.a_amax = amx;
   if (a3) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
   if (gn_fused(e, T) && !split_up_now(e)) up.act_silu_from = inner;  // the z half is stored as silu(z)
   gemm(e, up, sl.s);
@@ -909,6 +918,7 @@ void mlstm_up_z(lram_engine* e, int i, int T, const Slice& sl) {
   GemmArgs up;
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = e->bw[i].proj_up + (size_t)inner * D, up.ldw = D;
   up.c = e->U.p + r0 * e->ucols + inner, up.ldc = 2 * inner, up.m = rows, up.n = inner, up.k = D;
+  if (e->use_f16x2) up.a_amax = e->AMX_XN.p + r0;  // written by this block's norm launch (mlstm_front)
   if (a3_for(e, e->bw[i].proj_up, rows, D, D)) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
   if (gn_fused(e, T)) up.act_silu_from = 0;
   gemm(e, up, sl.s);
@@ -1011,10 +1021,11 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   gn.h = Y, gn.gamma = w.gn_g, gn.beta = w.gn_b, gn.out = X, gn.rows = rows, gn.NH = NH, gn.DH = SDH;
   gn.mode = 1, gn.eps = c.ln_eps, gn.skip = nullptr, gn.xa = nullptr, gn.u = nullptr;
   launch_group_norm(gn, s);
-  launch_row_norm(X, D, XN, D, w.ffn_norm_g, w.ffn_norm_b, rows, D, c.ln_eps, c.norm_is_rms, s);
+  float* amx = e->use_f16x2 ? e->AMX_XN.p + r0 : nullptr;
+  launch_row_norm(X, D, XN, D, w.ffn_norm_g, w.ffn_norm_b, rows, D, c.ln_eps, c.norm_is_rms, s, nullptr, nullptr, 0, amx);
   GemmArgs up;
   up.a = XN, up.lda = D, up.w = w.ffn_up, up.ldw = D, up.c = Ubuf, up.ldc = 2 * F;
-  up.m = rows, up.n = 2 * F, up.k = D;
+  up.m = rows, up.n = 2 * F, up.k = D, up.a_amax = amx;
   gemm(e, up, s);
   launch_gelu_gate(Ubuf, Gbuf, rows, F, s);
   GemmArgs dn;
@@ -1190,19 +1201,28 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   const uint8_t* rs = (reset && !(e->compat_stale && i > 0)) ? reset + b0 : nullptr;
   hipStream_t gs = sl.s;
   const bool a3_in = a3_for(e, w.in_proj, rows, D, D), a3_out = a3_for(e, w.out_proj, rows, di, di);
+  // f16x2 projections: the kernels that produce their operands hand the row maxima over -- the norm writes XN's (one
+  // wave per row), the conv and the state-update kernels one partial maximum per wave (d_inner / 64 per row, plain
+  // stores; the GEMM's prologue takes their maximum).  Atomic maxima were measured first: +20 us on the conv launch,
+  // +13 us on the state update (147k single-lane atomics per launch), as much as the row-maximum launches they replaced.
+  const bool amx = e->use_f16x2 && di % 64 == 0 && N == 16 && T <= 4;
+  const int parts = di / 64;
+  float* amx_xn = amx ? e->AMX_XN.p + r0 : nullptr;
+  float* amx_xa = amx ? e->AMX_XA.p + r0 * parts : nullptr;
+  float* amx_h = amx ? e->AMX_H.p + r0 * parts : nullptr;
   if (stage == 0) {
     launch_add_rms_norm(X, i == 0 ? nullptr : RES, RES, a3_in ? nullptr : XN, w.norm_g, rows, D, c.norm_eps, sl.s,
-                        a3_in ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane);
+                        a3_in ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, amx_xn);
   } else if (stage == 1) {
     MambaConvArgs ca;
     ca.xz = U, ca.conv_state = st.conv.p + b0 * di * c.d_conv, ca.conv_w = w.conv_w, ca.conv_b = w.conv_b, ca.xc = XA;
-    ca.reset = rs, ca.B = sl.nb, ca.T = T, ca.d_inner = di, ca.K = c.d_conv;
+    ca.reset = rs, ca.B = sl.nb, ca.T = T, ca.d_inner = di, ca.K = c.d_conv, ca.amax = amx_xa;
     launch_mamba_conv(ca, sl.s);
   } else {
     MambaSsmArgs sa;
     sa.ssm_state = st.s0.p + b0 * di * N, sa.xc = XA, sa.dtp = DTP, sa.dt_bias = w.dt_bias, sa.xdb = Q;
     sa.A_log = w.A_log, sa.Dp = w.Dp, sa.xz = U, sa.y = H, sa.reset = rs;
-    sa.B = sl.nb, sa.T = T, sa.d_inner = di, sa.N = N, sa.R = R;
+    sa.B = sl.nb, sa.T = T, sa.d_inner = di, sa.N = N, sa.R = R, sa.amax = amx_h;
     if (a3_out) sa.y = nullptr, sa.y3 = e->G3 + r0 * di, sa.y3_plane = (int64_t)e->g3_plane;
     prof_record(e, sl.s, true);
     launch_mamba_ssm(sa, sl.s);
@@ -1211,13 +1231,13 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   if (stage == 0) {
     GemmArgs in;
     in.a = XN, in.lda = D, in.w = w.in_proj, in.ldw = D, in.c = U, in.ldc = 2 * di, in.bias = w.in_proj_b;
-    in.m = rows, in.n = 2 * di, in.k = D;
+    in.m = rows, in.n = 2 * di, in.k = D, in.a_amax = amx_xn;
     if (a3_in) in.a3 = e->XN3 + r0 * D, in.a3_plane = (int64_t)e->xn3_plane;
     gemm(e, in, gs);
   } else if (stage == 1) {
     GemmArgs xp;
     xp.a = XA, xp.lda = di, xp.w = w.x_proj, xp.ldw = di, xp.c = Q, xp.ldc = ldx;
-    xp.m = rows, xp.n = ldx, xp.k = di;
+    xp.m = rows, xp.n = ldx, xp.k = di, xp.a_amax = amx_xa, xp.amax_parts = amx ? parts : 1;
     gemm(e, xp, gs);
     GemmArgs dp;
     dp.a = Q, dp.lda = ldx, dp.w = w.dt_proj, dp.ldw = R, dp.c = DTP, dp.ldc = di;
@@ -1226,7 +1246,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   } else {
     GemmArgs op;
     op.a = H, op.lda = di, op.w = w.out_proj, op.ldw = di, op.c = X, op.ldc = D, op.bias = w.out_proj_b;
-    op.m = rows, op.n = D, op.k = di;
+    op.m = rows, op.n = D, op.k = di, op.a_amax = amx_h, op.amax_parts = amx ? parts : 1;
     if (a3_out) op.a3 = e->G3 + r0 * di, op.a3_plane = (int64_t)e->g3_plane;
     gemm(e, op, gs);
   }
@@ -1972,11 +1992,11 @@ int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int
     LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scales), ((size_t)n + m) * sizeof(float)));
     try {
       launch_split_f16x2(dev_w, n, k, planes, scales, s);
-      launch_row_scale(dev_a, lda, nullptr, 0, m, k, scales + n, s);
+      launch_row_amax(dev_a, lda, nullptr, 0, m, k, scales + n, s);
       GemmArgs g;
       g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
       g.residual = accumulate ? dev_c : nullptr;
-      g.m = m, g.n = n, g.k = k, g.w2 = planes, g.w2_plane = (int64_t)numel, g.w_inv = scales, g.a_scale = scales + n;
+      g.m = m, g.n = n, g.k = k, g.w2 = planes, g.w2_plane = (int64_t)numel, g.w_inv = scales, g.a_amax = scales + n;
       launch_gemm_f16x2(g, s);
       LRAM_HIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {

@@ -18,8 +18,9 @@
 // <= 168 VGPRs: THREE workgroups per CU, three waves per SIMD, while one waits for its tile two others compute.
 //
 // W is split once when the weights are finalised (two [N,K] f16 planes + the per-row inverse scale); A is split on
-// the fly while its fp32 tile is staged into LDS, with per-row scales computed by `launch_row_scale` (or handed over
-// by the kernel that produced A).  Scales are powers of two: un-scaling the accumulator is exact.
+// the fly while its fp32 tile is staged into LDS; its per-row scale is derived from the row's largest magnitude, which
+// the kernel that produced A hands over (norm kernels: one wave per row; the Mamba conv / state-update kernels: an
+// atomic max per wave) or `launch_row_amax` computes.  Scales are powers of two: un-scaling the accumulator is exact.
 #include <algorithm>
 #include <cstdlib>
 
@@ -37,17 +38,6 @@ constexpr int BN = 128, BK = 32;
 constexpr int PITCH = 40;          // f16 elements per LDS row (80 B: conflict-free ds_read_b128)
 constexpr int PLANE = BN * PITCH;  // elements per 128-row plane
 
-// power-of-two scale that puts `mx` into [2^14, 2^15); 1 for an all-zero row
-__device__ __forceinline__ float pow2_scale(float mx) {
-  const unsigned bits = __float_as_uint(mx);
-  int e = (int)((bits >> 23) & 0xffu);  // biased exponent of the largest magnitude (0: zero / subnormal row)
-  if (mx == 0.f) return 1.f;
-  if (e == 0) e = 1;
-  int se = 268 - e;                     // biased exponent of 2^(14 - (e - 127))
-  se = se > 254 ? 254 : (se < 1 ? 1 : se);
-  return __uint_as_float((unsigned)se << 23);
-}
-
 // BM = 128: 64 x 64 per wave (2 x 2 MFMA tiles).  BM = 64: 32 x 64 per wave.  GATE: the fp32 A operand is multiplied
 // element-wise by g.gate while it is staged (mLSTM output gate); the row scales then are those of the gated rows.
 // ABL (measurement only, results are wrong for ABL != 0): 1 no fp32 -> f16 conversion arithmetic, 2 no global loads in
@@ -59,6 +49,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
   constexpr int TI = WM / 32;  // MFMA row tiles per wave
   constexpr int APLANE = BM * PITCH;
   __shared__ __attribute__((aligned(16))) _Float16 lds[2 * APLANE + 2 * PLANE];
+  __shared__ float srow[BM];        // power-of-two scale of each of the tile's A rows (0 beyond M)
   _Float16* As = lds;               // [2][BM][PITCH]   hi, lo
   _Float16* Bs = lds + 2 * APLANE;  // [2][128][PITCH]
 
@@ -77,6 +68,18 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
   const int tn_idx = bid - tm_idx * tiles_n;
   const int m0 = tm_idx * BM, n0 = tn_idx * BN;
 
+  // row scales from the producers' row maxima: a row's maximum may arrive in `amax_parts` partial maxima (one per wave
+  // of a producer whose workgroups each cover a slice of the row: plain stores there, no atomics, no zeroing)
+  if (tid < BM) {
+    const int gm = m0 + tid;
+    float mx = 0.f;
+    if (gm < g.m) {
+      const float* ap = g.a_amax + (int64_t)gm * g.amax_parts;
+      for (int q = 0; q < g.amax_parts; ++q) mx = fmaxf(mx, ap[q]);
+    }
+    srow[tid] = gm < g.m ? pow2_scale(mx) : 0.f;
+  }
+  __syncthreads();
   const int lr = tid >> 3;        // A: row within a 32-row slab
   const int lc = (tid & 7) << 2;  // A: k offset 0,4,..,28
   constexpr int NA = BM / 32;     // float4 per thread and K tile
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
     const int gm = m0 + lr + 32 * i;
     aok[i] = gm < g.m;
     const int gmc = aok[i] ? gm : g.m - 1;  // clamped: loads are unconditional (no branch around them), masked after
-    sa[i] = g.a_scale[gmc];
+    sa[i] = srow[lr + 32 * i];
     arow[i] = A + (int64_t)gmc * g.lda + lc;
     if (GATE) grow[i] = g.gate + (int64_t)gmc * g.ldg + lc;
   }
@@ -119,9 +122,6 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
   // through the scale of the tile / an AND mask on the weight chunks.
   const bool k_tail = (g.k & (BK - 1)) != 0;
   const int kt0_ = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
-#pragma unroll
-  for (int i = 0; i < NA; ++i)
-    if (!aok[i]) sa[i] = 0.f;
   auto load_tile = [&](int set, int k0) {
     if (ABL == 2 && k0 != kt0_ * BK) return;
 #pragma unroll
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + WM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < g.m) {
-          float v = acc[i][j][r] * (wi / g.a_scale[row]);
+          float v = acc[i][j][r] * (wi / srow[row - m0]);
           if (S != nullptr) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
             S[(int64_t)row * g.n + col] = v;
             continue;
@@ -290,9 +290,9 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
     }
 }
 
-// One wave per row: scale[r] = power of two that puts max_k |a[r][k] (* gate[r][k])| into [2^14, 2^15).
-__global__ __launch_bounds__(256) void row_scale_kernel(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows,
-                                                        int k, float* scale) {
+// One wave per row: amax[r] = max_k |a[r][k] (* gate[r][k])|.
+__global__ __launch_bounds__(256) void row_amax_kernel(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows,
+                                                       int k, float* amax) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* ar = a + (int64_t)row * lda;
@@ -306,9 +306,8 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* a, int64_t 
     }
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-  if (lane == 0) scale[row] = pow2_scale(mx);
+  mx = wave_max(mx);
+  if (lane == 0) amax[row] = mx;
 }
 
 // One wave per weight row: planes[0][n][k] = hi, planes[1][n][k] = lo of scale * w[n][k]; inv[n] = 1 / scale.
@@ -337,10 +336,10 @@ bool gemm_f16x2_supported(const GemmArgs& g) {
          (g.lda & 3) == 0 && (g.w2_plane & 7) == 0 && g.a3 == nullptr && (g.gate == nullptr || (g.ldg & 3) == 0);
 }
 
-void launch_row_scale(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* scale,
-                      hipStream_t stream) {
-  LRAM_REQUIRE((k & 3) == 0 && (lda & 3) == 0 && (gate == nullptr || (ldg & 3) == 0), "row scale: K, lda must be multiples of 4");
-  hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a, lda, gate, ldg, rows, k, scale);
+void launch_row_amax(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* amax,
+                     hipStream_t stream) {
+  LRAM_REQUIRE((k & 3) == 0 && (lda & 3) == 0 && (gate == nullptr || (ldg & 3) == 0), "row amax: K, lda must be multiples of 4");
+  hipLaunchKernelGGL(row_amax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a, lda, gate, ldg, rows, k, amax);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
@@ -393,7 +392,7 @@ static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     launch_bm_pf<BM, GATE, 1>(g, grid, stream);
 }
 
-// g.a_scale: per-row scales of A (of the gated rows when g.gate is set), from launch_row_scale or A's producer.
+// g.a_amax: per-row largest magnitude of A (of the gated rows when g.gate is set), from launch_row_amax or A's producer.
 void launch_gemm_f16x2(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
   static const int prio = [] {
@@ -402,7 +401,7 @@ void launch_gemm_f16x2(const GemmArgs& g_in, hipStream_t stream) {
   }();
   g.mfma_prio = prio;
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
-  LRAM_REQUIRE(gemm_f16x2_supported(g) && g.a_scale != nullptr, "gemm f16x2: unsupported operand layout");
+  LRAM_REQUIRE(gemm_f16x2_supported(g) && g.a_amax != nullptr, "gemm f16x2: unsupported operand layout");
   int S = 1;
   if (g.act_silu_from >= 0 || g.gate != nullptr)
     g.split_k = 1, g.k_tiles_per_split = 0;  // output activation / gated operand: K unsplit

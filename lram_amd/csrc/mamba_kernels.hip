@@ -31,7 +31,12 @@ __global__ __launch_bounds__(256) void mamba_conv_kernel(MambaConvArgs a) {
     win.z = win.w;
     win.w = x;
     const float y = win.x * w.x + win.y * w.y + win.z * w.z + win.w * w.w + bias;
-    a.xc[row * di + d] = silu_f(y);
+    const float o = silu_f(y);
+    a.xc[row * di + d] = o;
+    if (a.amax != nullptr) {  // (d_inner is a multiple of 64: the lanes of a wave share the env, hence the row)
+      const float m = wave_max(fabsf(o));
+      if ((threadIdx.x & 63) == 0) a.amax[row * (di >> 6) + (d >> 6)] = m;  // this wave's 64 channels of the row
+    }
   }
   *reinterpret_cast<float4*>(a.conv_state + gid * 4) = win;
 }
@@ -141,11 +146,17 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
   __syncthreads();
   for (int i = tid; i < ne * T * cpb; i += 256) {
     const int c = i % cpb, et = i / cpb;
+    float yabs = 0.f;
     if (dbase + c < di) {
       const int64_t off = ((int64_t)b0 * T + et) * di + dbase + c;
       const float yv = yo[et / T][et % T][c];
+      yabs = fabsf(yv);
       if (a.y != nullptr) a.y[off] = yv;
       if (a.y3 != nullptr) split3_store(yv, a.y3 + off, a.y3_plane);
+    }
+    if (a.amax != nullptr && cpb == 64) {  // one wave = one (env, token) row segment of 64 channels
+      const float m = wave_max(yabs);
+      if ((tid & 63) == 0) a.amax[((int64_t)b0 * T + et) * (di >> 6) + blockIdx.x] = m;
     }
   }
 }

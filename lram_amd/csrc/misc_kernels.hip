@@ -20,7 +20,7 @@ constexpr int kNormMaxV = 8;  // float4 per lane: d <= 2048
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t in_stride, float* out,
                                                        int64_t out_stride, const float* gamma, const float* beta,
                                                        int rows, int d, float eps, int rms, float* out2,
-                                                       uint16_t* planes, int64_t plane_stride) {
+                                                       uint16_t* planes, int64_t plane_stride, float* amax) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
   const float var = wave_sum(q) / (float)d;
   const float rstd = rms ? rsqrtf(var + eps) : 1.f / sqrtf(var + eps);
   float* dst = out + (int64_t)row * out_stride;
+  float mx = 0.f;
 #pragma unroll
   for (int j = 0; j < kNormMaxV; ++j) {
     const int i = lane + 64 * j;
@@ -64,9 +65,14 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
       o.z += bb.z;
       o.w += bb.w;
     }
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     if (out != nullptr) *reinterpret_cast<float4*>(dst + 4 * i) = o;
     if (out2 != nullptr) *reinterpret_cast<float4*>(out2 + (int64_t)row * out_stride + 4 * i) = o;  // second copy (taps)
     if (planes != nullptr) split3_store4(o, planes + (int64_t)row * out_stride + 4 * i, plane_stride);  // GEMM operand
+  }
+  if (amax != nullptr) {  // (uniform) the row's largest magnitude: the f16x2 GEMM derives its operand scale from it
+    mx = wave_max(mx);
+    if (lane == 0) amax[row] = mx;
   }
 }
 
@@ -74,7 +80,8 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
 // res_out = hidden + res_in ; normed = res_out * rsqrt(mean(res_out^2) + eps) * gamma
 __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, const float* res_in, float* res_out,
                                                            float* normed, const float* gamma, int rows, int d,
-                                                           float eps, uint16_t* planes, int64_t plane_stride) {
+                                                           float eps, uint16_t* planes, int64_t plane_stride,
+                                                           float* amax) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, 
     }
   }
   const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  float mx = 0.f;
 #pragma unroll
   for (int j = 0; j < kNormMaxV; ++j) {
     const int i = lane + 64 * j;
@@ -112,8 +120,13 @@ __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, 
     o.y = v[j].y * rstd * g.y;
     o.z = v[j].z * rstd * g.z;
     o.w = v[j].w * rstd * g.w;
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     if (normed != nullptr) *reinterpret_cast<float4*>(normed + base + 4 * i) = o;
     if (planes != nullptr) split3_store4(o, planes + base + 4 * i, plane_stride);
+  }
+  if (amax != nullptr) {
+    mx = wave_max(mx);
+    if (lane == 0) amax[row] = mx;
   }
 }
 
@@ -280,19 +293,19 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* buf, const uint8_
 
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2,
-                     uint16_t* planes, int64_t plane_stride) {
+                     uint16_t* planes, int64_t plane_stride, float* amax) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "row norm: d must be a multiple of 4 and <= 2048");
   hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, in_stride, out, out_stride,
-                     gamma, beta, rows, d, eps, rms, out2, planes, plane_stride);
+                     gamma, beta, rows, d, eps, rms, out2, planes, plane_stride, amax);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
                          const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes,
-                         int64_t plane_stride) {
+                         int64_t plane_stride, float* amax) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "rms norm: d must be a multiple of 4 and <= 2048");
   hipLaunchKernelGGL(add_rms_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, hidden, res_in, res_out,
-                     normed, gamma, rows, d, eps, planes, plane_stride);
+                     normed, gamma, rows, d, eps, planes, plane_stride, amax);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
