@@ -35,21 +35,33 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 constexpr int BN = 128, BK = 32;
-constexpr int PITCH = 40;          // f16 elements per LDS row (80 B: conflict-free ds_read_b128)
-constexpr int PLANE = BN * PITCH;  // elements per 128-row plane
+constexpr int kPitchPadded = 40;   // f16 elements per padded LDS row (80 B: conflict-free ds_read_b128)
 
 // BM = 128: 64 x 64 per wave (2 x 2 MFMA tiles).  BM = 64: 32 x 64 per wave.  GATE: the fp32 A operand is multiplied
 // element-wise by g.gate while it is staged (mLSTM output gate); the row scales then are those of the gated rows.
 // ABL (measurement only, results are wrong for ABL != 0): 1 no fp32 -> f16 conversion arithmetic, 2 no global loads in
 // the K loop, 3 no MFMA, 4 no LDS fragment reads in the loop, 5 no LDS writes, 6 no barriers -- the guide's "ablate before
 // optimising" (cdna_hip_programming.md section 7); LRAM_F16_ABL selects one for scripts/bench_gemm.py.
-template <bool HAS_BIAS, bool HAS_RES, int BM, bool GATE, int PF, int ABL = 0>
-__global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmArgs g) {
+// DB: two LDS stages and two register sets, ONE barrier per K tile: while the matrix cores work on stage s, the same
+// wave converts the next tile (already in registers) into stage s ^ 1 and the tile after that is in flight from
+// memory.  Without it the fp32 -> f16 conversion, the LDS writes and the MFMA block of a workgroup are separated by
+// barriers and overlap only with OTHER workgroups' phases: measured, the MFMA time was simply added on top of the rest
+// (16M proj_up: 66 us with, 52 us without the MFMAs, 15.5 us of pure MFMA time).
+template <bool HAS_BIAS, bool HAS_RES, int BM, bool GATE, int PF, int ABL = 0, bool DB = false>
+__global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kernel(GemmArgs g) {
   constexpr int WM = BM / 2;   // rows per wave
   constexpr int TI = WM / 32;  // MFMA row tiles per wave
+  // DB: un-padded 64-byte rows with the 16-byte chunk index XOR-ed by (row >> 2) & 3 (the 16 lanes of a ds_read_b128
+  // pass then cover all 64 banks: rows r, r + 4, r + 8, r + 12 of a pass would otherwise share their banks) -- 32 KB per
+  // stage, two stages of two workgroups fit a CU with room to spare; else rows padded to 80 bytes.
+  constexpr int PITCH = DB ? 32 : kPitchPadded;
+  constexpr int PLANE = BN * PITCH;
   constexpr int APLANE = BM * PITCH;
-  __shared__ __attribute__((aligned(16))) _Float16 lds[2 * APLANE + 2 * PLANE];
-  __shared__ float srow[BM];        // power-of-two scale of each of the tile's A rows (0 beyond M)
+  constexpr int STAGE = 2 * APLANE + 2 * PLANE;  // f16 elements of one LDS stage
+  __shared__ __attribute__((aligned(16))) _Float16 lds[(DB ? 2 : 1) * STAGE];
+  // power-of-two scale of each of the tile's A rows (0 beyond M): lives in the first stage's memory before the first
+  // tile is written and again after the last one is read (two stages of the 128-row tile are exactly half the CU's LDS)
+  float* srow = reinterpret_cast<float*>(lds);
   _Float16* As = lds;               // [2][BM][PITCH]   hi, lo
   _Float16* Bs = lds + 2 * APLANE;  // [2][128][PITCH]
 
@@ -80,15 +92,28 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
     srow[tid] = gm < g.m ? pow2_scale(mx) : 0.f;
   }
   __syncthreads();
+  auto refill_srow = [&]() {  // (after the K loop, behind its last barrier)
+    if (tid < BM) {
+      const int gm = m0 + tid;
+      float mx = 0.f;
+      if (gm < g.m) {
+        const float* ap = g.a_amax + (int64_t)gm * g.amax_parts;
+        for (int q = 0; q < g.amax_parts; ++q) mx = fmaxf(mx, ap[q]);
+      }
+      srow[tid] = gm < g.m ? pow2_scale(mx) : 0.f;
+    }
+    __syncthreads();
+  };
   const int lr = tid >> 3;        // A: row within a 32-row slab
   const int lc = (tid & 7) << 2;  // A: k offset 0,4,..,28
   constexpr int NA = BM / 32;     // float4 per thread and K tile
   // PF register sets: tile kt + PF is requested while tile kt is computed, so PF tiles of global loads are in flight
   // per workgroup at any time (PF = 2 keeps the memory pipe fed across the split / LDS-write / barrier stretch)
-  float4 ra[PF][NA];
-  float4 rz[PF][GATE ? NA : 1];
+  constexpr int NSET = DB ? 2 : PF;
+  float4 ra[NSET][NA];
+  float4 rz[NSET][GATE ? NA : 1];
   (void)rz;
-  uint4 rw[PF][4];
+  uint4 rw[NSET][4];
   float sa[NA];
   const float* arow[NA];
   const float* grow[GATE ? NA : 1];
@@ -103,6 +128,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
     arow[i] = A + (int64_t)gmc * g.lda + lc;
     if (GATE) grow[i] = g.gate + (int64_t)gmc * g.ldg + lc;
   }
+  __syncthreads();  // every thread has its row scales: the tile stages may overwrite srow now
   const _Float16* wrow[4];
   bool wok[4];
   int wkc[4];
@@ -136,7 +162,7 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
       rw[set][j] = *reinterpret_cast<const uint4*>(wrow[j] + (kin ? k0 : 0));
     }
   };
-  auto store_tile = [&](int set, int k0) {
+  auto store_tile = [&](int set, int k0, int buf = 0) {
     const float kmask = (!k_tail || k0 + lc < g.k) ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -155,7 +181,8 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
         hi = *reinterpret_cast<const f16x4*>(&ra[set][i].x);
         lo = *reinterpret_cast<const f16x4*>(&ra[set][i].z);
       }
-      _Float16* dst = As + (lr + 32 * i) * PITCH + lc;
+      const int arow = lr + 32 * i;
+      _Float16* dst = As + buf * STAGE + arow * PITCH + (DB ? ((((lc >> 3) ^ ((arow >> 2) & 3)) << 3) | (lc & 4)) : lc);
       if (ABL != 5) {
         *reinterpret_cast<f16x4*>(dst) = hi;
         *reinterpret_cast<f16x4*>(dst + APLANE) = lo;
@@ -171,7 +198,8 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
       const unsigned msk = (wok[j] && (!k_tail || k0 + wkc[j] < g.k)) ? 0xffffffffu : 0u;
       uint4 v = rw[set][j];
       v.x &= msk, v.y &= msk, v.z &= msk, v.w &= msk;
-      if (ABL != 5 || v.x == 0x12345u) *reinterpret_cast<uint4*>(Bs + plane * PLANE + r * PITCH + c) = v;
+      const int cs = DB ? (((c >> 3) ^ ((r >> 2) & 3)) << 3) : c;
+      if (ABL != 5 || v.x == 0x12345u) *reinterpret_cast<uint4*>(Bs + buf * STAGE + plane * PLANE + r * PITCH + cs) = v;
     }
   };
 
@@ -185,8 +213,9 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
 
   const int li = lane & 31, lh = lane >> 5;
   // lane (row li, half lh) holds k = 8*lh + j (j = 0..7) of a 16-deep MFMA step for both operands
-  const _Float16* a_base = As + (WM * wm + li) * PITCH + 8 * lh;
-  const _Float16* b_base = Bs + (64 * wn + li) * PITCH + 8 * lh;
+  const _Float16* a_base = As + (WM * wm + li) * PITCH + (DB ? 0 : 8 * lh);
+  const _Float16* b_base = Bs + (64 * wn + li) * PITCH + (DB ? 0 : 8 * lh);
+  const int sw = (li >> 2) & 3;  // DB: chunk swizzle of this lane's rows (row offsets of the tiles are multiples of 32)
 
   const int nk_all = (g.k + BK - 1) / BK;
   const int kt0 = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
@@ -239,6 +268,46 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
     }
     if (g.mfma_prio) __builtin_amdgcn_s_setprio(0);
   };
+  if (DB) {
+    // step(kt): tile kt sits in stage cur, register set cur ^ 1 holds tile kt + 1, set cur is free.
+    auto frag_mfma = [&](int buf, int ks) {
+      f16x8 af[TI][2], bf[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int ko = ((2 * ks + lh) ^ sw) << 3;
+          if (t < TI) af[t][p] = *reinterpret_cast<const f16x8*>(a_base + buf * STAGE + p * APLANE + 32 * t * PITCH + ko);
+          bf[t][p] = *reinterpret_cast<const f16x8*>(b_base + buf * STAGE + p * PLANE + 32 * t * PITCH + ko);
+        }
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);  // lo * hi
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);  // hi * lo
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);  // hi * hi
+        }
+    };
+    auto step = [&](int cur, int kt) {
+      load_tile(cur, min(kt + 2, nk - 1) * BK);       // into the free set; lands during the NEXT step
+      frag_mfma(cur, 0);
+      if (kt + 1 < nk) store_tile(cur ^ 1, (kt + 1) * BK, cur ^ 1);  // conversion + LDS writes between the MFMA halves
+      frag_mfma(cur, 1);
+      __syncthreads();
+    };
+    load_tile(0, kt0 * BK);
+    load_tile(1, min(kt0 + 1, nk - 1) * BK);
+    store_tile(0, kt0 * BK, 0);
+    __syncthreads();
+    int kt = kt0;
+    for (; kt + 2 <= nk; kt += 2) {
+      step(0, kt);
+      step(1, kt + 1);
+    }
+    if (kt < nk) step(0, kt);
+    refill_srow();
+  } else {
   // The prefetch of a half is unconditional (past the last tile it re-reads the last one; nothing consumes it) and the
   // loop body always runs all PF halves: hipcc's wait counts are then exact -- a load behind a condition makes it
   // assume the shorter queue on every path and wait for the NEWEST register set where the oldest is needed.
@@ -260,6 +329,8 @@ __global__ __launch_bounds__(256, PF == 1 ? 3 : 2) void gemm_f16x2_kernel(GemmAr
     for (int u = 0; u < PF; ++u) half(u, kt + u);
   }
   if (PF > 1 && kt < nk) half(0, kt);  // odd tile count: one half left
+  refill_srow();
+  }
 
   // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5));
   // un-scale with the exact inverse powers of two of the row (A) and column (W) scales
@@ -385,6 +456,28 @@ static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
       case 6: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 6>), grid, block, 0, stream, g); return;
       default: break;
     }
+  }
+  // Two LDS stages + one barrier per K tile (the kernel's DB note) pay where the launch cannot fill the chip with
+  // workgroups anyway -- at most one per CU: 206M proj_down (240 workgroups) 109 -> 86 us -- and lose where three
+  // single-stage workgroups per CU can overlap each other's phases (16M proj_up 62 -> 75 us, Mamba in_proj 128 -> 140).
+  // LRAM_F16_DB = 0 / 1 forces either (measurement knob), default 2 = by grid size.
+  static const int db = [] {
+    const char* v = std::getenv("LRAM_F16_DB");
+    return v ? std::atoi(v) : 2;
+  }();
+  const long wgs = (long)grid.x * grid.y * grid.z;
+  if ((db == 1 || (db == 2 && wgs <= 256)) && !GATE) {
+    const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
+    dim3 block(256);
+    if (hb && hr)
+      hipLaunchKernelGGL((gemm_f16x2_kernel<true, true, BM, false, 2, 0, true>), grid, block, 0, stream, g);
+    else if (hb)
+      hipLaunchKernelGGL((gemm_f16x2_kernel<true, false, BM, false, 2, 0, true>), grid, block, 0, stream, g);
+    else if (hr)
+      hipLaunchKernelGGL((gemm_f16x2_kernel<false, true, BM, false, 2, 0, true>), grid, block, 0, stream, g);
+    else
+      hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, BM, false, 2, 0, true>), grid, block, 0, stream, g);
+    return;
   }
   if (pf == 2)
     launch_bm_pf<BM, GATE, 2>(g, grid, stream);
