@@ -127,7 +127,7 @@ void launch_scatter_token0(float* x, const float* emb, int64_t emb_stride, int B
 // argmax over logits [B, act_dim*n_vocab] (+ de-tokenise)
 void launch_action_argmax(const float* logits, float* actions, int32_t* tokens, int B, int act_dim, int n_vocab,
                           int n_discrete, int action_channels, float tok_min, float tok_max, int discrete,
-                          int col_begin, hipStream_t stream);
+                          int col_begin, hipStream_t stream, int col_end = -1);
 
 // ---------------------------------------------------------------------------------------------
 // xLSTM

@@ -181,6 +181,12 @@ struct lram_engine {
   int n_micro = 0;  // 0 = auto
   // reference-trajectory modes of the Mamba agent (lram_set_compat_mode)
   int compat_repeat = 1;      // forwards per env-step: action dim i is read from forward min(i, repeat - 1)
+  // Repeated forwards share what does not depend on the recurrent state: the (s, rtg, r) token embeddings, and with them
+  // layer 0's add + RMSNorm and in_proj (identical inputs in every pass).  Pass 0 keeps them in X0 / U0; later passes skip
+  // the front end and layer 0's first stage.  compat_pass / compat_passes: the pass under way, set by step_launches.
+  DevBuf X0, U0;
+  int compat_pass = 0, compat_passes = 1;
+  bool compat_share = true;   // LRAM_COMPAT_SHARE=0: every repeated forward recomputes the front end and layer 0's in_proj
   bool compat_stale = false;  // a reset re-initialises layer 0 only; layers >= 1 keep the previous episode's state
   int cell_unroll = 16;   // C rows in flight per thread (LRAM_CELL_UNROLL overrides: 8 / 16 / 32)
   int cell_lds_pad = -1;  // -1 = auto;  // bytes of LDS the cell kernel requests per workgroup while pipelined (occupancy cap)
@@ -1191,7 +1197,12 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   float* X = e->X.p + r0 * D;
   float* RES = e->RES.p + r0 * D;
   float* XN = e->XN.p + r0 * D;
-  float* U = e->U.p + r0 * 2 * di;
+  // shared repeated forwards (step_launches): layer 0's residual input and in_proj output are the same in every pass
+  const bool share = e->compat_passes > 1;
+  if (share && i == 0 && stage == 0 && e->compat_pass > 0) return;
+  float* U = (share && i == 0) ? e->U0.p + r0 * 2 * di : e->U.p + r0 * 2 * di;
+  float* RES_out = (share && i == 0) ? e->X0.p + r0 * D : RES;   // layer 0: RES = the embedded tokens, kept in X0
+  const float* RES_in = i == 0 ? nullptr : ((share && i == 1) ? e->X0.p + r0 * D : RES);
   float* XA = e->XA.p + r0 * di;
   float* Q = e->Q.p + r0 * ldx;
   float* DTP = e->DTP.p + r0 * di;
@@ -1211,7 +1222,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   float* amx_xa = amx ? e->AMX_XA.p + r0 * parts : nullptr;
   float* amx_h = amx ? e->AMX_H.p + r0 * parts : nullptr;
   if (stage == 0) {
-    launch_add_rms_norm(X, i == 0 ? nullptr : RES, RES, a3_in ? nullptr : XN, w.norm_g, rows, D, c.norm_eps, sl.s,
+    launch_add_rms_norm(X, RES_in, RES_out, a3_in ? nullptr : XN, w.norm_g, rows, D, c.norm_eps, sl.s,
                         a3_in ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, amx_xn);
   } else if (stage == 1) {
     MambaConvArgs ca;
@@ -1433,7 +1444,7 @@ void persist_step(lram_engine* e, int path, const float* obs, int emb, const flo
 // output buffer is given).  One fork / join of the slice streams brackets the whole call.
 void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* rtg, const float* rew, int L,
                         const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s,
-                        int col_begin = 0) {
+                        int col_begin = 0, int shared_passes = 0) {
   const lram_config& c = e->cfg;
   const int D = c.d_model, T = c.tokens_per_step;
   const int64_t obs_w = emb ? D : c.state_dim;
@@ -1453,6 +1464,7 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
     Tc = T * Lc;
     last_steps = Lc;
     for (const Slice& x : sl) {
+      if (shared_passes > 1 && col_begin > 0) break;  // the tokens of this env-step were embedded by pass 0 (X0 / U0)
       const size_t r0 = (size_t)x.b0 * Tc, b0 = x.b0;
       float* X = e->X.p + r0 * D;
       for (int j = 0; j < Lc; ++j) {
@@ -1478,16 +1490,20 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   if (actions != nullptr) {
     const int64_t nlog = (int64_t)c.act_dim * c.n_vocab;
     const int pred = T * (last_steps - 1) + c.pred_token;  // rtg token of the last timestep in the last chunk
+    // shared repeated forwards: pass p only has to produce action dim p (the last pass every dim from its own on), so
+    // the head evaluates that column block of action_net alone
+    const int col_end = (shared_passes > 1 && col_begin + 1 < shared_passes) ? col_begin + 1 : c.act_dim;
+    const int col0 = shared_passes > 1 ? col_begin : 0;
     for (const Slice& x : sl) {
       const size_t r0 = (size_t)x.b0 * Tc, b0 = x.b0;
       GemmArgs gh;
-      gh.a = e->HID.p + (r0 + pred) * D, gh.lda = (int64_t)Tc * D, gh.w = e->w_head, gh.ldw = D;
-      gh.c = e->LOGITS.p + b0 * nlog, gh.ldc = nlog, gh.bias = e->b_head;
-      gh.m = x.nb, gh.n = (int)nlog, gh.k = D;
+      gh.a = e->HID.p + (r0 + pred) * D, gh.lda = (int64_t)Tc * D, gh.w = e->w_head + (size_t)col0 * c.n_vocab * D, gh.ldw = D;
+      gh.c = e->LOGITS.p + b0 * nlog + (size_t)col0 * c.n_vocab, gh.ldc = nlog, gh.bias = e->b_head + (size_t)col0 * c.n_vocab;
+      gh.m = x.nb, gh.n = (col_end - col0) * c.n_vocab, gh.k = D;
       gemm(e, gh, x.s);
       launch_action_argmax(e->LOGITS.p + b0 * nlog, actions + b0 * c.act_dim,
                            tokens ? tokens + b0 * c.act_dim : nullptr, x.nb, c.act_dim, c.n_vocab, c.n_discrete,
-                           c.action_channels, c.tok_min, c.tok_max, discrete, col_begin, x.s);
+                           c.action_channels, c.tok_min, c.tok_max, discrete, col_begin, x.s, col_end);
     }
   }
   if (multi) join_slices(e, sl, hbm, s);
@@ -1499,8 +1515,19 @@ void step_launches(lram_engine* e, const float* obs, int emb, const float* rtg, 
   // (state, rtg, reward) tokens go through the stack once per action dim with the cache on, and action dim i is the
   // prediction of forward i.  Forward p writes action columns >= p, so column i keeps forward min(i, repeat - 1).
   const int passes = discrete ? 1 : std::max(1, std::min(e->compat_repeat, e->cfg.act_dim));
-  for (int p = 0; p < passes; ++p)
-    timesteps_launches(e, obs, emb, rtg, rew, 1, p == 0 ? reset : nullptr, discrete, actions, tokens, s, p);
+  const bool share = passes > 1 && e->cfg.backbone == LRAM_BACKBONE_MAMBA && e->compat_share && e->cfg.n_blocks >= 2;
+  if (share) {
+    const size_t bt = (size_t)e->B * e->cfg.tokens_per_step;
+    if (e->X0.n < bt * e->cfg.d_model) e->X0.alloc(bt * e->cfg.d_model);
+    if (e->U0.n < bt * 2 * e->cfg.d_inner) e->U0.alloc(bt * 2 * e->cfg.d_inner);
+  }
+  e->compat_passes = share ? passes : 1;
+  for (int p = 0; p < passes; ++p) {
+    e->compat_pass = share ? p : 0;
+    timesteps_launches(e, obs, emb, rtg, rew, 1, p == 0 ? reset : nullptr, discrete, actions, tokens, s, p,
+                       share ? passes : 0);
+  }
+  e->compat_pass = 0, e->compat_passes = 1;
 }
 
 struct StateView {
@@ -1566,6 +1593,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     }
     if (const char* v = std::getenv("LRAM_PERSISTENT")) e->persist_mode = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_PERSIST_WGS")) e->persist_wgs = std::max(8, std::min(256, std::atoi(v)));
+    if (const char* v = std::getenv("LRAM_COMPAT_SHARE")) e->compat_share = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_LEAN_FRONT")) e->lean_front = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_A3")) e->use_a3 = std::atoi(v) != 0;

@@ -157,13 +157,14 @@ __global__ __launch_bounds__(256) void scatter_token0_kernel(float* x, const flo
 __global__ __launch_bounds__(256) void action_argmax_kernel(const float* logits, float* actions, int32_t* tokens,
                                                             int B, int act_dim, int n_vocab, int n_discrete,
                                                             int action_channels, float tok_min, float tok_max,
-                                                            int discrete, int col_begin) {
+                                                            int discrete, int col_begin, int col_end) {
   const int lane = threadIdx.x & 63;
   const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int ndim = discrete ? 1 : act_dim;
   if (item >= B * ndim) return;
   const int b = item / ndim, j = item - b * ndim;
-  if (j < col_begin) return;  // repeated-forward mode: pass p only writes action dims >= p (engine.hip)
+  if (j < col_begin || j >= col_end) return;  // repeated-forward mode: pass p writes action dim p, the last pass
+                                              // every dim from its own on (engine.hip::step_launches)
   const float* lg = logits + (int64_t)b * act_dim * n_vocab + (int64_t)j * n_vocab;
   const int n = discrete ? n_discrete : n_vocab;
   float best = -INFINITY;
@@ -328,10 +329,11 @@ void launch_scatter_token0(float* x, const float* emb, int64_t emb_stride, int B
 
 void launch_action_argmax(const float* logits, float* actions, int32_t* tokens, int B, int act_dim, int n_vocab,
                           int n_discrete, int action_channels, float tok_min, float tok_max, int discrete,
-                          int col_begin, hipStream_t stream) {
+                          int col_begin, hipStream_t stream, int col_end) {
   const int items = B * (discrete ? 1 : act_dim);
+  if (col_end < 0) col_end = act_dim;
   hipLaunchKernelGGL(action_argmax_kernel, dim3((items + 3) / 4), dim3(256), 0, stream, logits, actions, tokens, B,
-                     act_dim, n_vocab, n_discrete, action_channels, tok_min, tok_max, discrete, col_begin);
+                     act_dim, n_vocab, n_discrete, action_channels, tok_min, tok_max, discrete, col_begin, col_end);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
