@@ -18,7 +18,8 @@ import torch
 
 from lram_amd import init_state_dict, preset
 from oracle.dt_ref import OraclePolicy
-from tests.helpers import assert_actions_match, make_inputs, rel_err
+from tests.helpers import (assert_actions_match, assert_close_or_as_close_as_fp32_oracle, make_inputs, rel_err,
+                           relaxed_rows_fraction, relaxed_rows_reset)
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -72,6 +73,20 @@ def test_c5_206m_prefill_512_then_graph_decode_matches_oracle_fixture(hip_lib, m
     spec, _ = model_206m
     sd = init_state_dict(spec, seed=WEIGHT_SEED)   # as the fixture script draws them (no image encoder in the stream)
     fx = np.load(os.path.join(GOLD, "c5_prefill_206m.npz"))
+    # the same trajectory evaluated by the oracle in float64 (make_c5_fixture.py --fp64): after 1536 tokens x 20 blocks a
+    # fixed bar between two fp32 evaluations means little on ill-conditioned rows; the rule is the C4 test's -- within
+    # 2e-4 of the fp32 oracle, or as close to float64 as the fp32 oracle itself is (x 8), never further than 5e-3
+    fx64 = np.load(os.path.join(GOLD, "c5_prefill_206m_fp64.npz"))
+    assert abs(float(fx64["weight_checksum"]) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"])
+    relaxed_rows_reset()
+
+    def close(got, key, what, tol=2e-4):
+        want32, want64 = torch.from_numpy(fx[key]), torch.from_numpy(fx64[key])
+        got = got.detach().cpu().reshape(want32.shape)
+        if got.dim() == 1:
+            got, want32, want64 = got.unsqueeze(0), want32.unsqueeze(0), want64.unsqueeze(0)
+        assert_close_or_as_close_as_fp32_oracle(got, want32, want64, tol=tol, what=what)
+
     assert abs(weight_checksum(sd) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"]), \
         "seeded weights differ from the ones the fixture was computed with"
     obs, rtg = c5_inputs(spec)
@@ -83,19 +98,19 @@ def test_c5_206m_prefill_512_then_graph_decode_matches_oracle_fixture(hip_lib, m
     _, _, logits = eng.taps()
     ties = 0
     want_logits = torch.from_numpy(fx["logits_0"])
-    assert rel_err(logits.view_as(want_logits), want_logits) < 1e-3
+    close(logits, "logits_0", "C5 logits after the context")
     ties += assert_actions_match(act, torch.from_numpy(fx["actions_0"]), want_logits, spec, what="C5 last context step")
     # recurrent state after 1536 tokens
     r = probe(spec.head_dim).cuda()
     for i in STATE_BLOCKS:
         c = eng.export_state_tensor(i, 0)
-        assert rel_err(c @ r, fx[f"b{i}_Cr"]) < 1e-3, i
-        assert rel_err(r @ c, fx[f"b{i}_rC"]) < 1e-3, i
-        assert rel_err(c.abs().amax(dim=(-1, -2)), fx[f"b{i}_Cabsmax"]) < 1e-3, i
-        assert rel_err(eng.export_state_tensor(i, 1), fx[f"b{i}_n"]) < 1e-3, i
+        close(c @ r, f"b{i}_Cr", f"C5 block {i} C r")
+        close(r @ c, f"b{i}_rC", f"C5 block {i} r C")
+        close(c.abs().amax(dim=(-1, -2)), f"b{i}_Cabsmax", f"C5 block {i} max |C|")
+        close(eng.export_state_tensor(i, 1).squeeze(-1), f"b{i}_n", f"C5 block {i} n")
         assert rel_err(eng.export_state_tensor(i, 2), fx[f"b{i}_m"]) < 1e-4, i
-        assert rel_err(eng.export_state_tensor(i, 3), fx[f"b{i}_conv"]) < 1e-3, i
-    assert rel_err(eng.export_state_tensor(SLSTM_BLOCK, 0), fx[f"b{SLSTM_BLOCK}_slstm"]) < 1e-3
+        close(eng.export_state_tensor(i, 3), f"b{i}_conv", f"C5 block {i} conv")
+    close(eng.export_state_tensor(SLSTM_BLOCK, 0), f"b{SLSTM_BLOCK}_slstm", "C5 sLSTM state")
     # decode: hipGraph-captured single steps on fixed device buffers
     eng.set_graph_mode(True)
     d_obs = torch.empty(B, spec.state_dim, device="cuda")
@@ -107,10 +122,13 @@ def test_c5_206m_prefill_512_then_graph_decode_matches_oracle_fixture(hip_lib, m
         torch.cuda.synchronize()
         _, hidden, lg = eng.taps()
         want = torch.from_numpy(fx[f"logits_{k}"])
-        assert rel_err(hidden, fx[f"hidden_{k}"]) < 1e-3, k
-        assert rel_err(lg.view_as(want), want) < 1e-3, k
+        close(hidden, f"hidden_{k}", f"C5 decode {k} hidden")
+        close(lg, f"logits_{k}", f"C5 decode {k} logits")
         ties += assert_actions_match(a, torch.from_numpy(fx[f"actions_{k}"]), want, spec, what=f"C5 decode step {k}")
     assert ties == 0
+    if os.environ.get("LRAM_TEST_REPORT"):
+        print(f"[report] C5 fixture: {relaxed_rows_fraction():.2%} of the compared rows needed the float64 rule")
+    assert relaxed_rows_fraction() <= 0.25
     eng.close()
 
 
