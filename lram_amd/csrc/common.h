@@ -209,6 +209,10 @@ struct MlstmLazyArgs {
   // GN(h) * gn_g (+ gn_b) + gn_skip * xa, the output gate silu(z) is applied by proj_down while it stages its operand
   const float *gn_g = nullptr, *gn_b = nullptr, *gn_skip = nullptr;
   float gn_eps = 0.f;
+  // fold + readout in one pass over the due envs' matrix memory: the fold kernel, run AFTER this step's front end, also
+  // leaves the partial readouts y_t[c] = sum_r q_t[r] C_new[r][c] of its 64 rows in ypart [B, NH, DH / 64, T, DH]; the
+  // read pass then sums them (fixed order) instead of streaming C_base again for the envs that just folded
+  float* ypart = nullptr;
   float* pw = nullptr;    // [B, NH, T, kLazyWT] window scores: only for geometries with several column slices per head
   const uint8_t* reset;   // [B] or null
   int B, T, NH, DH;

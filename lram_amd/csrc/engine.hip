@@ -132,6 +132,16 @@ struct lram_engine {
                             // rounds: 391.1k / 393.5k off vs 395.8k / 397.5k on at 4096 slots; 1024 slots: -0.4 %)
                             // operand staging (measured: +0.7 % at 4096 env slots, -0.3 % at 1024: opt-in)
   bool split_up = true;     // LRAM_SPLIT_UP=0: proj_up as one GEMM ahead of the front end
+  // fold + readout (mlstm_lazy.hip, LRAM_FOLD_FUSED=1): an env's fold runs right ahead of its slice's read pass, after the
+  // front end, and hands the read pass q . C_new for the 64-row strips it has just rewritten -- the due envs' matrix memory
+  // is then read once per fold step instead of twice (-2.3 GB of 48 per step).  Correct (lazy / real-batch / full-size
+  // suites green with it) and SLOWER: 420.6k -> 400.5k env-steps/s in the state-pass queue, 397.6k on the fold stream
+  // (same box, round 3): the read passes get 4 % shorter and the 14 half-size folds cost what the 7 full ones did, but a
+  // fold that needs this step's q sits on the slice's critical chain (front end -> fold -> read pass), while the q-free
+  // folds run in the state-pass queue's idle stretches.  Default off.
+  bool fold_fused = false;
+  bool fold_fused_stream = true;  // LRAM_FOLD_FUSED_STREAM=0: fused folds inside the state-pass queue
+  DevBuf YPART;  // [B, NH, DH / 64, T, DH]
   int fold_gaps = 0;        // LRAM_FOLD_GAPS=g: the last g mLSTM blocks' folds run just ahead of their own read passes
   int front_stagger = 0;    // LRAM_FRONT_STAGGER=1: in the step's first mLSTM block, slice k's front end waits for slice k-1's
   int fold_bubbles = 2;     // LRAM_FOLD_BUBBLES=k: k folds before the first read pass, the rest behind the sLSTM block, all
@@ -589,6 +599,7 @@ void lazy_alloc(lram_engine* e) {
   }
   e->LZ_COUNT.alloc(2 * B);
   e->LZ_COUNT.zero();
+  if (e->fold_fused) e->YPART.alloc(B * NH * (DH / 64) * 4 * DH);  // (lazy steps take at most 4 tokens)
   for (int i = 0; i < c.n_blocks; ++i) {
     if (c.block_is_slstm[i]) continue;
     BlockState& s = e->st[i];
@@ -1069,8 +1080,10 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   // This step's folds depend on nothing this step computes (window rows, coefficients and counts are last step's).
   // They run on their own stream, one block ahead of the cells: block i's cells wait for fold(i), and fold(i + 1) is
   // enqueued right then, so it streams beside the cells of block i (the read-only cell pass leaves HBM headroom).
+  // fold + readout: no separate fold schedule at all, each slice's fold is launched right ahead of its read pass
+  const bool fused = lazy && e->fold_fused && e->YPART.p != nullptr && T <= 4;
   hipStream_t fs = hbm;
-  if (lazy && sl.size() > 1) {
+  if (lazy && (!fused || e->fold_fused_stream) && sl.size() > 1) {
     if (!e->fold_stream) LRAM_HIP_CHECK(hipStreamCreateWithFlags(&e->fold_stream, hipStreamNonBlocking));
     fs = e->fold_stream;
     stream_after(e, fs, hbm);  // hbm was forked from the caller's stream: inherit that dependency
@@ -1090,11 +1103,11 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   // fold_ahead: every block's fold is queued when the step starts (own stream, one event per block), so the folds
   // stream through HBM while the state pass has nothing to do -- the first front end of the step and the sLSTM
   // blocks -- instead of one block ahead of the cells, beside them.
-  const bool fold_ahead = lazy && fs != hbm && e->fold_ahead;
+  const bool fold_ahead = lazy && !fused && fs != hbm && e->fold_ahead;
   // fold_bubbles: the folds go onto the state-pass stream itself, into the two stretches of a step where that stream has
   // nothing to run -- before the first read pass (the step's front end and block 0's projections are still under way) and
   // while both slices are inside an sLSTM block -- instead of beside the read passes, which they slow down.
-  const int fold_bubbles = (lazy && fs != hbm && !fold_ahead) ? e->fold_bubbles : 0;
+  const int fold_bubbles = (lazy && !fused && fs != hbm && !fold_ahead) ? e->fold_bubbles : 0;
   std::vector<char> folded(c.n_blocks, 0);
   auto launch_folds_on_hbm = [&](int i) {
     MlstmLazyArgs la = lazy_args(e, i, T, reset, 0, e->B);
@@ -1113,7 +1126,7 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
       launch_folds(i);
       fold_done[i] = record_on(e, fs);
     }
-  } else if (lazy && next_mlstm(-1) >= 0) {
+  } else if (lazy && !fused && next_mlstm(-1) >= 0) {
     launch_folds(next_mlstm(-1));
   }
   for (int i = 0; i < c.n_blocks; ++i) {
@@ -1131,7 +1144,7 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
       if (!folded[i]) launch_folds_on_hbm(i);  // (stacks without an sLSTM block: one fold ahead of its read passes)
     } else if (fold_ahead) {
       LRAM_HIP_CHECK(hipStreamWaitEvent(hbm, fold_done[i], 0));  // fold(i) done before cell(i)
-    } else if (lazy) {
+    } else if (lazy && !fused) {
       stream_after(e, hbm, fs);  // fold(i) done before cell(i)
       const int nxt = next_mlstm(i);
       if (nxt >= 0) launch_folds(nxt);
@@ -1158,6 +1171,19 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
           la.lean_xa = e->XA.p + r0 * e->icols, la.lean_u = e->U.p + r0 * e->ucols;
           la.lean_wq = w.wq, la.lean_wk = w.wk, la.lean_wv = w.wv;
           if (gn_fused(e, T)) la.gn_g = w.on_g, la.gn_b = w.on_b, la.gn_skip = w.skip, la.gn_eps = c.ln_eps;
+        }
+        if (fused) {  // this slice's due envs: C_base <- g C_base + window, and q . C_new for the read pass, in one pass
+          la.ypart = e->YPART.p + (size_t)x.b0 * c.n_heads * (la.DH / 64) * T * la.DH;
+          MlstmLazyArgs fa = la;
+          fa.compact = e->lazy_compact ? 1 : 0;
+          // on the fold stream (fs != hbm): as soon as the slice's front end is through, beside whatever read pass is
+          // running, instead of in the state-pass queue between that pass and this slice's own
+          if (fs != hbm) stream_after(e, fs, x.s);
+          else stream_after(e, hbm, x.s);
+          prof_record(e, fs, true, true);
+          launch_mlstm_lazy_fold(fa, fs);
+          prof_record(e, fs, false, true);
+          if (fs != hbm) stream_after(e, hbm, fs);
         }
         stream_after(e, hbm, x.s);
         prof_record(e, hbm, true);
@@ -1600,6 +1626,8 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_SPLIT_UP")) e->split_up = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_BUBBLES")) e->fold_bubbles = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_FOLD_FUSED")) e->fold_fused = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_FOLD_FUSED_STREAM")) e->fold_fused_stream = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_GAPS")) e->fold_gaps = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_FRONT_STAGGER")) e->front_stagger = std::atoi(v);
     if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));

@@ -69,9 +69,12 @@ constexpr int kFPK = 40;   // LDS pitch of the scaled khat tile (32 rows of DH)
 constexpr int kFR = 64;    // rows of C per workgroup (two 32-row MFMA tiles): many short workgroups hide the
                            // load -> MFMA -> store latency of a fold better than few long ones
 
+constexpr int kFT = 4;      // at most this many tokens per step (readout partials of the fused fold)
+
 __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
   __shared__ __attribute__((aligned(16))) float Vs[W * kFPV];
   __shared__ __attribute__((aligned(16))) float Ks[(kFR / 32) * W * kFPK];
+  __shared__ float Qs[kFT * kFR];  // q_t of this workgroup's rows (fold + readout: a.ypart != nullptr)
   const int DH = a.DH, NH = a.NH;
   const int nsl = DH / kFC;
   int wid = blockIdx.x;
@@ -95,6 +98,20 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
   const float* wkb = a.wk + (((int64_t)b * NH + h) * W) * DH + row0;
   const float* wvb = a.wv + (((int64_t)b * NH + h) * W) * DH + slice * kFC;
   const float* cfb = a.coef_in + ((int64_t)b * NH + h) * W;
+  const bool readout = a.ypart != nullptr;
+  if (readout && tid < a.T * kFR) {  // this step's q_t for the workgroup's 64 rows (the step's front end has run)
+    const int t = tid / kFR, r = tid % kFR;
+    const int ch = h * DH + row0 + r, inner = NH * DH;
+    float qv;
+    if (a.lean_wq != nullptr) {  // lean front end: q rebuilt from the conv branch with the block-diagonal 4 x 4 weights
+      const float4 xa = *reinterpret_cast<const float4*>(a.lean_xa + ((int64_t)b * a.T + t) * inner + (ch & ~3));
+      const float* wq = a.lean_wq + (int64_t)ch * 4;
+      qv = wq[0] * xa.x + wq[1] * xa.y + wq[2] * xa.z + wq[3] * xa.w;
+    } else {
+      qv = a.q[((int64_t)b * a.T + t) * inner + ch];
+    }
+    Qs[t * kFR + r] = qv;
+  }
   // every global load of the workgroup is issued before the first use: one memory round trip, not one per phase
   float* cp0 = Cg + (int64_t)(row0 + 4 * lh) * DH + 32 * w + li;
   float cold[kFR / 32][16];
@@ -140,6 +157,9 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
     }
   }
   __syncthreads();
+  float yp[kFT];
+#pragma unroll
+  for (int x = 0; x < kFT; ++x) yp[x] = 0.f;
 #pragma unroll
   for (int t = 0; t < kFR / 32; ++t) {
     f32x16 acc;
@@ -155,6 +175,27 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) cp0[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * DH] = acc[r];
+    if (readout) {  // q_t . (this lane's 16 rows of the NEW tile): column 32 w + li, rows 32 t + acc_row(r, lh)
+#pragma unroll
+      for (int x = 0; x < kFT; ++x) {
+        if (x < a.T) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) yp[x] += Qs[x * kFR + 32 * t + acc_row(r, lh)] * acc[r];
+        }
+      }
+    }
+  }
+  if (readout) {
+    // the two lane halves hold different rows of the same column; one partial per (env, head, row split, token, column),
+    // summed in fixed order by the read pass: deterministic, no atomics
+    float* yo = a.ypart + ((((int64_t)b * NH + h) * nrs + rsplit) * a.T) * DH + slice * kFC + 32 * w + li;
+#pragma unroll
+    for (int x = 0; x < kFT; ++x) {
+      if (x < a.T) {
+        const float v = yp[x] + __shfl_xor(yp[x], 32, 64);
+        if (lh == 0) yo[(int64_t)x * DH] = v;
+      }
+    }
   }
 }
 
@@ -469,7 +510,8 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = (v4f)(0.f);
   const float* Cb = a.C + (((int64_t)b * NH + h) * DH) * DH + col0;
-  if (!lv.zero) {  // (after a restart C_base holds nothing until the env's next fold)
+  const bool from_fold = lv.fold && a.ypart != nullptr;  // q . C_base comes from the fold kernel's partial readouts
+  if (!lv.zero && !from_fold) {  // (after a restart C_base holds nothing until the env's next fold)
     for (int r0 = rg; r0 < DH; r0 += RP * UNR) {
       v4f c[UNR];
 #pragma unroll
@@ -504,6 +546,11 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       float y = 0.f;
 #pragma unroll
       for (int g = 0; g < RP; ++g) y += red[(g * T + t) * CW + c];
+      if (from_fold) {
+        const int nrs = DH / kFR;
+        const float* yi = a.ypart + ((((int64_t)b * NH + h) * nrs) * T + t) * DH + slice * CW + c;
+        for (int g = 0; g < nrs; ++g) y += yi[(int64_t)g * T * DH];
+      }
       hn[t] = G[t] * y;
     }
 #pragma unroll
@@ -686,6 +733,7 @@ bool mlstm_lazy_supported(int DH, int T) { return DH % 128 == 0 && T >= 1 && T <
 void launch_mlstm_lazy_fold(const MlstmLazyArgs& a_in, hipStream_t stream) {
   MlstmLazyArgs a = a_in;
   LRAM_REQUIRE(a.DH % kFC == 0 && a.DH % kFR == 0, "lazy mLSTM: head dim must be a multiple of 128");
+  LRAM_REQUIRE(a.ypart == nullptr || (a.T >= 1 && a.T <= kFT), "lazy mLSTM: fold + readout takes 1..4 tokens per step");
   long envs = a.B;
   if (a.compact) {
     a.first = (a.period - a.phase % a.period) % a.period;  // smallest b with (phase + b) % period == 0
