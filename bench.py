@@ -45,6 +45,15 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 LAZY_PERIOD = 13        # engine default fold period (lram_set_state_mode)
 
 
+GEMM_KINDS = {   # LRAM_GEMM (engine.hip::finalize); every kind is fp32-accurate, checked against fp64 in tests/
+    "f16x2": "as fp32-accurate 2-way f16-split products on the f16 matrix cores (f16x2: rows scaled by a power of two, "
+             "3 MFMA products per fp32 product)",
+    "bf16x3": "as fp32-accurate 3-way bf16-split products on the bf16 matrix cores (bf16x3: 6 MFMA products per fp32 product)",
+    "f32": "on the exact fp32 MFMA (k-ordered fma chain)",
+}
+MFMA_PEAK_PFLOPS = 2.5   # dense f16 / bf16 matrix-core peak of MI355X (MI355X_MICROARCH.md; the 2:1-sparsity figure is not used)
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -291,6 +300,8 @@ def main(argv=None, engine_factory=None, device=None):
         if on_gpu:
             torch.cuda.synchronize()
 
+    gemm_kind = os.environ.get("LRAM_GEMM", "f16x2")
+    gemm_kind = gemm_kind if gemm_kind in GEMM_KINDS else "f16x2"
     spec = preset(args.config)
     sd = init_state_dict(spec, seed=0, with_image_encoder=args.obs == "image") if not stub else None
     B, T, K, W = args.batch, spec.tokens_per_step, args.steps, args.warmup
@@ -388,11 +399,10 @@ def main(argv=None, engine_factory=None, device=None):
         "scaling": "strong" if args.global_batch > 0 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"{args.config}: xLSTM[7:1] 16M rollout, {B} env slots per GPU, 3 tokens/timestep, "
                                 "cheetah-run-shaped obs (17 of 204 dims), continuous 8x274 head; fp32 state and "
-                                "accumulation, dense projections as fp32-accurate 3-way bf16-split products on the bf16 "
-                                "matrix cores (bf16x3)"
+                                f"accumulation, dense projections {GEMM_KINDS[gemm_kind]}"
                                 if args.config == "xlstm_16m" and args.obs == "state"
                                 else f"{args.config}, {B} env slots per GPU, {args.obs} observations; fp32 state, "
-                                     "bf16x3 projections"),
+                                     f"projections {GEMM_KINDS[gemm_kind]}"),
                    "batch_per_gpu": B, "global_batch": global_batch, "tokens_per_step": T,
                    "state_bytes_per_env": spec.state_bytes_per_env(), "parallelism": f"env-shard x{world}",
                    "graph": bool(args.graph), "micro_batches": args.micro, "state_mode": state_mode,
@@ -497,7 +507,7 @@ def main(argv=None, engine_factory=None, device=None):
         eng.set_micro_batches(args.micro)
     # HBM bytes per launch come from a separate rocprofv3 --pmc pass (scripts/pmc_pass.sh -> profiles/): a constant
     # read from a committed file, labelled as such
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         pmc_file = os.path.join(ROOT, "profiles", "%s_cell_kernel_hbm_traffic%s.json" % (rnd, "_lazy" if lazy else ""))
         if not os.path.exists(pmc_file):
             continue
@@ -516,6 +526,35 @@ def main(argv=None, engine_factory=None, device=None):
         except Exception:
             pass
     out["roofline"] = roofline
+    if spec.backbone == "mamba":
+        # C3 is projection-bound (report the matrix cores beside the HBM state term).  Issued MFMA work of one
+        # env-step = 2 M N K per projection x the piece products of the split scheme, over the measured step time: a
+        # whole-step average (the projections occupy ~58 % of the device time, profiles/r03_kernel_stats_mamba48m_*), so
+        # the in-kernel rate is higher; the matrix-pipe busy share of the projection kernels themselves comes from a
+        # separate rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES), a constant read from profiles/.
+        rows = B * T
+        di, D, N, R = spec.d_inner, spec.d_model, spec.d_state, spec.dt_rank
+        per_layer = 2.0 * rows * (2 * di * D + (R + 2 * N) * di + di * R + D * di)
+        head = 2.0 * B * spec.act_dim * spec.n_vocab * D
+        products = {"f16x2": 3, "bf16x3": 6, "f32": 1}[gemm_kind]
+        passes = compat["mamba_repeat"] if args.mamba_compat else 1
+        flops = passes * (spec.n_blocks * per_layer + head)
+        issued = flops * products
+        m = {"bound": "mfma", "fp32_equiv_flop_per_step": flops, "mfma_products_per_fp32_product": products,
+             "issued_flop_per_step": issued, "issued_PFLOPs_over_step": issued / (wall / K) / 1e15,
+             "peak": MFMA_PEAK_PFLOPS, "unit": "PFLOP/s", "frac_over_step": issued / (wall / K) / 1e15 / MFMA_PEAK_PFLOPS,
+             "note": "matrix-core work of the projections averaged over the WHOLE env-step (state update, conv, norms "
+                     "included in the time); f32 kind: peak is 0.157 PFLOP/s, frac not comparable"}
+        pmc = os.path.join(ROOT, "profiles", "r03_gemm_mfma_busy.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as fh:
+                    pj = json.load(fh)
+                m["mfma_busy_in_projection_kernels"] = pj.get(gemm_kind)
+                m["mfma_busy_source"] = "profiles/r03_gemm_mfma_busy.json (separate rocprofv3 --pmc pass over scripts/bench_gemm.py)"
+            except Exception:
+                pass
+        out["mfma"] = m
 
     # STREAM-like ceilings on this box, for context (not the roofline peak)
     if not args.no_stream_ceilings:

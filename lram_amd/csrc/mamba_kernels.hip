@@ -9,6 +9,7 @@
 
 namespace lram {
 namespace {
+typedef float v4f_t __attribute__((ext_vector_type(4)));
 
 // conv_state.roll(-1); conv_state[..., -1] = x;  xc = silu(sum_k conv_state[.., k] * w[d, k] + b[d])
 template <int T>
@@ -88,6 +89,28 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
   const int tid = threadIdx.x;
   const int ldx = a.R + 2 * N;
   const int dbase = blockIdx.x * cpb;
+  // the recurrent state and the per-channel constants do not depend on the LDS staging below: request them first, so
+  // their round trip overlaps the staging loads instead of following the barrier (one dependent memory phase fewer)
+  const int qd = tid % Q;
+  const int cl = tid / Q;
+  const int d0 = dbase + cl;
+  const bool active = d0 < di;
+  const int d = active ? d0 : di - 1;
+  const float4 al = *reinterpret_cast<const float4*>(a.A_log + (int64_t)d * N + 4 * qd);
+  const float4 A = make_float4(-expf(al.x), -expf(al.y), -expf(al.z), -expf(al.w));
+  const float Dd = a.Dp[d];
+  float4 s[kSsmEnvs];
+#pragma unroll
+  for (int e = 0; e < kSsmEnvs; ++e) {
+    const int b = b0 + e;
+    const bool rs = e >= ne || (a.reset != nullptr && a.reset[b] != 0);
+    if (rs) {
+      s[e] = f4_zero();
+    } else {  // streamed once per env-step: non-temporal, the projections' operands keep the caches
+      const v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(a.ssm_state + (((int64_t)b * di + d) * Q + qd) * 4));
+      s[e] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  }
   for (int i = tid; i < ne * T * 2 * N; i += 256) {
     const int et = i / (2 * N), j = i - et * 2 * N;     // et = e * T + t
     bc[et / T][et % T][j / N][j % N] = a.xdb[((int64_t)b0 * T + et) * ldx + a.R + j];
@@ -106,21 +129,6 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
     sc[et / T][et % T][w][c] = v;
   }
   __syncthreads();
-  const int qd = tid % Q;
-  const int cl = tid / Q;
-  const int d0 = dbase + cl;
-  const bool active = d0 < di;
-  const int d = active ? d0 : di - 1;
-  const float4 al = *reinterpret_cast<const float4*>(a.A_log + (int64_t)d * N + 4 * qd);
-  const float4 A = make_float4(-expf(al.x), -expf(al.y), -expf(al.z), -expf(al.w));
-  const float Dd = a.Dp[d];
-  float4 s[kSsmEnvs];
-#pragma unroll
-  for (int e = 0; e < kSsmEnvs; ++e) {
-    const int b = b0 + e;
-    const bool rs = e >= ne || (a.reset != nullptr && a.reset[b] != 0);
-    s[e] = rs ? f4_zero() : *reinterpret_cast<const float4*>(a.ssm_state + (((int64_t)b * di + d) * Q + qd) * 4);
-  }
 #pragma unroll
   for (int e = 0; e < kSsmEnvs; ++e) {
     if (e >= ne) break;
@@ -141,7 +149,11 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
       for (int off = 1; off < Q; off <<= 1) y += __shfl_xor(y, off, 64);
       if (qd == 0) yo[e][t][cl] = (y + Dd * x) * sc[e][t][2][cl];
     }
-    if (active) *reinterpret_cast<float4*>(a.ssm_state + (((int64_t)b * di + d) * Q + qd) * 4) = s[e];
+    if (active) {
+      v4f_t v;
+      v.x = s[e].x, v.y = s[e].y, v.z = s[e].z, v.w = s[e].w;
+      __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(a.ssm_state + (((int64_t)b * di + d) * Q + qd) * 4));
+    }
   }
   __syncthreads();
   for (int i = tid; i < ne * T * cpb; i += 256) {

@@ -88,7 +88,13 @@ _lib = None
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", _LIB_NAME)
+    """The in-tree library; LRAM_LIB_VARIANT=<name> picks csrc/_variants/<name>.so instead -- A/B measurements of two
+    builds inside one GPU call (scripts/gpu_ab.sh), never set in tests or by the driver."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    variant = os.environ.get("LRAM_LIB_VARIANT")
+    if variant:
+        return os.path.join(here, "csrc", "_variants", variant + ".so")
+    return os.path.join(here, "csrc", _LIB_NAME)
 
 
 def load_library():
