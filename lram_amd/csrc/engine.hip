@@ -96,6 +96,7 @@ struct lram_engine {
   // f16x2 projection kernel (gemm_f16x2.hip): un-batched weights also get two row-scaled f16 planes + inverse scales;
   // LRAM_GEMM=bf16x3 keeps the three-plane bf16 kernel for them too
   bool use_f16x2 = true;
+  int f16x2_min_rows = 1024;  // LRAM_F16_MIN_ROWS
   struct Split16 {
     uint16_t* planes;  // [2][rows][k] f16
     float* inv;        // [rows] exact inverse of each weight row's power-of-two scale
@@ -721,7 +722,9 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
     g.splitk_ws = e->SK.p + (size_t)slot * lram_engine::kSplitKSlotElems;
     g.splitk_ws_elems = (int64_t)lram_engine::kSplitKSlotElems;
   }
-  if (e->use_f16x2 && !gemm_small_m(g) && g.nb1 * g.nb2 == 1 && g.a3 == nullptr && e->ASCALE.p != nullptr &&
+  // (from 1024 rows: below that a step is launch-bound -- 16M at 32 envs 0.66 ms on bf16x3, 0.83 ms with the f16x2 kernel's
+  // extra row-maximum launches -- and the three-workgroups-per-CU advantage needs a grid that fills the chip)
+  if (e->use_f16x2 && g.m >= e->f16x2_min_rows && g.nb1 * g.nb2 == 1 && g.a3 == nullptr && e->ASCALE.p != nullptr &&
       (size_t)g.m <= e->ascale_rows) {
     auto it = e->split16.upper_bound(g.w);
     if (it != e->split16.begin() && (--it, g.w < it->first + it->second.rows * it->second.k) && (int)it->second.k == g.ldw) {
@@ -1619,6 +1622,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     }
     if (const char* v = std::getenv("LRAM_PERSISTENT")) e->persist_mode = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_PERSIST_WGS")) e->persist_wgs = std::max(8, std::min(256, std::atoi(v)));
+    if (const char* v = std::getenv("LRAM_F16_MIN_ROWS")) e->f16x2_min_rows = std::max(9, std::atoi(v));
     if (const char* v = std::getenv("LRAM_COMPAT_SHARE")) e->compat_share = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_LEAN_FRONT")) e->lean_front = std::atoi(v) != 0;

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
 // saved keep the kernel at 144 VGPRs -- three of its waves then leave room for a projection GEMM's wave on the SIMD).
 // SF: the window scores are reduced BEFORE the pass over C_base (the khat registers are dead while it runs and hold
 // its rows in flight instead) rather than after it.
-template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false>
+template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false, bool EARLY = false>
 __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   constexpr int kRowsPerWave = (WP + T + 3) / 4;
   constexpr int CW = 4 * LPR;
@@ -504,15 +504,38 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
     }
   }
   };
-  if (SF) window_scores();
   const int col0 = slice * CW + 4 * cl;
   v4f acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = (v4f)(0.f);
   const float* Cb = a.C + (((int64_t)b * NH + h) * DH) * DH + col0;
   const bool from_fold = lv.fold && a.ypart != nullptr;  // q . C_base comes from the fold kernel's partial readouts
-  if (!lv.zero && !from_fold) {  // (after a restart C_base holds nothing until the env's next fold)
-    for (int r0 = rg; r0 < DH; r0 += RP * UNR) {
+  const bool stream = !lv.zero && !from_fold;            // (after a restart C_base holds nothing until the env's next fold)
+  // EARLY (scores-first instances): the first UNR rows of C_base are requested before the window scores are reduced, so
+  // the pass does not start with a full memory round trip after them
+  v4f c0[(SF && EARLY) ? UNR : 1];
+  if (SF && EARLY && stream) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int r = rg + u * RP;
+      c0[u] = r < DH ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(Cb + (int64_t)r * DH)) : (v4f)(0.f);
+    }
+  }
+  if (SF) window_scores();
+  if (stream) {
+    int r_begin = rg;
+    if (SF && EARLY) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int r = rg + u * RP;
+        if (r < DH) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) acc[t] += qs[t * DH + r] * c0[u];
+        }
+      }
+      r_begin = rg + RP * UNR;
+    }
+    for (int r0 = r_begin; r0 < DH; r0 += RP * UNR) {
       v4f c[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -641,7 +664,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_clear_kernel(int32_t* count, f
   if (gid == b * NH) count[b] = 0;
 }
 
-template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false>
+template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false, bool EARLY = false>
 void launch_cell_tluk(const MlstmLazyArgs& a, hipStream_t s) {
   constexpr int CW = 4 * LPR, RP = 256 / LPR;
   dim3 grid(a.DH / CW, a.NH, a.B), block(256);
@@ -654,11 +677,11 @@ void launch_cell_tluk(const MlstmLazyArgs& a, hipStream_t s) {
   if (shmem > 48 * 1024) {
     static uint64_t raised = 0;
     if (first_use_on_device(raised)) {
-      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF>),
+      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF, EARLY>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
   }
-  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF>), grid, block, shmem, s, a);
+  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF, EARLY>), grid, block, shmem, s, a);
 }
 
 template <int T>
@@ -688,6 +711,11 @@ void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
     }();
     if (T == 3 && narrow && scores_first) {
       if (unroll == 16) return launch_cell_tluk<T, 64, 16, 4, 36, true>(a, s);
+      static const int early = [] {   // LRAM_LAZY_EARLY (measurement knob): first C_base rows requested before the scores
+        const char* v = std::getenv("LRAM_LAZY_EARLY");
+        return v ? std::atoi(v) : 0;
+      }();
+      if (unroll == 8 && early) return launch_cell_tluk<T, 64, 8, 4, 36, true, true>(a, s);
       if (unroll == 8) return launch_cell_tluk<T, 64, 8, 4, 36, true>(a, s);
       if (unroll == 4) return launch_cell_tluk<T, 64, 4, 4, 36, true>(a, s);
     }

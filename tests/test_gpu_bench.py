@@ -14,7 +14,8 @@ def test_bench_line_contract_and_physical_roofline(hip_lib, capsys):
         assert key in out, key
     assert out["metric"].startswith("env-steps/sec") and out["unit"] == "env-steps/s" and out["dtype"] == "f32"
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["vs_baseline"] is None
-    assert out["config"]["state_mode"] == "lazy" and "bf16x3" in out["config"]["workload"]
+    assert out["config"]["state_mode"] == "lazy" and "f16x2" in out["config"]["workload"]
+    assert out["ranks_seen"] == 1
     assert abs(out["value"] - 512 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
