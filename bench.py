@@ -65,15 +65,20 @@ def cell_bytes_materialised(spec, T):
     return 2 * spec.n_heads * spec.head_dim ** 2 * 4 + T * 4 * spec.inner * 4 + T * spec.n_heads * 16
 
 
-def cell_bytes_lazy(spec, T, period=LAZY_PERIOD):
+def cell_bytes_lazy(spec, T, period=LAZY_PERIOD, r2_model=False):
     """Lazy state pass = mlstm_lazy_cell_kernel + its share of mlstm_lazy_fold_kernel:
-    C_base read once; the pending window's V rows (steady-state mean T (period - 1) / 2 tokens); q, v read, h written,
-    the step's khat / v rows appended; score rows; plus 1/period of a fold (C_base read + written, the whole window's
-    khat and v rows read)."""
+    C_base read once; the pending window (steady-state mean T (period - 1) / 2 tokens): its V rows for the window
+    attention and -- head dims whose read pass computes the window scores itself (128 / 256: one column slice per head) --
+    its khat rows for q . khat_j; q, v read, h written, the step's khat / v rows appended; plus 1/period of a fold (C_base
+    read + written, the whole window's khat and v rows read).
+    r2_model: the figure rounds 1-2 reported, which left the khat rows out (it dated from the separate score kernel and
+    counted that kernel's 3 KB of score rows instead); kept beside the corrected one for continuity."""
     nh, dh, inner = spec.n_heads, spec.head_dim, spec.inner
     c = nh * dh * dh * 4
     mean_pending = T * (period - 1) / 2.0
-    read_pass = c + mean_pending * inner * 4 + 3 * T * inner * 4 + 2 * T * inner * 4 + T * nh * 64 * 4
+    fused_scores = dh in (128, 256) and not r2_model
+    window = mean_pending * inner * 4 * (2 if fused_scores else 1)
+    read_pass = c + window + 3 * T * inner * 4 + 2 * T * inner * 4 + (0 if fused_scores else T * nh * 64 * 4)
     fold = 2 * c + 2 * T * period * inner * 4
     return read_pass + fold / period
 
@@ -488,6 +493,13 @@ def main(argv=None, engine_factory=None, device=None):
     if kern_n > 0:
         fill(roofline, kern_ms, kern_n, fold_ms, fold_n, K, B)
         roofline["kernel_share_of_step"] = (kern_ms + fold_ms) / (wall * 1e3)
+    if lazy and roofline.get("avg_launch_ms"):
+        r2 = cell_bytes_lazy(spec, T, r2_model=True)
+        roofline["frac_round2_byte_model"] = r2 * roofline["envs_per_launch"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        roofline["byte_model_note"] = ("round 3 counts the pending window's khat rows the fused read pass loads for the scores "
+                                       "(mean %d B per env and launch) and no longer the separate score kernel's 3 KB of score "
+                                       "rows; `frac_round2_byte_model` is the same measurement priced with rounds 1-2's bytes"
+                                       % int(T * (LAZY_PERIOD - 1) / 2.0 * spec.inner * 4))
     if lazy:
         roofline["note"] = ("lazy matrix memory: `achieved` / `frac` price the bytes the lazy state pass has to move (C_base "
                             "read once, window rows, q / v / h, 1/13 of a fold's read + write of C_base) against the measured "

@@ -17,6 +17,9 @@ SHAPES = [  # (tag, M, N, K)
     ("mamba_dt", 6144, 1536, 48),
     ("206m_up", 1536, 5120, 1280), ("206m_down", 1536, 1280, 2560),
     ("16m_up_b4096", 12288, 2048, 512), ("prefill_up", 12288 * 2, 2048, 512),
+    # Mamba-48M at 2048 envs runs two slices of 1024 envs: 3072 rows per projection launch
+    ("mamba_in_s", 3072, 3072, 768), ("mamba_out_s", 3072, 768, 1536), ("mamba_x_s", 3072, 80, 1536),
+    ("mamba_dt_s", 3072, 1536, 48),
 ]
 REPS = 5
 
