@@ -724,7 +724,10 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
   }
   // (from 1024 rows: below that a step is launch-bound -- 16M at 32 envs 0.66 ms on bf16x3, 0.83 ms with the f16x2 kernel's
   // extra row-maximum launches -- and the three-workgroups-per-CU advantage needs a grid that fills the chip)
-  if (e->use_f16x2 && g.m >= e->f16x2_min_rows && g.nb1 * g.nb2 == 1 && g.a3 == nullptr && e->ASCALE.p != nullptr &&
+  // (wide weights -- the 206M stack's 5120 x 1280 / 1280 x 2560 -- pay from 512 rows: 206M at 512 slots runs 768-row slices,
+  // 28.1k env-steps/s on bf16x3 vs 29.5k on f16x2)
+  const bool f16_rows = g.m >= e->f16x2_min_rows || (g.m >= 512 && (int64_t)g.n * g.k >= 2500000);
+  if (e->use_f16x2 && f16_rows && g.nb1 * g.nb2 == 1 && g.a3 == nullptr && e->ASCALE.p != nullptr &&
       (size_t)g.m <= e->ascale_rows) {
     auto it = e->split16.upper_bound(g.w);
     if (it != e->split16.begin() && (--it, g.w < it->first + it->second.rows * it->second.k) && (int)it->second.k == g.ldw) {
