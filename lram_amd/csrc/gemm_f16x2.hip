@@ -39,15 +39,14 @@ constexpr int kPitchPadded = 40;   // f16 elements per padded LDS row (80 B: con
 
 // BM = 128: 64 x 64 per wave (2 x 2 MFMA tiles).  BM = 64: 32 x 64 per wave.  GATE: the fp32 A operand is multiplied
 // element-wise by g.gate while it is staged (mLSTM output gate); the row scales then are those of the gated rows.
-// ABL (measurement only, results are wrong for ABL != 0): 1 no fp32 -> f16 conversion arithmetic, 2 no global loads in
-// the K loop, 3 no MFMA, 4 no LDS fragment reads in the loop, 5 no LDS writes, 6 no barriers -- the guide's "ablate before
-// optimising" (cdna_hip_programming.md section 7); LRAM_F16_ABL selects one for scripts/bench_gemm.py.
+// (The ablation variants this kernel carried while it was tuned -- no conversion / no loads / no MFMA / no LDS writes / no
+// barriers, profiles/EXPERIMENTS.md -- are in the git history: commit "gemm_f16x2: double-buffered, swizzled-LDS variant".)
 // DB: two LDS stages and two register sets, ONE barrier per K tile: while the matrix cores work on stage s, the same
 // wave converts the next tile (already in registers) into stage s ^ 1 and the tile after that is in flight from
 // memory.  Without it the fp32 -> f16 conversion, the LDS writes and the MFMA block of a workgroup are separated by
 // barriers and overlap only with OTHER workgroups' phases: measured, the MFMA time was simply added on top of the rest
 // (16M proj_up: 66 us with, 52 us without the MFMAs, 15.5 us of pure MFMA time).
-template <bool HAS_BIAS, bool HAS_RES, int BM, bool GATE, int PF, int ABL = 0, bool DB = false>
+template <bool HAS_BIAS, bool HAS_RES, int BM, bool GATE, int PF, bool DB = false>
 __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kernel(GemmArgs g) {
   constexpr int WM = BM / 2;   // rows per wave
   constexpr int TI = WM / 32;  // MFMA row tiles per wave
@@ -147,9 +146,7 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
   // zeroed arithmetically -- rows beyond M carry scale 0, a K tail (K is a multiple of 8, not of 32) zeroes its columns
   // through the scale of the tile / an AND mask on the weight chunks.
   const bool k_tail = (g.k & (BK - 1)) != 0;
-  const int kt0_ = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
   auto load_tile = [&](int set, int k0) {
-    if (ABL == 2 && k0 != kt0_ * BK) return;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int ko = (!k_tail || k0 + lc < g.k) ? k0 : 0;
@@ -177,18 +174,10 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
         hi[e] = h;
         lo[e] = (_Float16)(v - (float)h);
       }
-      if (ABL == 1) {  // raw bits instead of the conversion
-        hi = *reinterpret_cast<const f16x4*>(&ra[set][i].x);
-        lo = *reinterpret_cast<const f16x4*>(&ra[set][i].z);
-      }
       const int arow = lr + 32 * i;
       _Float16* dst = As + buf * STAGE + arow * PITCH + (DB ? ((((lc >> 3) ^ ((arow >> 2) & 3)) << 3) | (lc & 4)) : lc);
-      if (ABL != 5) {
-        *reinterpret_cast<f16x4*>(dst) = hi;
-        *reinterpret_cast<f16x4*>(dst + APLANE) = lo;
-      } else if (hi[0] == (_Float16)12345.f) {
-        *reinterpret_cast<f16x4*>(dst) = lo;
-      }
+      *reinterpret_cast<f16x4*>(dst) = hi;
+      *reinterpret_cast<f16x4*>(dst + APLANE) = lo;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -199,7 +188,7 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
       uint4 v = rw[set][j];
       v.x &= msk, v.y &= msk, v.z &= msk, v.w &= msk;
       const int cs = DB ? (((c >> 3) ^ ((r >> 2) & 3)) << 3) : c;
-      if (ABL != 5 || v.x == 0x12345u) *reinterpret_cast<uint4*>(Bs + buf * STAGE + plane * PLANE + r * PITCH + cs) = v;
+      *reinterpret_cast<uint4*>(Bs + buf * STAGE + plane * PLANE + r * PITCH + cs) = v;
     }
   };
 
@@ -220,18 +209,6 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
   const int nk_all = (g.k + BK - 1) / BK;
   const int kt0 = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
   const int nk = g.split_k > 1 ? min(nk_all, kt0 + g.k_tiles_per_split) : nk_all;
-  f16x8 af0[2][TI][2], bf0[2][2][2];  // ABL == 4: fragments read once
-  if (ABL == 4) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          if (t < TI) af0[ks][t][p] = *reinterpret_cast<const f16x8*>(a_base + p * APLANE + 32 * t * PITCH + 16 * ks);
-          bf0[ks][t][p] = *reinterpret_cast<const f16x8*>(b_base + p * PLANE + 32 * t * PITCH + 16 * ks);
-        }
-  }
   auto mfma_tile = [&]() {
     if (g.mfma_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -241,21 +218,9 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          if (ABL == 4) {
-            if (t < TI) af[t][p] = af0[ks][t][p];
-            bf[t][p] = bf0[ks][t][p];
-            continue;
-          }
           if (t < TI) af[t][p] = *reinterpret_cast<const f16x8*>(a_base + p * APLANE + 32 * t * PITCH + 16 * ks);
           bf[t][p] = *reinterpret_cast<const f16x8*>(b_base + p * PLANE + 32 * t * PITCH + 16 * ks);
         }
-      if (ABL == 3) {  // keep the fragment reads alive without the matrix pipe
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j][0] += (float)af[i][0][0] + (float)af[i][1][1] + (float)bf[j][0][2] + (float)bf[j][1][3];
-        continue;
-      }
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -316,10 +281,10 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
     // with it the wait for that set's loads -- every load would again have to land before the first barrier)
     __builtin_amdgcn_sched_barrier(0);
     store_tile(u, kt * BK);
-    if (ABL != 6) __syncthreads();
+    __syncthreads();
     load_tile(u, min(kt + PF, nk - 1) * BK);
     mfma_tile();
-    if (ABL != 6) __syncthreads();
+    __syncthreads();
   };
   load_tile(0, kt0 * BK);
   if (PF > 1) load_tile(PF - 1, min(kt0 + 1, nk - 1) * BK);
@@ -441,22 +406,6 @@ static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     const char* v = std::getenv("LRAM_F16_PF");
     return v ? std::atoi(v) : 1;
   }();
-  static const int abl = [] {
-    const char* v = std::getenv("LRAM_F16_ABL");
-    return v ? std::atoi(v) : 0;
-  }();
-  if (abl != 0 && BM == 128 && !GATE) {
-    dim3 block(256);
-    switch (abl) {
-      case 1: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 1>), grid, block, 0, stream, g); return;
-      case 2: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 2>), grid, block, 0, stream, g); return;
-      case 3: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 3>), grid, block, 0, stream, g); return;
-      case 4: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 4>), grid, block, 0, stream, g); return;
-      case 5: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 5>), grid, block, 0, stream, g); return;
-      case 6: hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, 128, false, 1, 6>), grid, block, 0, stream, g); return;
-      default: break;
-    }
-  }
   // Two LDS stages + one barrier per K tile (the kernel's DB note) pay where the launch cannot fill the chip with
   // workgroups anyway -- at most one per CU: 206M proj_down (240 workgroups) 109 -> 86 us -- and lose where three
   // single-stage workgroups per CU can overlap each other's phases (16M proj_up 62 -> 75 us, Mamba in_proj 128 -> 140).
@@ -471,13 +420,13 @@ static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
     dim3 block(256);
     if (hb && hr)
-      hipLaunchKernelGGL((gemm_f16x2_kernel<true, true, BM, false, 2, 0, true>), grid, block, 0, stream, g);
+      hipLaunchKernelGGL((gemm_f16x2_kernel<true, true, BM, false, 2, true>), grid, block, 0, stream, g);
     else if (hb)
-      hipLaunchKernelGGL((gemm_f16x2_kernel<true, false, BM, false, 2, 0, true>), grid, block, 0, stream, g);
+      hipLaunchKernelGGL((gemm_f16x2_kernel<true, false, BM, false, 2, true>), grid, block, 0, stream, g);
     else if (hr)
-      hipLaunchKernelGGL((gemm_f16x2_kernel<false, true, BM, false, 2, 0, true>), grid, block, 0, stream, g);
+      hipLaunchKernelGGL((gemm_f16x2_kernel<false, true, BM, false, 2, true>), grid, block, 0, stream, g);
     else
-      hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, BM, false, 2, 0, true>), grid, block, 0, stream, g);
+      hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, BM, false, 2, true>), grid, block, 0, stream, g);
     return;
   }
   if (pf == 2)
