@@ -259,6 +259,17 @@ def test_mamba_48m_shapes(hip_lib):
     assert _run_parity("mamba_48m", B=6, steps=4) == 0
 
 
+@pytest.mark.parametrize("kind", ["f16x2", "bf16x3", "f32"])
+@pytest.mark.parametrize("name,B,steps", [("xlstm_16m", 12, 4), ("mamba_48m", 6, 4)])
+def test_every_projection_kernel_kind_meets_the_parity_bars(hip_lib, monkeypatch, kind, name, B, steps):
+    """LRAM_GEMM selects the projection kernel at lram_finalize.  The dispatcher keeps bf16x3 below 1024 operand rows, so at
+    oracle-sized batches the default build would never run f16x2: LRAM_F16_MIN_ROWS=9 forces it here (its K tails, split-K,
+    producer-handed row maxima and the standalone row-maximum launch included), and the two alternatives stay covered."""
+    monkeypatch.setenv("LRAM_GEMM", kind)
+    monkeypatch.setenv("LRAM_F16_MIN_ROWS", "9")
+    assert _run_parity(name, B=B, steps=steps) == 0
+
+
 def test_discrete_head_bit_exact(hip_lib):
     assert _run_parity("xlstm_tiny", B=16, steps=8, seed=3, discrete=True) == 0
 
