@@ -130,3 +130,29 @@ def test_compat_mode_is_rejected_on_xlstm(hip_lib):
     eng.close()
     with pytest.raises(ValueError):
         RecurrentAgent(spec, sd, n_envs=1, device="cuda:0", compat_mamba_repeat=True)
+
+
+def test_shared_repeated_forwards_equal_the_unshared_ones(hip_lib, monkeypatch):
+    """LRAM_COMPAT_SHARE (default on): the repeated forwards of the reference-trajectory mode share the token front end and
+    layer 0's norm + in_proj and evaluate only the head columns a pass needs.  Same actions and the same final state as
+    recomputing everything in every pass (Mamba-48M shapes, random resets, 4 forwards per env-step)."""
+    from lram_amd.engine import Engine
+    spec = preset("mamba_48m")
+    sd = init_state_dict(spec, seed=3)
+    B, R = 9, 4
+    seq = make_inputs(spec, B, 6, seed=77, reset_prob=0.2)
+    outs = {}
+    for share in ("1", "0"):
+        monkeypatch.setenv("LRAM_COMPAT_SHARE", share)
+        eng = Engine(spec, sd, B, device="cuda:0")
+        eng.set_compat_mode(R, True)
+        acts = []
+        for obs, rtg, rew, mask in seq:
+            a, _ = eng.step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+            acts.append(a.clone())
+        torch.cuda.synchronize()
+        outs[share] = (torch.stack(acts), eng.export_state_tensor(spec.n_blocks - 1, 0).clone(), eng.export_state_tensor(0, 0).clone())
+        eng.close()
+    monkeypatch.delenv("LRAM_COMPAT_SHARE")
+    assert float((outs["1"][0][..., :R] - outs["0"][0][..., :R]).abs().max()) <= 1e-4
+    assert rel_err(outs["1"][1], outs["0"][1]) < 1e-5 and rel_err(outs["1"][2], outs["0"][2]) < 1e-5
