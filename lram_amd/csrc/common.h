@@ -348,7 +348,10 @@ struct MambaSsmArgs {
   uint16_t* y3 = nullptr;   // y as a bf16x3 GEMM operand: three planes [B*T, d_inner], y3_plane elements apart
   int64_t y3_plane = 0;
   float* amax = nullptr;    // optional [B*T][d_inner / 64]: per-64-channel partial row maxima of y (f16x2 GEMM's a_amax)
+  const float* dt_wt = nullptr;  // optional dt_proj.weight TRANSPOSED [R, d_inner]: dt_proj evaluated inside the kernel, dtp unused
 };
+inline bool mamba_ssm_dt_fusable(int N, int R) { return N == 16 && R >= 1 && R <= 128; }
+void launch_transpose_f32(const float* src, int rows, int cols, float* dst, hipStream_t stream);
 void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

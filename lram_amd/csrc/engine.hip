@@ -103,6 +103,7 @@ struct lram_engine {
     size_t rows, k;
   };
   std::map<const float*, Split16> split16;
+  std::vector<DevBuf> dt_wt;   // Mamba: dt_proj.weight transposed to [dt_rank, d_inner] per block (state-update kernel's operand)
   DevBuf ASCALE;  // per-row maxima of a GEMM's A operand computed by launch_row_amax, one region per stream slot (like
   size_t ascale_rows = 0;  // the split-K slabs)
   // row maxima handed over by the kernels that produce the projections' operands, indexed like the rows of X:
@@ -128,6 +129,7 @@ struct lram_engine {
   bool lazy_ready = false;  // buffers allocated for the current batch
   int lazy_period = 13;
   bool lean_front = true;   // LRAM_LEAN_FRONT=0
+  bool mamba_dt_fuse = true;  // LRAM_MAMBA_DT_FUSE: dt_proj inside the selective-state-update kernel (d_state 16, dt_rank <= 64)
   int gn_fuse = 2;          // LRAM_GN_FUSE: output group norm + skip in the read pass's epilogue, gate in proj_down's
                             // operand staging.  0 off, 1 on, 2 auto = on from 2048 env slots (round 3, same box, two
                             // rounds: 391.1k / 393.5k off vs 395.8k / 397.5k on at 4096 slots; 1024 slots: -0.4 %)
@@ -236,6 +238,8 @@ struct lram_engine {
     split.clear();
     for (auto& kv : split16) (void)hipFree(kv.second.planes), (void)hipFree(kv.second.inv);
     split16.clear();
+    for (DevBuf& b : dt_wt) b.release();
+    dt_wt.clear();
   }
   void drop_graph() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -478,6 +482,14 @@ void finalize(lram_engine* e) {
         ws.push_back(p);
     for (const float* p : ws)
       if (p != nullptr) make_split(e, p, numel(p));
+    LRAM_HIP_CHECK(hipDeviceSynchronize());
+  }
+  e->dt_wt.assign(e->bw.size(), DevBuf());
+  if (c.backbone == LRAM_BACKBONE_MAMBA && e->mamba_dt_fuse && mamba_ssm_dt_fusable(c.d_state, c.dt_rank)) {
+    for (size_t i = 0; i < e->bw.size(); ++i) {
+      e->dt_wt[i].alloc((size_t)c.d_inner * c.dt_rank);
+      launch_transpose_f32(e->bw[i].dt_proj, c.d_inner, c.dt_rank, e->dt_wt[i].p, nullptr);
+    }
     LRAM_HIP_CHECK(hipDeviceSynchronize());
   }
   e->finalized = true;
@@ -1248,6 +1260,8 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   // wave per row), the conv and the state-update kernels one partial maximum per wave (d_inner / 64 per row, plain
   // stores; the GEMM's prologue takes their maximum).  Atomic maxima were measured first: +20 us on the conv launch,
   // +13 us on the state update (147k single-lane atomics per launch), as much as the row-maximum launches they replaced.
+  // dt_proj (K = dt_rank) inside the state-update kernel instead of a GEMM launch + its [rows, d_inner] round trip
+  const bool dt_fused = e->mamba_dt_fuse && mamba_ssm_dt_fusable(N, R) && e->dt_wt[i].p != nullptr;
   const bool amx = e->use_f16x2 && di % 64 == 0 && N == 16 && T <= 4;
   const int parts = di / 64;
   float* amx_xn = amx ? e->AMX_XN.p + r0 : nullptr;
@@ -1266,6 +1280,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     sa.ssm_state = st.s0.p + b0 * di * N, sa.xc = XA, sa.dtp = DTP, sa.dt_bias = w.dt_bias, sa.xdb = Q;
     sa.A_log = w.A_log, sa.Dp = w.Dp, sa.xz = U, sa.y = H, sa.reset = rs;
     sa.B = sl.nb, sa.T = T, sa.d_inner = di, sa.N = N, sa.R = R, sa.amax = amx_h;
+    if (dt_fused) sa.dt_wt = e->dt_wt[i].p, sa.dtp = nullptr;
     if (a3_out) sa.y = nullptr, sa.y3 = e->G3 + r0 * di, sa.y3_plane = (int64_t)e->g3_plane;
     prof_record(e, sl.s, true);
     launch_mamba_ssm(sa, sl.s);
@@ -1282,10 +1297,12 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     xp.a = XA, xp.lda = di, xp.w = w.x_proj, xp.ldw = di, xp.c = Q, xp.ldc = ldx;
     xp.m = rows, xp.n = ldx, xp.k = di, xp.a_amax = amx_xa, xp.amax_parts = amx ? parts : 1;
     gemm(e, xp, gs);
-    GemmArgs dp;
-    dp.a = Q, dp.lda = ldx, dp.w = w.dt_proj, dp.ldw = R, dp.c = DTP, dp.ldc = di;
-    dp.m = rows, dp.n = di, dp.k = R;
-    gemm(e, dp, gs);
+    if (!dt_fused) {
+      GemmArgs dp;
+      dp.a = Q, dp.lda = ldx, dp.w = w.dt_proj, dp.ldw = R, dp.c = DTP, dp.ldc = di;
+      dp.m = rows, dp.n = di, dp.k = R;
+      gemm(e, dp, gs);
+    }
   } else {
     GemmArgs op;
     op.a = H, op.lda = di, op.w = w.out_proj, op.ldw = di, op.c = X, op.ldc = D, op.bias = w.out_proj_b;
@@ -1627,6 +1644,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_PERSIST_WGS")) e->persist_wgs = std::max(8, std::min(256, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_F16_MIN_ROWS")) e->f16x2_min_rows = std::max(9, std::atoi(v));
     if (const char* v = std::getenv("LRAM_COMPAT_SHARE")) e->compat_share = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_MAMBA_DT_FUSE")) e->mamba_dt_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_LEAN_FRONT")) e->lean_front = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_A3")) e->use_a3 = std::atoi(v) != 0;

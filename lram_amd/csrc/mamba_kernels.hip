@@ -69,6 +69,14 @@ __global__ __launch_bounds__(256) void mamba_conv_rt_kernel(MambaConvArgs a) {
   *reinterpret_cast<float4*>(a.conv_state + gid * 4) = win;
 }
 
+// dst[c][r] = src[r][c] (finalize-time helper: small weight matrices only)
+__global__ void transpose_f32_kernel(const float* src, int rows, int cols, float* dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  dst[(int64_t)c * rows + r] = src[i];
+}
+
 // kSsmEnvs envs per workgroup (4 for an env-step: amortises A = -exp(A_log) and keeps 4 state loads in flight
 // per lane; 1 for the long prefill chunks, whose LDS staging grows with T)
 
@@ -111,12 +119,44 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
       s[e] = make_float4(v.x, v.y, v.z, v.w);
     }
   }
+  // dt_wt given (launcher: N = 16, so 64 channels = 64 lanes per wave): dt_proj is evaluated here, exact fp32 -- 64 channels
+  // x <= 16 rows x dt_rank MACs per workgroup -- instead of a [rows, d_inner] GEMM launch plus a write and a read of its
+  // output.  Wave g takes rows g, g + 4, ...: the raw dt row (x_proj's first dt_rank columns) has a wave-uniform address,
+  // the weights are the transposed copy [dt_rank, d_inner] (lane = channel: 256-byte rows); nothing here waits for LDS, so
+  // these loads are in flight with the state's.
+  const bool fuse_dt = a.dt_wt != nullptr;
+  if (fuse_dt) {
+    constexpr int kRows = (kSsmEnvs * T + 3) / 4;
+    const int c = tid & 63, g = __builtin_amdgcn_readfirstlane(tid >> 6), nrow = ne * T;
+    const int dch = min(dbase + c, di - 1);
+    const float* __restrict__ wt = a.dt_wt + dch;
+    const float* __restrict__ xr[kRows];
+    float acc[kRows];
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+      acc[i] = 0.f;
+      xr[i] = a.xdb + ((int64_t)b0 * T + min(g + 4 * i, nrow - 1)) * ldx;
+    }
+#pragma unroll 8
+    for (int r = 0; r < a.R; ++r) {
+      const float wv = wt[(int64_t)r * di];
+#pragma unroll
+      for (int i = 0; i < kRows; ++i) acc[i] += wv * xr[i][r];
+    }
+    const float bias = a.dt_bias[dch];
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+      const int et = g + 4 * i;
+      if (et < nrow) sc[et / T][et % T][1][c] = softplus_f(acc[i] + bias);
+    }
+  }
   for (int i = tid; i < ne * T * 2 * N; i += 256) {
     const int et = i / (2 * N), j = i - et * 2 * N;     // et = e * T + t
     bc[et / T][et % T][j / N][j % N] = a.xdb[((int64_t)b0 * T + et) * ldx + a.R + j];
   }
   for (int i = tid; i < ne * T * 3 * cpb; i += 256) {
     const int c = i % cpb, w = (i / cpb) % 3, et = i / (3 * cpb);
+    if (fuse_dt && w == 1) continue;
     const int d = min(dbase + c, di - 1);
     const int64_t row = (int64_t)b0 * T + et;
     float v;
@@ -175,6 +215,12 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
 
 }  // namespace
 
+void launch_transpose_f32(const float* src, int rows, int cols, float* dst, hipStream_t stream) {
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, rows, cols, dst);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
 void launch_mamba_conv(const MambaConvArgs& a, hipStream_t stream) {
   LRAM_REQUIRE(a.K == 4, "Mamba d_conv must be 4");
   const int64_t n = (int64_t)a.B * a.d_inner;
@@ -196,6 +242,8 @@ void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream) {
   LRAM_REQUIRE(a.N % 4 == 0 && Q >= 1 && Q <= 16 && (Q & (Q - 1)) == 0, "Mamba d_state must be 4 * 2^k, <= 64");
   const int cpb = 256 / Q;
   const unsigned gx = (unsigned)((a.d_inner + cpb - 1) / cpb);
+  LRAM_REQUIRE(a.dt_wt == nullptr || mamba_ssm_dt_fusable(a.N, a.R), "fused dt_proj needs d_state 16 and dt_rank <= 128");
+  LRAM_REQUIRE(a.dt_wt != nullptr || a.dtp != nullptr, "selective state update needs dtp or dt_w");
   dim3 block(256);
   dim3 g4(gx, (unsigned)((a.B + 3) / 4)), g1(gx, (unsigned)a.B);
   switch (a.T) {

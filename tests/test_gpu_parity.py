@@ -259,6 +259,40 @@ def test_mamba_48m_shapes(hip_lib):
     assert _run_parity("mamba_48m", B=6, steps=4) == 0
 
 
+@pytest.mark.parametrize("name,B", [("mamba_48m", 6), ("mamba_tiny", 7)])
+def test_mamba_dt_proj_as_its_own_gemm_stays_correct(hip_lib, monkeypatch, name, B):
+    """Default: dt_proj (K = dt_rank) is evaluated inside the selective-state-update kernel (d_state 16, dt_rank <= 64; every
+    other Mamba test runs that).  LRAM_MAMBA_DT_FUSE=0 keeps it a projection launch -- the path wider presets (dt_rank 112)
+    take: same parity bars, and the two agree step by step and after a 9-timestep prefill (12-token state passes)."""
+    from lram_amd.engine import Engine
+    monkeypatch.setenv("LRAM_MAMBA_DT_FUSE", "0")
+    assert _run_parity(name, B=B, steps=4) == 0
+    spec = preset(name)
+    sd = init_state_dict(spec, seed=5)
+    seq = make_inputs(spec, B, 9, seed=11, reset_prob=0.15)
+    engines = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("LRAM_MAMBA_DT_FUSE", fuse)
+        engines[fuse] = Engine(spec, sd, B, device="cuda:0")
+    for obs, rtg, rew, mask in seq:
+        a0, _ = engines["0"].step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+        a1, _ = engines["1"].step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+        assert float((a0 - a1).abs().max()) <= 1e-4
+    obs_seq = torch.stack([x[0] for x in seq], 1).contiguous().cuda()
+    rtg_seq = torch.stack([x[1] for x in seq], 1).contiguous().cuda()
+    rew_seq = torch.stack([x[2] for x in seq], 1).contiguous().cuda()
+    ones = torch.ones(B, dtype=torch.uint8).cuda()
+    p0, _ = engines["0"].prefill(obs_seq, rtg_seq, rew_seq, reset_mask=ones)
+    p1, _ = engines["1"].prefill(obs_seq, rtg_seq, rew_seq, reset_mask=ones)
+    torch.cuda.synchronize()
+    assert float((p0 - p1).abs().max()) <= 1e-4
+    for blk in (0, spec.n_blocks - 1):
+        for which in (0, 3):
+            assert rel_err(engines["0"].export_state_tensor(blk, which), engines["1"].export_state_tensor(blk, which)) < 1e-5
+    for e in engines.values():
+        e.close()
+
+
 @pytest.mark.parametrize("kind", ["f16x2", "bf16x3", "f32"])
 @pytest.mark.parametrize("name,B,steps", [("xlstm_16m", 12, 4), ("mamba_48m", 6, 4)])
 def test_every_projection_kernel_kind_meets_the_parity_bars(hip_lib, monkeypatch, kind, name, B, steps):
