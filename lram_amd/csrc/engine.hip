@@ -855,7 +855,7 @@ hipEvent_t record_on(lram_engine* e, hipStream_t src) {
 std::vector<Slice> make_slices(lram_engine* e, hipStream_t s, hipStream_t* hbm) {
   int n = e->n_micro;
   if (n == 0) n = e->B >= 512 ? 2 : 1;  // auto
-  if (e->cfg.backbone == LRAM_BACKBONE_MAMBA) n = std::min(n, 2);  // the Mamba schedule is written for two slices
+  if (e->cfg.backbone == LRAM_BACKBONE_MAMBA && e->n_micro == 0) n = std::min(n, 2);
   if (e->graph_mode) n = 1;  // graph replay targets small, launch-bound batches: one slice, one stream
   n = std::max(1, std::min(n, std::min(e->B, 8)));
   *hbm = s;
@@ -1321,14 +1321,10 @@ void run_mamba_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   const lram_config& c = e->cfg;
   const int D = c.d_model;
   const int n_stages = 3 * c.n_blocks;
-  if (sl.size() == 1) {
-    for (int k = 0; k < n_stages; ++k) mamba_stage(e, k / 3, k % 3, T, reset, sl[0]);
-  } else {
-    for (int k = 0; k <= n_stages; ++k) {
-      if (k < n_stages) mamba_stage(e, k / 3, k % 3, T, reset, sl[0]);
-      if (k > 0) mamba_stage(e, (k - 1) / 3, (k - 1) % 3, T, reset, sl[1]);
-    }
-  }
+  const int ns = (int)sl.size();
+  for (int k = 0; k < n_stages + ns - 1; ++k)   // slice j is enqueued j stages behind slice 0
+    for (int j = 0; j < ns; ++j)
+      if (k - j >= 0 && k - j < n_stages) mamba_stage(e, (k - j) / 3, (k - j) % 3, T, reset, sl[j]);
   for (const Slice& x : sl) {
     const size_t r0 = (size_t)x.b0 * T;
     launch_add_rms_norm(e->X.p + r0 * D, e->RES.p + r0 * D, nullptr, e->HID.p + r0 * D, e->post_g, x.nb * T, D,

@@ -312,13 +312,15 @@ def test_graph_replay_matches(hip_lib):
     assert _run_parity("xlstm_tiny", B=8, steps=10, seed=5, graph=True) == 0
 
 
-def test_micro_batch_pipeline_matches_single_slice(hip_lib):
-    """Env slices on separate streams (cell kernels serialised on their own stream) == one slice, eager and under
+@pytest.mark.parametrize("name", ["xlstm_tiny", "mamba_tiny"])
+def test_micro_batch_pipeline_matches_single_slice(hip_lib, name):
+    """Env slices on separate streams (cell kernels serialised on their own stream; Mamba: free-running slices, slice j
+    enqueued j stages behind slice 0) == one slice, eager and under
     hipGraph capture, including ragged splits.  At this tiny batch the per-slice kernel choices (GEMV vs tile GEMM,
     split-K, cell column slicing) differ with the slice size, so equality is to fp32 rounding; at 4096 envs it is
     bit for bit (tests/test_gpu_fullsize.py)."""
     from lram_amd.engine import Engine
-    spec = preset("xlstm_tiny")
+    spec = preset(name)
     sd = init_state_dict(spec, seed=13)
     B = 11
     seq = make_inputs(spec, B, 6, seed=99)
