@@ -570,7 +570,7 @@ def main(argv=None, engine_factory=None, device=None):
 
     # STREAM-like ceilings on this box, for context (not the roofline peak)
     if not args.no_stream_ceilings:
-        from lram_amd.engine import stream_copy, stream_rmw
+        from lram_amd.engine import stream_copy, stream_read, stream_rmw
         n_copy = 256 * 1024 * 1024
         src = torch.empty(n_copy, device=dev)
         dst = torch.empty(n_copy, device=dev)
@@ -589,6 +589,9 @@ def main(argv=None, engine_factory=None, device=None):
         out["hbm_copy_measured_GBps"] = rate(lambda: stream_copy(dst, src))
         # the same bytes as an in-place read-modify-write with the cell kernel's access pattern (no arithmetic)
         out["hbm_rmw_measured_GBps"] = rate(lambda: stream_rmw(src))
+        # half those bytes as a read-only stream with the lazy read pass's access shape (no arithmetic)
+        sink = torch.zeros(1024, device=dev)
+        out["hbm_read_measured_GBps"] = rate(lambda: stream_read(src, sink)) / 2
         del src, dst
     out["algorithmic_bytes_per_env_step"] = 2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim
     out["whole_step_8d_GBps"] = out["algorithmic_bytes_per_env_step"] * value / world / 1e9

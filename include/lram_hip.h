@@ -289,6 +289,12 @@ int32_t lram_selftest_concurrent(int32_t iters, int64_t* n_diff);
 /* STREAM-like device copy (float4), used by bench.py to measure the achievable HBM rate on the box. */
 int32_t lram_stream_copy(float* dev_dst, const float* dev_src, size_t numel, void* stream);
 
+/* Measurement aid: read-only stream over `numel` floats (a multiple of 1 Mi) with the access shape of the lazy mLSTM read
+ * pass (mlstm_lazy.hip: whole 1 KiB rows per wave, several rows in flight per lane, non-temporal loads) and none of its
+ * arithmetic; per-workgroup sums are accumulated into dev_sink (1024 floats).  The practical ceiling for "read the state
+ * once" that bench.py reports beside the read pass's rate. */
+int32_t lram_stream_read(const float* dev_buf, size_t numel, float* dev_sink, void* stream);
+
 /* Measurement aid: in-place read-modify-write stream (x *= 1) over `numel` floats (a multiple of 65536) with the
  * access pattern of the mLSTM cell kernel and none of its arithmetic -- the practical ceiling for "read the state
  * once, write it once" that bench.py reports beside the cell kernel's rate. */

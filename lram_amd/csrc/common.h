@@ -374,6 +374,7 @@ void launch_relu(float* x, int64_t n, hipStream_t stream);
 void launch_pad_obs(const float* native, int n_native, const int32_t* inv_index, const float* mean, const float* stdv,
                     float* out, int B, int state_dim, hipStream_t stream);
 void launch_stream_copy(float* dst, const float* src, size_t numel, hipStream_t stream);
+void launch_stream_read(const float* buf, size_t numel, float* sink, hipStream_t stream);  // read only; sink: 1024 floats
 void launch_stream_rmw(float* buf, size_t numel, hipStream_t stream);  // in place, the cell kernel's access pattern
 void launch_zero_rows(float* buf, const uint8_t* mask, int B, int64_t row_elems, int64_t outer, int64_t outer_stride,
                       hipStream_t stream);

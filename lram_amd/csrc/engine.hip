@@ -2137,6 +2137,10 @@ int32_t lram_stream_copy(float* dev_dst, const float* dev_src, size_t numel, voi
   return guarded([&] { launch_stream_copy(dev_dst, dev_src, numel, static_cast<hipStream_t>(stream)); });
 }
 
+int32_t lram_stream_read(const float* dev_buf, size_t numel, float* dev_sink, void* stream) {
+  return guarded([&] { launch_stream_read(dev_buf, numel, dev_sink, static_cast<hipStream_t>(stream)); });
+}
+
 int32_t lram_stream_rmw(float* dev_buf, size_t numel, void* stream) {
   return guarded([&] { launch_stream_rmw(dev_buf, numel, static_cast<hipStream_t>(stream)); });
 }

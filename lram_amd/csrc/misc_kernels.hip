@@ -337,6 +337,30 @@ void launch_action_argmax(const float* logits, float* actions, int32_t* tokens, 
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
+// Read-only stream with the lazy read pass's access shape and none of its arithmetic: one workgroup per contiguous
+// block of RB rows of 1 KiB (a wave reads whole rows), UNR rows (UNR x 16 B per lane) in flight per thread, non-temporal
+// loads; the lane sums land in one float per workgroup so the loads cannot be dropped.  Its rate is the practical
+// ceiling for "read the state once" on this part.
+template <int UNR>
+__global__ __launch_bounds__(256) void stream_read_kernel(const float* __restrict__ buf, float* __restrict__ sink, int rows_per_wg) {
+  extern __shared__ float pad_lds[];
+  (void)pad_lds;
+  const float* blk = buf + (size_t)blockIdx.x * rows_per_wg * 256;
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  v4f_t acc = {0.f, 0.f, 0.f, 0.f};
+  for (int r0 = rg; r0 < rows_per_wg; r0 += 4 * UNR) {
+    v4f_t c[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+      c[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(blk + (size_t)(r0 + 4 * u) * 256 + 4 * cl));
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) acc += c[u];
+  }
+  float s = acc.x + acc.y + acc.z + acc.w;
+  s = wave_sum(s);
+  if (cl == 0) atomicAdd(sink + (blockIdx.x & 1023), s);
+}
+
 void launch_pad_obs(const float* native, int n_native, const int32_t* inv_index, const float* mean, const float* stdv,
                     float* out, int B, int state_dim, hipStream_t stream) {
   const int64_t n = (int64_t)B * state_dim;
@@ -381,6 +405,27 @@ void launch_stream_rmw(float* buf, size_t numel, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024));
   }
   hipLaunchKernelGGL(stream_rmw_kernel, dim3((unsigned)(numel / 65536)), dim3(256), 84 * 1024, stream, buf, 1.0f);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_stream_read(const float* buf, size_t numel, float* sink, hipStream_t stream) {
+  // LRAM_READ_VARIANT = 100 * rows-in-flight per thread (4 / 8 / 16) + log2(rows per workgroup / 64) (0..4), + 1000 to
+  // request 48 KiB of LDS per workgroup (three workgroups per CU, the read pass's residency); default 1804: 8 rows in
+  // flight, 1 MiB blocks, three workgroups per CU (6.0-6.6 TB/s over the variants on MI355X, profiles/r03_read_ceiling.txt)
+  static const int variant = [] {
+    const char* v = std::getenv("LRAM_READ_VARIANT");
+    return v ? std::atoi(v) : 1804;
+  }();
+  const int unr = (variant % 1000) / 100, lg = variant % 100;
+  const int rows = 64 << std::max(0, std::min(lg, 4));
+  const size_t lds = variant >= 1000 ? 48 * 1024 : 0;
+  LRAM_REQUIRE(numel % ((size_t)rows * 256) == 0 && numel > 0, "stream read: numel must be a positive multiple of the block size");
+  const dim3 grid((unsigned)(numel / ((size_t)rows * 256)));
+  switch (unr) {
+    case 4: hipLaunchKernelGGL(stream_read_kernel<4>, grid, dim3(256), lds, stream, buf, sink, rows); break;
+    case 16: hipLaunchKernelGGL(stream_read_kernel<16>, grid, dim3(256), lds, stream, buf, sink, rows); break;
+    default: hipLaunchKernelGGL(stream_read_kernel<8>, grid, dim3(256), lds, stream, buf, sink, rows); break;
+  }
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

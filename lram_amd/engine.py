@@ -79,6 +79,7 @@ _SYMBOLS = {
     "lram_set_state_mode": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32]),
     "lram_get_state_mode": (ctypes.c_int32, [_VP]),
     "lram_stream_rmw": (ctypes.c_int32, [_VP, ctypes.c_size_t, _VP]),
+    "lram_stream_read": (ctypes.c_int32, [_VP, ctypes.c_size_t, _VP, _VP]),
     "lram_pad_obs": (ctypes.c_int32, [_VP, ctypes.c_int32, _VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_selftest_concurrent": (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]),
     "lram_stream_copy": (ctypes.c_int32, [_VP, _VP, ctypes.c_size_t, _VP]),
@@ -459,6 +460,13 @@ def pad_obs(native: torch.Tensor, state_dim: int, inv_index: Optional[torch.Tens
 def stream_copy(dst: torch.Tensor, src: torch.Tensor):
     lib = load_library()
     _check(lib, lib.lram_stream_copy(_ptr(dst), _ptr(src), src.numel(), _stream_ptr(src.device)))
+
+
+def stream_read(buf: torch.Tensor, sink: torch.Tensor):
+    """Read-only stream with the lazy read pass's access shape (lram_stream_read): the practical HBM ceiling for reading
+    the recurrent state once.  `sink`: 1024 floats on the same device."""
+    lib = load_library()
+    _check(lib, lib.lram_stream_read(_ptr(buf), buf.numel(), _ptr(sink), _stream_ptr(buf.device)))
 
 
 def stream_rmw(buf: torch.Tensor):
