@@ -147,6 +147,7 @@ struct lram_engine {
   DevBuf YPART;  // [B, NH, DH / 64, T, DH]
   int fold_gaps = 0;        // LRAM_FOLD_GAPS=g: the last g mLSTM blocks' folds run just ahead of their own read passes
   int front_stagger = 0;    // LRAM_FRONT_STAGGER=1: in the step's first mLSTM block, slice k's front end waits for slice k-1's
+  bool fold_spread = true;  // LRAM_FOLD_SPREAD: the folds behind the first read passes are shared out over all sLSTM stretches
   int fold_bubbles = 2;     // LRAM_FOLD_BUBBLES=k: k folds before the first read pass, the rest behind the sLSTM block, all
                             // on the state-pass stream (0 = folds on their own stream, one block ahead); measured on one
                             // box: k = 0 364k, 1 367k, 2 368k, 3 367k, 4 366k env-steps/s
@@ -1149,13 +1150,22 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   }
   for (int i = 0; i < c.n_blocks; ++i) {
     if (c.block_is_slstm[i]) {
-      for (const Slice& x : sl) slstm_block(e, i, T, reset, x);
-      if (fold_bubbles > 0) {  // every fold still outstanding runs now, behind the previous block's read passes
-        int left = 0;
+      // (enqueued BEFORE the sLSTM block's ~50 launches: with short kernels the host is only just ahead of the device
+      // there, and folds queued behind them reached the state-pass stream 0.26 ms after it had gone idle -- 206M, 512 slots)
+      if (fold_bubbles > 0) {
+        // the folds still outstanding run behind the previous block's read passes, shared out over this and the later sLSTM
+        // blocks of the stack (206M: three stretches, five folds each, instead of fifteen in the first and none in the
+        // other two); at least the blocks whose read passes come before the next sLSTM block
+        int left = 0, stretches = 0, must = 0;
         for (int k = next_mlstm(i); k >= 0; k = next_mlstm(k)) left += folded[k] ? 0 : 1;
-        for (int k = next_mlstm(i); k >= 0 && left > e->fold_gaps; k = next_mlstm(k))
-          if (!folded[k]) launch_folds_on_hbm(k), --left;
+        for (int k = i; k < c.n_blocks; ++k) stretches += c.block_is_slstm[k] ? 1 : 0;
+        for (int k = i + 1; k < c.n_blocks && !c.block_is_slstm[k]; ++k) must += folded[k] ? 0 : 1;
+        int take = std::max(0, left - e->fold_gaps);
+        if (e->fold_spread && stretches > 1) take = std::max((take + stretches - 1) / stretches, std::min(must, take));
+        for (int k = next_mlstm(i); k >= 0 && take > 0; k = next_mlstm(k))
+          if (!folded[k]) launch_folds_on_hbm(k), --take;
       }
+      for (const Slice& x : sl) slstm_block(e, i, T, reset, x);
       continue;
     }
     if (fold_bubbles > 0) {
@@ -1647,6 +1657,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_SPLIT_UP")) e->split_up = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_BUBBLES")) e->fold_bubbles = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_FOLD_SPREAD")) e->fold_spread = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_FUSED")) e->fold_fused = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_FUSED_STREAM")) e->fold_fused_stream = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_GAPS")) e->fold_gaps = std::max(0, std::atoi(v));
