@@ -220,6 +220,7 @@ struct MlstmLazyArgs {
   int force;              // fold kernel: fold every env that has pending tokens (materialise)
   int compact = 0;        // fold kernel: launch only over the envs whose phase comes up (no window can overflow)
   int first = 0;          // set by the launcher
+  int fold_wmax = 0;      // fold kernel: host-side upper bound of the pending tokens of the envs that fold (0 = unknown)
   int min_lds_bytes = 0;
 };
 void launch_mlstm_lazy_fold(const MlstmLazyArgs& a, hipStream_t stream);

@@ -147,6 +147,8 @@ struct lram_engine {
   DevBuf YPART;  // [B, NH, DH / 64, T, DH]
   int fold_gaps = 0;        // LRAM_FOLD_GAPS=g: the last g mLSTM blocks' folds run just ahead of their own read passes
   int front_stagger = 0;    // LRAM_FRONT_STAGGER=1: in the step's first mLSTM block, slice k's front end waits for slice k-1's
+  int stream_prio = 0;      // LRAM_STREAM_PRIO: 1 slice streams highest / state-pass stream lowest priority, 2 slices highest only,
+                            // 3 the reverse of 1 (measured: see profiles/EXPERIMENTS.md)
   bool fold_spread = true;  // LRAM_FOLD_SPREAD: the folds behind the first read passes are shared out over all sLSTM stretches
   int fold_bubbles = 2;     // LRAM_FOLD_BUBBLES=k: k folds before the first read pass, the rest behind the sLSTM block, all
                             // on the state-pass stream (0 = folds on their own stream, one block ahead); measured on one
@@ -154,6 +156,7 @@ struct lram_engine {
   bool fold_ahead = false;  // LRAM_FOLD_AHEAD=1: every fold queued at the step start (measured: no gain over one block ahead)
   int64_t lazy_step = 0;    // steps taken in lazy mode: fold phase and ping-pong parity
   std::vector<int> lazy_bound;  // host-side upper bound of pending tokens per fold class (b % period)
+  int lazy_due_bound = 0;       // lazy_bound of the class that folds this step, before it is cleared
   bool lazy_compact = false;    // this step's fold launches may use the compact grid (no window can overflow)
   bool lazy_dirty = false;      // a lazy step ran since the last materialise: windows may hold pending tokens
   DevBuf LZ_COUNT;          // [2][B] int32 pending tokens per env
@@ -851,6 +854,15 @@ hipEvent_t record_on(lram_engine* e, hipStream_t src) {
   return ev;
 }
 
+// level: +1 the device's highest stream priority, -1 its lowest, 0 default
+hipError_t create_stream(hipStream_t* s, int level) {
+  if (level == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  int least = 0, greatest = 0;
+  hipError_t err = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (err != hipSuccess) return err;
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, level > 0 ? greatest : least);
+}
+
 // Slices for this call.  One slice on the caller's stream unless micro-batching is on: then n_micro slices on
 // engine-owned streams plus one stream that serialises the HBM-bound cell kernels (see run_xlstm_stack).
 std::vector<Slice> make_slices(lram_engine* e, hipStream_t s, hipStream_t* hbm) {
@@ -863,10 +875,10 @@ std::vector<Slice> make_slices(lram_engine* e, hipStream_t s, hipStream_t* hbm) 
   if (n == 1) return {Slice{0, e->B, s}};
   while ((int)e->micro_streams.size() < n) {
     hipStream_t ns;
-    LRAM_HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+    LRAM_HIP_CHECK(create_stream(&ns, e->stream_prio == 1 || e->stream_prio == 2 ? +1 : (e->stream_prio == 3 ? -1 : 0)));
     e->micro_streams.push_back(ns);
   }
-  if (!e->hbm_stream) LRAM_HIP_CHECK(hipStreamCreateWithFlags(&e->hbm_stream, hipStreamNonBlocking));
+  if (!e->hbm_stream) LRAM_HIP_CHECK(create_stream(&e->hbm_stream, e->stream_prio == 1 ? -1 : (e->stream_prio == 3 ? +1 : 0)));
   *hbm = e->hbm_stream;
   std::vector<Slice> out;
   const int base = e->B / n, rem = e->B % n;
@@ -1088,6 +1100,7 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
       e->lazy_compact = false;
     }
     const int c_due = (P - (int)(e->lazy_step % P)) % P;
+    e->lazy_due_bound = e->lazy_bound[c_due];  // pending tokens of the envs this step's compact fold covers, at most
     for (int cls = 0; cls < P; ++cls) {
       if (cls == c_due)
         e->lazy_bound[cls] = 0;
@@ -1109,7 +1122,7 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   }
   auto launch_folds = [&](int i) {  // one launch per block over all env slots: folds do not care about the slices
     MlstmLazyArgs la = lazy_args(e, i, T, reset, 0, e->B);
-    la.compact = e->lazy_compact ? 1 : 0;
+    la.compact = e->lazy_compact ? 1 : 0, la.fold_wmax = e->lazy_compact ? e->lazy_due_bound : 0;
     prof_record(e, fs, true, true);
     launch_mlstm_lazy_fold(la, fs);
     prof_record(e, fs, false, true);
@@ -1130,7 +1143,7 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   std::vector<char> folded(c.n_blocks, 0);
   auto launch_folds_on_hbm = [&](int i) {
     MlstmLazyArgs la = lazy_args(e, i, T, reset, 0, e->B);
-    la.compact = e->lazy_compact ? 1 : 0;
+    la.compact = e->lazy_compact ? 1 : 0, la.fold_wmax = e->lazy_compact ? e->lazy_due_bound : 0;
     prof_record(e, hbm, true, true);
     launch_mlstm_lazy_fold(la, hbm);
     prof_record(e, hbm, false, true);
@@ -1658,6 +1671,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_BUBBLES")) e->fold_bubbles = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_FOLD_SPREAD")) e->fold_spread = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_STREAM_PRIO")) e->stream_prio = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_FOLD_FUSED")) e->fold_fused = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_FUSED_STREAM")) e->fold_fused_stream = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_GAPS")) e->fold_gaps = std::max(0, std::atoi(v));

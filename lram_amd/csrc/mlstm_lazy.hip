@@ -66,15 +66,21 @@ __device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r 
 constexpr int kFC = 128;   // columns per workgroup
 constexpr int kFPV = 136;  // LDS pitch of the V rows
 constexpr int kFPK = 40;   // LDS pitch of the scaled khat tile (32 rows of DH)
-constexpr int kFR = 64;    // rows of C per workgroup (two 32-row MFMA tiles): many short workgroups hide the
+#ifndef LRAM_KFR
+#define LRAM_KFR 64
+#endif
+constexpr int kFR = LRAM_KFR;    // rows of C per workgroup (two 32-row MFMA tiles): many short workgroups hide the
                            // load -> MFMA -> store latency of a fold better than few long ones
 
 constexpr int kFT = 4;      // at most this many tokens per step (readout partials of the fused fold)
 
+// WF: window rows held in LDS (48; 40 -- opt-in, when the host's bound on the pending tokens of the folding envs allows it --
+// is 34.6 KB of LDS = four workgroups per CU instead of three); READOUT: the fold + readout form (a.ypart)
+template <int WF, bool READOUT>
 __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
-  __shared__ __attribute__((aligned(16))) float Vs[W * kFPV];
-  __shared__ __attribute__((aligned(16))) float Ks[(kFR / 32) * W * kFPK];
-  __shared__ float Qs[kFT * kFR];  // q_t of this workgroup's rows (fold + readout: a.ypart != nullptr)
+  __shared__ __attribute__((aligned(16))) float Vs[WF * kFPV];
+  __shared__ __attribute__((aligned(16))) float Ks[(kFR / 32) * WF * kFPK];
+  __shared__ float Qs[READOUT ? kFT * kFR : 1];  // q_t of this workgroup's rows (fold + readout: a.ypart != nullptr)
   const int DH = a.DH, NH = a.NH;
   const int nsl = DH / kFC;
   int wid = blockIdx.x;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
   const float* wkb = a.wk + (((int64_t)b * NH + h) * W) * DH + row0;
   const float* wvb = a.wv + (((int64_t)b * NH + h) * W) * DH + slice * kFC;
   const float* cfb = a.coef_in + ((int64_t)b * NH + h) * W;
-  const bool readout = a.ypart != nullptr;
+  constexpr bool readout = READOUT;
   if (readout && tid < a.T * kFR) {  // this step's q_t for the workgroup's 64 rows (the step's front end has run)
     const int t = tid / kFR, r = tid % kFR;
     const int ch = h * DH + row0 + r, inner = NH * DH;
@@ -120,39 +126,39 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       cold[t][r] = lv.zero_in ? 0.f : cp0[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * DH];
-  float4 rv[(W * (kFC / 4) + 255) / 256];
+  float4 rv[(WF * (kFC / 4) + 255) / 256];
 #pragma unroll
-  for (int i = 0; i < (W * (kFC / 4) + 255) / 256; ++i) {
+  for (int i = 0; i < (WF * (kFC / 4) + 255) / 256; ++i) {
     const int idx = tid + 256 * i;
     const int j = idx / (kFC / 4), c4 = (idx % (kFC / 4)) << 2;
-    rv[i] = (idx < W * (kFC / 4) && j < n) ? *reinterpret_cast<const float4*>(wvb + (int64_t)j * DH + c4) : f4_zero();
+    rv[i] = (idx < WF * (kFC / 4) && j < n) ? *reinterpret_cast<const float4*>(wvb + (int64_t)j * DH + c4) : f4_zero();
   }
-  float4 rk[(W * (kFR / 4) + 255) / 256];
-  float rc[(W * (kFR / 4) + 255) / 256];
+  float4 rk[(WF * (kFR / 4) + 255) / 256];
+  float rc[(WF * (kFR / 4) + 255) / 256];
 #pragma unroll
-  for (int i = 0; i < (W * (kFR / 4) + 255) / 256; ++i) {
+  for (int i = 0; i < (WF * (kFR / 4) + 255) / 256; ++i) {
     const int idx = tid + 256 * i;
     const int j = idx / (kFR / 4), r4 = (idx % (kFR / 4)) << 2;
-    const bool ok = idx < W * (kFR / 4) && j < n;
+    const bool ok = idx < WF * (kFR / 4) && j < n;
     rk[i] = ok ? *reinterpret_cast<const float4*>(wkb + (int64_t)j * DH + r4) : f4_zero();
     rc[i] = ok ? cfb[j] : 0.f;
   }
 #pragma unroll
-  for (int i = 0; i < (W * (kFC / 4) + 255) / 256; ++i) {
+  for (int i = 0; i < (WF * (kFC / 4) + 255) / 256; ++i) {
     const int idx = tid + 256 * i;
-    if (idx < W * (kFC / 4)) {
+    if (idx < WF * (kFC / 4)) {
       const int j = idx / (kFC / 4), c4 = (idx % (kFC / 4)) << 2;
       *reinterpret_cast<float4*>(Vs + j * kFPV + c4) = rv[i];
     }
   }
 #pragma unroll
-  for (int i = 0; i < (W * (kFR / 4) + 255) / 256; ++i) {
+  for (int i = 0; i < (WF * (kFR / 4) + 255) / 256; ++i) {
     const int idx = tid + 256 * i;
-    if (idx < W * (kFR / 4)) {
+    if (idx < WF * (kFR / 4)) {
       const int j = idx / (kFR / 4), r4 = (idx % (kFR / 4)) << 2;  // row r4 .. r4+3 of this workgroup's kFR rows
       const float cj = rc[i];
       // scaled khat, tile (r4 / 32): Ks[tile][j][r4 % 32]
-      *reinterpret_cast<float4*>(Ks + (r4 >> 5) * W * kFPK + j * kFPK + (r4 & 31)) =
+      *reinterpret_cast<float4*>(Ks + (r4 >> 5) * WF * kFPK + j * kFPK + (r4 & 31)) =
           make_float4(cj * rk[i].x, cj * rk[i].y, cj * rk[i].z, cj * rk[i].w);
     }
   }
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = g * cold[t][r];
-    const float* Kt = Ks + t * W * kFPK;
+    const float* Kt = Ks + t * WF * kFPK;
     for (int j8 = 0; j8 < kt8; ++j8) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -769,7 +775,23 @@ void launch_mlstm_lazy_fold(const MlstmLazyArgs& a_in, hipStream_t stream) {
     envs = (a.B - a.first + a.period - 1) / a.period;
   }
   const long nwg = envs * a.NH * (a.DH / kFC) * (a.DH / kFR);
-  hipLaunchKernelGGL(mlstm_lazy_fold_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, a);
+  // 40 window rows in LDS when no folding env can hold more pending tokens (host bound; 0 = unknown)
+  // opt-in (LRAM_FOLD_W40=1): the fold itself gets 25 % shorter inside the pipeline (0.243 -> 0.183 ms at 16M / 4096 slots),
+  // the step does not -- the sLSTM chains beside it slow down by as much (16M +0.5 %, 1024 slots -0.8 %, 206M -1 %;
+  // profiles/r03_ab_fold_w40.txt)
+  static const bool allow40 = [] {
+    const char* v = std::getenv("LRAM_FOLD_W40");
+    return v != nullptr && std::atoi(v) != 0;
+  }();
+  const bool w40 = allow40 && a.fold_wmax > 0 && a.fold_wmax <= 40 && a.force == 0 && a.compact != 0;
+  const dim3 grid((unsigned)nwg), block(256);
+  if (a.ypart != nullptr) {
+    hipLaunchKernelGGL((mlstm_lazy_fold_kernel<W, true>), grid, block, 0, stream, a);
+  } else if (w40) {
+    hipLaunchKernelGGL((mlstm_lazy_fold_kernel<40, false>), grid, block, 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((mlstm_lazy_fold_kernel<W, false>), grid, block, 0, stream, a);
+  }
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
