@@ -316,6 +316,20 @@ struct SlstmPointwiseArgs {
 };
 void launch_slstm_pointwise(const SlstmPointwiseArgs& a, hipStream_t stream);
 
+// recurrent projection + pointwise cell of ONE token in one launch (few env rows; xlstm_kernels.hip)
+struct SlstmTokenArgs {
+  const float* gates;  // [B*T, 4, H] input pre-activations (Wx)
+  const float* rt;     // [NH, 4, SDH, SDH] recurrent weights (out, in)
+  const float* bias;   // [4, H]
+  const float* hprev;  // h_{t-1}: row b at hprev + b * hprev_ld (the state's h plane, or yout rows of token t - 1)
+  int64_t hprev_ld;
+  float* state;        // [4, state_B, H] in/out (h plane written only when write_h)
+  float* yout;         // [B*T, H]
+  int B, T, t, H, NH, state_B, write_h;
+};
+bool slstm_token_supported(int H, int NH);
+void launch_slstm_token(const SlstmTokenArgs& a, hipStream_t stream);
+
 // a[r, f] = gelu(p[r, f]) * p[r, F + f]      p: [rows, 2F]
 void launch_gelu_gate(const float* p, float* a, int rows, int F, hipStream_t stream);
 

@@ -147,6 +147,9 @@ struct lram_engine {
   DevBuf YPART;  // [B, NH, DH / 64, T, DH]
   int fold_gaps = 0;        // LRAM_FOLD_GAPS=g: the last g mLSTM blocks' folds run just ahead of their own read passes
   int front_stagger = 0;    // LRAM_FRONT_STAGGER=1: in the step's first mLSTM block, slice k's front end waits for slice k-1's
+  int slstm_fused_rows = 512;  // LRAM_SLSTM_FUSED_ROWS: slices of slstm_fused_min .. this many envs (at sLSTM head dim <= 128; fewer above:
+                               // x 128 / head dim) take the one-launch sLSTM token kernel (0 = never)
+  int slstm_fused_min = 1;     // LRAM_SLSTM_FUSED_MIN
   int stream_prio = 0;      // LRAM_STREAM_PRIO: 1 slice streams highest / state-pass stream lowest priority, 2 slices highest only,
                             // 3 the reverse of 1 (measured: see profiles/EXPERIMENTS.md)
   bool fold_spread = true;  // LRAM_FOLD_SPREAD: the folds behind the first read passes are shared out over all sLSTM stretches
@@ -1053,7 +1056,22 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     ga.m = rows, ga.n = SDH, ga.k = SDH, ga.nb1 = NH;
     gemm(e, ga, s);
   }
-  for (int t = 0; t < T; ++t) {
+  // few env rows (slstm_fused_min .. slstm_fused_rows): recurrent projection + pointwise cell as ONE lean launch per token instead of a
+  // batched matrix-core GEMM (fixed latency of a 128-row tile) and the pointwise kernel
+  // (measured, same box each: 16M 1 env +1.9 %, 8 +4.2 %, 12 +6.6 %, 32 +6.0 %, 128 +3.3 %, 512-env slices +1.6 %, 1024-env
+  // slices +-0; 206M 16 envs +6.1 %, 64 +2.9 %, 256-env slices -1.4 %: the row limit scales with 128 / head dim)
+  const bool tok_fused = e->slstm_fused_rows > 0 && sl.nb >= e->slstm_fused_min &&
+                         (int64_t)sl.nb * std::max(SDH, 128) <= (int64_t)e->slstm_fused_rows * 128 && slstm_token_supported(Hs, NH);
+  for (int t = 0; tok_fused && t < T; ++t) {
+    SlstmTokenArgs ta;
+    ta.gates = gates, ta.rt = w.rt, ta.bias = w.rbias, ta.state = state, ta.yout = Y;
+    ta.hprev = t == 0 ? state : Y + (int64_t)(t - 1) * Hs, ta.hprev_ld = t == 0 ? Hs : (int64_t)T * Hs;
+    ta.B = sl.nb, ta.T = T, ta.t = t, ta.H = Hs, ta.NH = NH, ta.state_B = e->B, ta.write_h = (t == T - 1 && t > 0) ? 1 : 0;
+    launch_slstm_token(ta, s);
+  }
+  if (tok_fused && T == 1)  // the single launch read the state's h plane: it is refreshed from the output rows afterwards
+    LRAM_HIP_CHECK(hipMemcpyAsync(state, Y, (size_t)sl.nb * Hs * sizeof(float), hipMemcpyDeviceToDevice, s));
+  for (int t = 0; !tok_fused && t < T; ++t) {
     GemmArgs ra;
     ra.a = state, ra.lda = Hs, ra.sA1 = SDH, ra.sA2 = 0;
     ra.w = w.rt, ra.ldw = SDH, ra.sW1 = 4 * (int64_t)SDH * SDH, ra.sW2 = (int64_t)SDH * SDH;
@@ -1671,6 +1689,8 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_BUBBLES")) e->fold_bubbles = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_FOLD_SPREAD")) e->fold_spread = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_SLSTM_FUSED_MIN")) e->slstm_fused_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_STREAM_PRIO")) e->stream_prio = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_FOLD_FUSED")) e->fold_fused = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_FUSED_STREAM")) e->fold_fused_stream = std::atoi(v) != 0;

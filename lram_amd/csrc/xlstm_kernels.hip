@@ -692,6 +692,89 @@ __global__ __launch_bounds__(256) void slstm_pointwise_kernel(SlstmPointwiseArgs
   a.yout[row * H + c] = ynew;
 }
 
+// sLSTM token step for few env rows: the head's recurrent projection R_g h_{t-1} and the pointwise cell in ONE launch, where
+// the generic path runs a batched per-head GEMM (a 128-row bf16x3 tile for, say, 64 rows: ~24 us of fixed latency) and the
+// pointwise kernel after it.  One workgroup = 32 envs x 8 channels x 4 gates of one head: a single 32 x 32 tile of the exact
+// fp32 matrix-core instruction (v_mfma_f32_32x32x2_f32), K = SDH split over the four waves.  Each lane requests its
+// operands straight from global memory -- its env's h_{t-1} row and its output's R row over the wave's K range, contiguous
+// 16-byte runs, all in flight together (one memory round trip, no LDS staging) -- the four partial tiles meet in LDS, then
+// thread (env, channel) applies slstm_pointwise_kernel's cell update ([3P] slstm_pointwise) to its four gate sums.
+// h_{t-1} is read from `hprev` (the state's h plane for the first token of a launch sequence, the previous token's rows of
+// yout afterwards) and h_t goes to yout -- and to the state's h plane only when a.write_h is set (never in a launch that
+// reads that plane: other workgroups still need it).
+constexpr int kSlTokCh = 8, kSlTokEnv = 32;
+typedef float sl_f32x16 __attribute__((ext_vector_type(16)));
+template <int SDH>
+__global__ __launch_bounds__(256) void slstm_token_kernel(SlstmTokenArgs a) {
+  __shared__ float part[4][kSlTokEnv][33];
+  const int H = a.H;
+  constexpr int ncb = SDH / kSlTokCh;
+  constexpr int S = SDH / 8;  // K steps per lane: wave w, lane half lh own k = w * SDH/4 + lh * SDH/8 + [0, S)
+  static_assert(S % 4 == 0, "sLSTM token kernel: head dim must be a multiple of 32");
+  const int cb = blockIdx.x % ncb, head = blockIdx.x / ncb;
+  const int b0 = blockIdx.y * kSlTokEnv;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int kbase = w * (SDH / 4) + lh * S;
+  // operands: A row = env li, B row = output n = li = 4 * channel + gate
+  const int bl = min(b0 + li, a.B - 1);
+  const float* ap = a.hprev + (int64_t)bl * a.hprev_ld + head * SDH + kbase;
+  const float* bp = a.rt + (((int64_t)head * 4 + (li & 3)) * SDH + cb * kSlTokCh + (li >> 2)) * SDH + kbase;
+  float4 av[S / 4], bv[S / 4];
+#pragma unroll
+  for (int i = 0; i < S / 4; ++i) av[i] = *reinterpret_cast<const float4*>(ap + 4 * i);
+#pragma unroll
+  for (int i = 0; i < S / 4; ++i) bv[i] = *reinterpret_cast<const float4*>(bp + 4 * i);
+  // this thread's cell: env e, channel c (requested before the matrix products need their operands)
+  const int e = tid >> 3, ch = tid & 7;
+  const int c = head * SDH + cb * kSlTokCh + ch;
+  const int b = b0 + e;
+  const bool live = b < a.B;
+  const int bb = live ? b : a.B - 1;
+  const int64_t row = (int64_t)bb * a.T + a.t;
+  const float* gp = a.gates + row * 4 * H + c;
+  const float gi = gp[0] + a.bias[c], gf = gp[H] + a.bias[H + c], gz = gp[2 * H] + a.bias[2 * H + c],
+              go = gp[3 * H] + a.bias[3 * H + c];
+  const int64_t BH = (int64_t)a.state_B * H;
+  float* st = a.state + (int64_t)bb * H + c;
+  const float cs = st[BH], ns = st[2 * BH], ms = st[3 * BH];
+  // every request above is issued before the first matrix product (left alone, the scheduler feeds the products with one
+  // or two loads in flight: S / 4 dependent round trips instead of one)
+  __builtin_amdgcn_sched_barrier(0);
+  sl_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < S / 4; ++i) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[i].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[i].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+  }
+  // lane (li, lh) holds column n = li of rows (r & 3) + 8 (r >> 2) + 4 lh
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[w][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+  __syncthreads();
+  if (!live) return;
+  float sum[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    sum[g] = (part[0][e][4 * ch + g] + part[1][e][4 * ch + g]) + (part[2][e][4 * ch + g] + part[3][e][4 * ch + g]);
+  const float iraw = gi + sum[0], fraw = gf + sum[1], zraw = gz + sum[2], oraw = go + sum[3];
+  const float logfplusm = ms + log_sigmoid(fraw);
+  const float mnew = (ns == 0.f) ? iraw : fmaxf(iraw, logfplusm);
+  const float ogate = sigmoid_f(oraw);
+  const float igate = fminf(expf(iraw - mnew), 1.f);
+  const float fgate = fminf(expf(logfplusm - mnew), 1.f);
+  const float cnew = fgate * cs + igate * tanhf(zraw);
+  const float nnew = fgate * ns + igate;
+  const float ynew = ogate * cnew / nnew;
+  if (a.write_h) st[0] = ynew;
+  st[BH] = cnew;
+  st[2 * BH] = nnew;
+  st[3 * BH] = mnew;
+  a.yout[row * H + c] = ynew;
+}
+
 __global__ __launch_bounds__(256) void gelu_gate_kernel(const float* p, float* out, int64_t rows, int F) {
   const int nv = F >> 2;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -913,6 +996,31 @@ void launch_slstm_conv(const SlstmConvArgs& a, hipStream_t stream) {
       hipLaunchKernelGGL(slstm_conv_rt_kernel, grid, block, 0, stream, a);
   }
   LRAM_HIP_CHECK(hipGetLastError());
+}
+
+bool slstm_token_supported(int H, int NH) {
+  const int SDH = NH > 0 ? H / NH : 0;
+  return NH > 0 && H % NH == 0 && (SDH == 32 || SDH == 64 || SDH == 128 || SDH == 192 || SDH == 256 || SDH == 320);
+}
+
+template <int SDH>
+void launch_slstm_token_sdh(const SlstmTokenArgs& a, hipStream_t stream) {
+  const dim3 grid((unsigned)(a.NH * (SDH / kSlTokCh)), (unsigned)((a.B + kSlTokEnv - 1) / kSlTokEnv));
+  hipLaunchKernelGGL(slstm_token_kernel<SDH>, grid, dim3(256), 0, stream, a);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_slstm_token(const SlstmTokenArgs& a, hipStream_t stream) {
+  LRAM_REQUIRE(slstm_token_supported(a.H, a.NH), "sLSTM token kernel: head dim must be 32, 64, 128, 192, 256 or 320");
+  LRAM_REQUIRE(!(a.write_h && a.hprev == a.state), "sLSTM token kernel: a launch that reads the state's h plane must not write it");
+  switch (a.H / a.NH) {
+    case 32: return launch_slstm_token_sdh<32>(a, stream);
+    case 64: return launch_slstm_token_sdh<64>(a, stream);
+    case 128: return launch_slstm_token_sdh<128>(a, stream);
+    case 192: return launch_slstm_token_sdh<192>(a, stream);
+    case 256: return launch_slstm_token_sdh<256>(a, stream);
+    default: return launch_slstm_token_sdh<320>(a, stream);
+  }
 }
 
 void launch_slstm_pointwise(const SlstmPointwiseArgs& a, hipStream_t stream) {

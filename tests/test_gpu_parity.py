@@ -218,6 +218,45 @@ def test_xlstm_206m_shapes_two_blocks(hip_lib):
     assert _run_parity("xlstm_206m_cut", B=3, steps=4, spec=spec) == 0
 
 
+@pytest.mark.parametrize("d_model,n_blocks,B", [(128, 3, 11), (512, 3, 40), (768, 2, 19), (1024, 2, 17), (1280, 3, 21)])
+def test_slstm_token_kernel_matches_oracle_and_the_gemm_path(hip_lib, monkeypatch, d_model, n_blocks, B):
+    """Slices of 9 .. 256 envs run the sLSTM recurrence as ONE launch per token (slstm_token_kernel: recurrent projection in
+    exact fp32 + pointwise cell; sLSTM head dims 32 / 128 / 192 / 256 / 320 here, ragged 16-env tiles) instead of a batched
+    GEMM plus the pointwise kernel (LRAM_SLSTM_FUSED_ROWS=0): both against the oracle, and against each other after
+    env-steps with resets, a 1-token encoder step (the launch that reads the state's h plane must not write it) and a
+    9-timestep prefill (12-token passes)."""
+    from lram_amd.config import ModelSpec
+    from lram_amd.engine import Engine
+    spec = ModelSpec(backbone="xlstm", d_model=d_model, n_blocks=n_blocks, slstm_at=[1]) if d_model != 128 else preset("xlstm_tiny")
+    for rows in ("256", "0"):
+        monkeypatch.setenv("LRAM_SLSTM_FUSED_ROWS", rows)
+        assert _run_parity(f"slstm_tok_{d_model}_{rows}", B=B, steps=4, spec=spec) == 0
+    sd = init_state_dict(spec, seed=7)
+    seq = make_inputs(spec, B, 9, seed=21, reset_prob=0.2)
+    engines = {}
+    for rows in ("256", "0"):
+        monkeypatch.setenv("LRAM_SLSTM_FUSED_ROWS", rows)
+        engines[rows] = Engine(spec, sd, B, device="cuda:0")
+    for obs, rtg, rew, mask in seq[:5]:
+        a1, _ = engines["256"].step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+        a0, _ = engines["0"].step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+        assert float((a0 - a1).abs().max()) <= 1e-4
+    x = torch.randn(B, 1, spec.d_model, generator=torch.Generator().manual_seed(3)).cuda()
+    for _ in range(2):   # two single-token passes: the second reads the h plane the first one left
+        y1, y0 = engines["256"].encoder_step(x), engines["0"].encoder_step(x)
+        assert rel_err(y1, y0) < 1e-5
+    obs_seq = torch.stack([t[0] for t in seq], 1).contiguous().cuda()
+    rtg_seq = torch.stack([t[1] for t in seq], 1).contiguous().cuda()
+    rew_seq = torch.stack([t[2] for t in seq], 1).contiguous().cuda()
+    p1, _ = engines["256"].prefill(obs_seq, rtg_seq, rew_seq)
+    p0, _ = engines["0"].prefill(obs_seq, rtg_seq, rew_seq)
+    torch.cuda.synchronize()
+    assert float((p0 - p1).abs().max()) <= 1e-4
+    assert rel_err(engines["256"].export_state_tensor(1, 0), engines["0"].export_state_tensor(1, 0)) < 1e-5
+    for e in engines.values():
+        e.close()
+
+
 @pytest.mark.parametrize("d_model,slstm_at", [(704, [1]), (1064, []), (1432, []), (1792, [1])])
 def test_reference_half_presets_geometry(hip_lib, d_model, slstm_at):
     """The widths of the reference's xlstm_*_half presets (configs/agent_params/huggingface): head dims 352 / 544 / 720
