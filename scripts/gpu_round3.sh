@@ -25,3 +25,6 @@ python bench.py --config mamba_48m --batch 2048 --steps 64 --warmup 8 --no-cpu-b
 python bench.py --config mamba_48m --batch 2048 --steps 32 --warmup 8 --no-cpu-baseline --mamba-compat --env-act-dim 4 > profiles/${RND}_bench_mamba48m_b2048_reference_trajectory.json 2>> $OUT/bench.err; cut -c1-200 profiles/${RND}_bench_mamba48m_b2048_reference_trajectory.json; echo
 bash scripts/gpu_sweep.sh > $OUT/sweep.txt 2>/dev/null; cp $OUT/sweep.txt profiles/${RND}_config_sweep.txt; cat $OUT/sweep.txt
 cp profiles/${RND}_* $OUT/profiles_out/
+{ PREFILL_MODES=chunkwise python scripts/bench_prefill.py xlstm_206m 64 512 | tail -1; PREFILL_MODES=chunkwise python scripts/bench_prefill.py xlstm_16m 1024 63 | tail -1; } > profiles/${RND}_prefill_chunkwise_bench.txt 2>/dev/null; cat profiles/${RND}_prefill_chunkwise_bench.txt
+python scripts/read_ceiling.py >> profiles/${RND}_prefill_chunkwise_bench.txt 2>/dev/null
+cp profiles/${RND}_* $OUT/profiles_out/
