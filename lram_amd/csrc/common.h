@@ -87,6 +87,8 @@ int gemm_choose_split_k(GemmArgs& g);                             // fills split
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream);  // C = sum_s ws[s] (+ bias) (+ residual)
 void launch_gemm_f32(const GemmArgs& g, hipStream_t stream);      // exact fp32 MFMA (k-ordered fma chain)
 bool gemm_small_m(const GemmArgs& g);                             // M <= 8: launch_gemm_f32 takes the GEMV path
+bool gemm_skinny_supported(const GemmArgs& g);                    // few-row kernel: 32 x 32 fp32 MFMA tile per workgroup, K over the waves
+void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream);
 bool gemm_bf16x3_supported(const GemmArgs& g);
 void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t stream);   // fp32-accurate, 3 x bf16 split operands
 void launch_split_bf16x3(const float* w, uint16_t* out, size_t n, hipStream_t stream);

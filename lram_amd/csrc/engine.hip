@@ -150,6 +150,8 @@ struct lram_engine {
   int slstm_fused_rows = 512;  // LRAM_SLSTM_FUSED_ROWS: slices of slstm_fused_min .. this many envs (at sLSTM head dim <= 128; fewer above:
                                // x 128 / head dim) take the one-launch sLSTM token kernel (0 = never)
   int slstm_fused_min = 1;     // LRAM_SLSTM_FUSED_MIN
+  int gemm_skinny_rows = 384;  // LRAM_GEMM_SKINNY_ROWS: GEMMs with 9 .. this many operand rows (half of it for weights above 600k elements) ...
+  int gemm_skinny_k = 1024;    // LRAM_GEMM_SKINNY_K: ... and K up to this take the few-row kernel (rows 0 = never)
   int stream_prio = 0;      // LRAM_STREAM_PRIO: 1 slice streams highest / state-pass stream lowest priority, 2 slices highest only,
                             // 3 the reverse of 1 (measured: see profiles/EXPERIMENTS.md)
   bool fold_spread = true;  // LRAM_FOLD_SPREAD: the folds behind the first read passes are shared out over all sLSTM stretches
@@ -768,6 +770,18 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
       }
       g.w2 = nullptr, g.w_inv = nullptr;
     }
+  }
+  // few operand rows (more than the GEMV's 8, at most gemm_skinny_rows): one 32 x 32 fp32 matrix-core tile per workgroup, operands
+  // straight into registers, no split-K slab / reduce launch
+  // Where it wins (same box each, `profiles/r03_ab_gemm_few_rows.txt`): K <= 1024 -- a lane group walks its K range in rounds
+  // of 8 float4, one memory round trip each, so a long K is a long serial chain where the tile kernels' split-K spreads it
+  // over workgroups (Mamba x_proj / out_proj, K = 1536: -3 % each at 32 envs; the 206M stack's K = 1280 / 2560: -7 % at 64
+  // envs) -- and up to 192 operand rows, 384 for weights of at most 600k elements (every 32-row tile re-reads the weight).
+  // 16M at 4 / 12 / 32 / 64 / 128 envs: +17 / +17 / +16 / +12 / +10 %; C1 (2 blocks, D = 128) at 32 envs: 0.130 -> 0.093 ms.
+  const bool skinny_shape = g.k <= e->gemm_skinny_k && (g.m <= e->gemm_skinny_rows / 2 || (int64_t)g.n * g.k <= 600000);
+  if (g.m <= e->gemm_skinny_rows && skinny_shape && gemm_skinny_supported(g)) {
+    launch_gemm_skinny(g, s);
+    return;
   }
   if (e->use_bf16x3 && !gemm_small_m(g)) {
     // planes of the weight tensor that contains g.w (a GEMM may address a row range of a weight: proj_up's halves)
@@ -1691,6 +1705,8 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_FOLD_SPREAD")) e->fold_spread = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_MIN")) e->slstm_fused_min = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_ROWS")) e->gemm_skinny_rows = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_K")) e->gemm_skinny_k = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_STREAM_PRIO")) e->stream_prio = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_FOLD_FUSED")) e->fold_fused = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_FUSED_STREAM")) e->fold_fused_stream = std::atoi(v) != 0;
@@ -2075,6 +2091,17 @@ int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64
     g.residual = accumulate ? dev_c : nullptr;
     g.m = m, g.n = n, g.k = k;
     launch_gemm_f32(g, static_cast<hipStream_t>(stream));
+  });
+}
+
+int32_t lram_gemm_skinny(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
+                         const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
+  return guarded([&] {
+    GemmArgs g;
+    g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
+    g.residual = accumulate ? dev_c : nullptr;
+    g.m = m, g.n = n, g.k = k;
+    launch_gemm_skinny(g, static_cast<hipStream_t>(stream));
   });
 }
 

@@ -227,6 +227,119 @@ __global__ __launch_bounds__(256) void gemv_small_m_kernel(GemmArgs g) {
   }
 }
 
+// Few-row path (9 .. a few hundred rows: tens of envs x 3 tokens).  A 128 x 128 tile kernel leaves most of its tile empty
+// there, needs split-K plus a reduce launch to reach more than a handful of CUs, and pays a serial K loop of global -> LDS ->
+// MFMA round trips.  Here one workgroup owns a 32 x 32 output tile as ONE accumulator of the exact fp32 matrix instruction
+// (v_mfma_f32_32x32x2_f32), K is split over the four waves and the two lane halves, and every lane requests its operands --
+// its A row and its W row over the lane's K range, contiguous 16-byte runs -- straight from global memory into registers:
+// kSkQ float4 per operand per round, the next round's requests issued before the current round's matrix instructions.
+// No LDS staging, no split-K workspace, no second launch; the four partial tiles meet in LDS and leave as 16-byte stores
+// with bias / residual applied.  Same arithmetic class as gemm_f32_kernel (fp32 products, fp32 accumulation).
+constexpr int kSkQ = 8;  // float4 per operand per lane per round (64 VGPRs for the two operands, twice with the prefetch)
+
+template <bool HAS_BIAS, bool HAS_RES>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+  __shared__ float part[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int z = blockIdx.z;
+  const int z1 = z / g.nb2, z2 = z - z1 * g.nb2;
+  const float* A = g.a + z1 * g.sA1 + z2 * g.sA2;
+  const float* W = g.w + z1 * g.sW1 + z2 * g.sW2;
+  float* C = g.c + z1 * g.sC1 + z2 * g.sC2;
+  const float* R = HAS_RES ? g.residual + z1 * g.sC1 + z2 * g.sC2 : nullptr;
+  const float* bias = HAS_BIAS ? g.bias + z1 * g.sBias1 + z2 * g.sBias2 : nullptr;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  // lane group (w, lh) owns the float4 indices [q0, q1) of the K axis
+  const int nq = g.k >> 2;
+  const int per = (nq + 7) >> 3;
+  const int grp = 2 * w + lh;
+  const int q0 = min(grp * per, nq), q1 = min(q0 + per, nq);
+  const float4* ap = reinterpret_cast<const float4*>(A + (int64_t)min(m0 + li, g.m - 1) * g.lda);
+  const float4* bp = reinterpret_cast<const float4*>(W + (int64_t)min(n0 + li, g.n - 1) * g.ldw);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 av0[kSkQ], bv0[kSkQ], av1[kSkQ], bv1[kSkQ];  // two register sets, named apart: a run-time set index would put them in scratch
+  // unconditional loads at clamped indices (a load under a lane condition costs a branch and a full wait); what lies
+  // beyond the lane's range is multiplied by zero
+  auto request = [&](float4 (&av)[kSkQ], float4 (&bv)[kSkQ], int q) {
+#pragma unroll
+    for (int i = 0; i < kSkQ; ++i) {
+      const int qi = min(q + i, nq - 1);
+      av[i] = ap[qi];
+      bv[i] = bp[qi];
+    }
+  };
+  auto products = [&](const float4 (&av)[kSkQ], const float4 (&bv)[kSkQ], int q) {
+#pragma unroll
+    for (int i = 0; i < kSkQ; ++i) {
+      const float live = (q + i < q1) ? 1.f : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x * live, bv[i].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y * live, bv[i].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z * live, bv[i].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w * live, bv[i].w, acc, 0, 0, 0);
+    }
+  };
+  // every lane group runs the same number of rounds (the matrix instruction is wave-wide; the groups' ranges differ by
+  // at most one float4)
+  const int rounds = (per + kSkQ - 1) / kSkQ;
+  request(av0, bv0, q0);
+  // bias / residual of this thread's four outputs, requested with the first operands
+  const int er = tid >> 3, ec = (tid & 7) << 2;
+  const int row = m0 + er, col = n0 + ec;
+  const bool ok = row < g.m && col < g.n;
+  float4 bz = make_float4(0.f, 0.f, 0.f, 0.f), rz = bz;
+  const bool vec = ok && col + 3 < g.n && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+  if (HAS_BIAS && ok) {
+    bz.x = bias[col];
+    if (col + 1 < g.n) bz.y = bias[col + 1];
+    if (col + 2 < g.n) bz.z = bias[col + 2];
+    if (col + 3 < g.n) bz.w = bias[col + 3];
+  }
+  if (HAS_RES && ok) {
+    const float* rp = R + (int64_t)row * g.ldc + col;
+    if (vec) {
+      rz = *reinterpret_cast<const float4*>(rp);
+    } else {
+      rz.x = rp[0];
+      if (col + 1 < g.n) rz.y = rp[1];
+      if (col + 2 < g.n) rz.z = rp[2];
+      if (col + 3 < g.n) rz.w = rp[3];
+    }
+  }
+  for (int r = 0; r < rounds; r += 2) {
+    const int q = q0 + r * kSkQ;
+    __builtin_amdgcn_sched_barrier(0);
+    if (r + 1 < rounds) request(av1, bv1, q + kSkQ);
+    __builtin_amdgcn_sched_barrier(0);
+    products(av0, bv0, q);
+    if (r + 1 < rounds) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (r + 2 < rounds) request(av0, bv0, q + 2 * kSkQ);
+      __builtin_amdgcn_sched_barrier(0);
+      products(av1, bv1, q + kSkQ);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[w][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
+  __syncthreads();
+  if (!ok) return;
+  float4 o;
+  o.x = ((part[0][er][ec] + part[1][er][ec]) + (part[2][er][ec] + part[3][er][ec]) + bz.x) + rz.x;
+  o.y = ((part[0][er][ec + 1] + part[1][er][ec + 1]) + (part[2][er][ec + 1] + part[3][er][ec + 1]) + bz.y) + rz.y;
+  o.z = ((part[0][er][ec + 2] + part[1][er][ec + 2]) + (part[2][er][ec + 2] + part[3][er][ec + 2]) + bz.z) + rz.z;
+  o.w = ((part[0][er][ec + 3] + part[1][er][ec + 3]) + (part[2][er][ec + 3] + part[3][er][ec + 3]) + bz.w) + rz.w;
+  float* cp = C + (int64_t)row * g.ldc + col;
+  if (vec) {
+    *reinterpret_cast<float4*>(cp) = o;
+  } else {
+    cp[0] = o.x;
+    if (col + 1 < g.n) cp[1] = o.y;
+    if (col + 2 < g.n) cp[2] = o.z;
+    if (col + 3 < g.n) cp[3] = o.w;
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   const int64_t total = (int64_t)g.m * g.n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -272,6 +385,27 @@ void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream) {
 }
 
 bool gemm_small_m(const GemmArgs& g) { return g.m <= kGemvMaxM; }
+
+bool gemm_skinny_supported(const GemmArgs& g) {
+  return g.m > kGemvMaxM && g.k >= 32 && (g.k & 3) == 0 && (g.lda & 3) == 0 && (g.ldw & 3) == 0 &&
+         ((g.sA1 | g.sA2 | g.sW1 | g.sW2) & 3) == 0 && g.gate == nullptr && g.act_silu_from < 0 && g.a3 == nullptr &&
+         (reinterpret_cast<uintptr_t>(g.a) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.w) & 15) == 0;
+}
+
+void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream) {
+  LRAM_REQUIRE(gemm_skinny_supported(g), "gemm: shape not supported by the few-row kernel");
+  dim3 grid((g.n + 31) / 32, (g.m + 31) / 32, g.nb1 * g.nb2);
+  const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
+  if (hb && hr)
+    hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), grid, dim3(256), 0, stream, g);
+  else if (hb)
+    hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), grid, dim3(256), 0, stream, g);
+  else if (hr)
+    hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), grid, dim3(256), 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), grid, dim3(256), 0, stream, g);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
 
 void launch_gemm_f32(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;

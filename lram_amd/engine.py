@@ -69,6 +69,8 @@ _SYMBOLS = {
                                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "lram_gemm_f32": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                        ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
+    "lram_gemm_skinny": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_bf16x3": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_f16x2": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
@@ -434,7 +436,7 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
     bf16x3 kernel (kernel="bf16x3") the engine uses for its projections."""
     lib = load_library()
     fn = {"f32": lib.lram_gemm_f32, "bf16x3": lib.lram_gemm_bf16x3, "bf16x3_presplit": lib.lram_gemm_bf16x3_presplit,
-          "f16x2": lib.lram_gemm_f16x2}[kernel]
+          "f16x2": lib.lram_gemm_f16x2, "skinny": lib.lram_gemm_skinny}[kernel]
     M, K = a.shape
     N = w.shape[0]
     if out is None:

@@ -41,6 +41,37 @@ def test_gemm_f32_matches_fp64(hip_lib, m, n, k):
     assert (out2.cpu().double() - ref2).abs().max().item() < 2e-6 * k ** 0.5 * 16
 
 
+@pytest.mark.parametrize("m,n,k", [(9, 80, 1536), (96, 2192, 512), (36, 2048, 512), (96, 512, 1024), (192, 2816, 512),
+                                   (33, 130, 36), (100, 513, 1344), (24, 1280, 2560), (63, 5120, 1280), (17, 32, 32)])
+def test_gemm_few_row_kernel_matches_fp64(hip_lib, m, n, k):
+    """gemm_skinny_kernel (9 .. 192 operand rows in the engine): exact fp32 products on the matrix cores, K split over eight
+    lane groups (ragged ranges, clamped loads), ragged 32 x 32 tiles, bias and residual (in place) -- same bar as the
+    k-ordered fp32 kernel."""
+    from lram_amd.engine import gemm_f32
+    g = torch.Generator().manual_seed(m * 11 + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g)
+    bias = torch.randn(n, generator=g)
+    ref = (a.double() @ w.double().t() + bias.double())
+    out = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="skinny")
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-6 * k ** 0.5 * 16, (m, n, k, err)
+    base = torch.randn(m, n, generator=g)
+    out2 = gemm_f32(a.cuda(), w.cuda(), None, out=base.clone().cuda(), accumulate=True, kernel="skinny")
+    torch.cuda.synchronize()
+    ref2 = base.double() + a.double() @ w.double().t()
+    assert (out2.cpu().double() - ref2).abs().max().item() < 2e-6 * k ** 0.5 * 16
+    # a row range of a wider operand (lda > k) and of a wider output (ldc > n), as the engine's slices address them
+    wide_a = torch.randn(m, k + 8, generator=g)
+    wide_c = torch.zeros(m, n + 4).cuda()
+    out3 = gemm_f32(wide_a.cuda()[:, :k], w.cuda(), bias.cuda(), out=wide_c[:, :n], kernel="skinny")
+    torch.cuda.synchronize()
+    ref3 = wide_a[:, :k].double() @ w.double().t() + bias.double()
+    assert (out3.cpu().double() - ref3).abs().max().item() < 2e-6 * k ** 0.5 * 16
+    assert float(wide_c[:, n:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (96, 2192, 512), (300, 80, 1536), (1000, 1408, 512),
                                    (4096, 512, 1024), (5, 8, 8), (257, 129, 48)])
 def test_gemm_bf16x3_matches_fp64(hip_lib, m, n, k):
