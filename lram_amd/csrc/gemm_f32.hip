@@ -235,11 +235,11 @@ __global__ __launch_bounds__(256) void gemv_small_m_kernel(GemmArgs g) {
 // kSkQ float4 per operand per round, the next round's requests issued before the current round's matrix instructions.
 // No LDS staging, no split-K workspace, no second launch; the four partial tiles meet in LDS and leave as 16-byte stores
 // with bias / residual applied.  Same arithmetic class as gemm_f32_kernel (fp32 products, fp32 accumulation).
-constexpr int kSkQ = 8;  // float4 per operand per lane per round (64 VGPRs for the two operands, twice with the prefetch)
-
-template <bool HAS_BIAS, bool HAS_RES>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
-  __shared__ float part[4][32][33];
+// Instances: NW waves x Q float4 per operand per lane and round.  ONE round where it fits -- K <= 256: <4, 8>, K <= 512:
+// <4, 16> (+1..2 % over two rounds) -- else <4, 8> with a second register set for the next round.
+template <bool HAS_BIAS, bool HAS_RES, int NW, int Q, bool MULTI>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmArgs g) {
+  __shared__ float part[NW][32][33];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int z = blockIdx.z;
   const int z1 = z / g.nb2, z2 = z - z1 * g.nb2;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   // lane group (w, lh) owns the float4 indices [q0, q1) of the K axis
   const int nq = g.k >> 2;
-  const int per = (nq + 7) >> 3;
+  const int per = (nq + 2 * NW - 1) / (2 * NW);
   const int grp = 2 * w + lh;
   const int q0 = min(grp * per, nq), q1 = min(q0 + per, nq);
   const float4* ap = reinterpret_cast<const float4*>(A + (int64_t)min(m0 + li, g.m - 1) * g.lda);
@@ -259,20 +259,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float4 av0[kSkQ], bv0[kSkQ], av1[kSkQ], bv1[kSkQ];  // two register sets, named apart: a run-time set index would put them in scratch
+  float4 av0[Q], bv0[Q];
+  float4 av1[MULTI ? Q : 1], bv1[MULTI ? Q : 1];  // second register set, named apart: a run-time set index would put both in scratch
   // unconditional loads at clamped indices (a load under a lane condition costs a branch and a full wait); what lies
   // beyond the lane's range is multiplied by zero
-  auto request = [&](float4 (&av)[kSkQ], float4 (&bv)[kSkQ], int q) {
+  auto request = [&](auto& av, auto& bv, int q) {
 #pragma unroll
-    for (int i = 0; i < kSkQ; ++i) {
+    for (int i = 0; i < Q; ++i) {
       const int qi = min(q + i, nq - 1);
       av[i] = ap[qi];
       bv[i] = bp[qi];
     }
   };
-  auto products = [&](const float4 (&av)[kSkQ], const float4 (&bv)[kSkQ], int q) {
+  auto products = [&](const auto& av, const auto& bv, int q) {
 #pragma unroll
-    for (int i = 0; i < kSkQ; ++i) {
+    for (int i = 0; i < Q; ++i) {
       const float live = (q + i < q1) ? 1.f : 0.f;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x * live, bv[i].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y * live, bv[i].y, acc, 0, 0, 0);
@@ -280,14 +281,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w * live, bv[i].w, acc, 0, 0, 0);
     }
   };
-  // every lane group runs the same number of rounds (the matrix instruction is wave-wide; the groups' ranges differ by
-  // at most one float4)
-  const int rounds = (per + kSkQ - 1) / kSkQ;
   request(av0, bv0, q0);
-  // bias / residual of this thread's four outputs, requested with the first operands
-  const int er = tid >> 3, ec = (tid & 7) << 2;
+  // bias / residual of this thread's outputs, requested with the first operands: 256 threads x 4 outputs cover the tile
+  // (an 8-wave workgroup's upper half only takes part in the products)
+  const int et = tid & 255;
+  const int er = et >> 3, ec = (et & 7) << 2;
   const int row = m0 + er, col = n0 + ec;
-  const bool ok = row < g.m && col < g.n;
+  const bool ok = tid < 256 && row < g.m && col < g.n;
   float4 bz = make_float4(0.f, 0.f, 0.f, 0.f), rz = bz;
   const bool vec = ok && col + 3 < g.n && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
   if (HAS_BIAS && ok) {
@@ -307,36 +307,47 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
       if (col + 3 < g.n) rz.w = rp[3];
     }
   }
-  for (int r = 0; r < rounds; r += 2) {
-    const int q = q0 + r * kSkQ;
-    __builtin_amdgcn_sched_barrier(0);
-    if (r + 1 < rounds) request(av1, bv1, q + kSkQ);
-    __builtin_amdgcn_sched_barrier(0);
-    products(av0, bv0, q);
-    if (r + 1 < rounds) {
+  if (!MULTI) {
+    __builtin_amdgcn_sched_barrier(0);  // every request above is issued before the first matrix instruction
+    products(av0, bv0, q0);
+  } else {
+    // every lane group runs the same number of rounds (the matrix instruction is wave-wide; the groups' ranges differ by
+    // at most one float4)
+    const int rounds = (per + Q - 1) / Q;
+    for (int r = 0; r < rounds; r += 2) {
+      const int q = q0 + r * Q;
       __builtin_amdgcn_sched_barrier(0);
-      if (r + 2 < rounds) request(av0, bv0, q + 2 * kSkQ);
+      if (r + 1 < rounds) request(av1, bv1, q + Q);
       __builtin_amdgcn_sched_barrier(0);
-      products(av1, bv1, q + kSkQ);
+      products(av0, bv0, q);
+      if (r + 1 < rounds) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (r + 2 < rounds) request(av0, bv0, q + 2 * Q);
+        __builtin_amdgcn_sched_barrier(0);
+        products(av1, bv1, q + Q);
+      }
     }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[w][(r & 3) + 8 * (r >> 2) + 4 * lh][li] = acc[r];
   __syncthreads();
   if (!ok) return;
-  float4 o;
-  o.x = ((part[0][er][ec] + part[1][er][ec]) + (part[2][er][ec] + part[3][er][ec]) + bz.x) + rz.x;
-  o.y = ((part[0][er][ec + 1] + part[1][er][ec + 1]) + (part[2][er][ec + 1] + part[3][er][ec + 1]) + bz.y) + rz.y;
-  o.z = ((part[0][er][ec + 2] + part[1][er][ec + 2]) + (part[2][er][ec + 2] + part[3][er][ec + 2]) + bz.z) + rz.z;
-  o.w = ((part[0][er][ec + 3] + part[1][er][ec + 3]) + (part[2][er][ec + 3] + part[3][er][ec + 3]) + bz.w) + rz.w;
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v = (part[0][er][ec + j] + part[1][er][ec + j]) + (part[2][er][ec + j] + part[3][er][ec + j]);
+    if (NW == 8) v += (part[4][er][ec + j] + part[5][er][ec + j]) + (part[6][er][ec + j] + part[7][er][ec + j]);
+    o[j] = v;
+  }
+  o[0] = (o[0] + bz.x) + rz.x, o[1] = (o[1] + bz.y) + rz.y, o[2] = (o[2] + bz.z) + rz.z, o[3] = (o[3] + bz.w) + rz.w;
   float* cp = C + (int64_t)row * g.ldc + col;
   if (vec) {
-    *reinterpret_cast<float4*>(cp) = o;
+    *reinterpret_cast<float4*>(cp) = make_float4(o[0], o[1], o[2], o[3]);
   } else {
-    cp[0] = o.x;
-    if (col + 1 < g.n) cp[1] = o.y;
-    if (col + 2 < g.n) cp[2] = o.z;
-    if (col + 3 < g.n) cp[3] = o.w;
+    cp[0] = o[0];
+    if (col + 1 < g.n) cp[1] = o[1];
+    if (col + 2 < g.n) cp[2] = o[2];
+    if (col + 3 < g.n) cp[3] = o[3];
   }
 }
 
@@ -392,19 +403,34 @@ bool gemm_skinny_supported(const GemmArgs& g) {
          (reinterpret_cast<uintptr_t>(g.a) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.w) & 15) == 0;
 }
 
-void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream) {
-  LRAM_REQUIRE(gemm_skinny_supported(g), "gemm: shape not supported by the few-row kernel");
-  dim3 grid((g.n + 31) / 32, (g.m + 31) / 32, g.nb1 * g.nb2);
+template <int NW, int Q, bool MULTI>
+void launch_gemm_skinny_inst(const GemmArgs& g, hipStream_t stream) {
+  dim3 grid((g.n + 31) / 32, (g.m + 31) / 32, g.nb1 * g.nb2), block(64 * NW);
   const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
   if (hb && hr)
-    hipLaunchKernelGGL((gemm_skinny_kernel<true, true>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_skinny_kernel<true, true, NW, Q, MULTI>), grid, block, 0, stream, g);
   else if (hb)
-    hipLaunchKernelGGL((gemm_skinny_kernel<true, false>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_skinny_kernel<true, false, NW, Q, MULTI>), grid, block, 0, stream, g);
   else if (hr)
-    hipLaunchKernelGGL((gemm_skinny_kernel<false, true>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_skinny_kernel<false, true, NW, Q, MULTI>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_skinny_kernel<false, false>), grid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL((gemm_skinny_kernel<false, false, NW, Q, MULTI>), grid, block, 0, stream, g);
   LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream) {
+  LRAM_REQUIRE(gemm_skinny_supported(g), "gemm: shape not supported by the few-row kernel");
+  // LRAM_GEMM_SKINNY_FORM (measurement knob): 0 = always the multi-round <4, 8> instance, 1 = one round where it fits
+  static const int form = [] {
+    const char* v = std::getenv("LRAM_GEMM_SKINNY_FORM");
+    return v ? std::atoi(v) : 1;
+  }();
+  const int nq = g.k >> 2;
+  if (form == 0) return launch_gemm_skinny_inst<4, 8, true>(g, stream);
+  if ((nq + 7) / 8 <= 8) return launch_gemm_skinny_inst<4, 8, false>(g, stream);
+  if ((nq + 7) / 8 <= 16) return launch_gemm_skinny_inst<4, 16, false>(g, stream);
+  // (an 8-wave instance with one round up to K = 1024 measured slower: Mamba-48M at 16 envs 0.887 -> 0.948 ms)
+  launch_gemm_skinny_inst<4, 8, true>(g, stream);
 }
 
 void launch_gemm_f32(const GemmArgs& g_in, hipStream_t stream) {
