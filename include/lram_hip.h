@@ -255,7 +255,7 @@ int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, in
                          int32_t k, void* stream);
 /* Same contract through the few-row kernel (gemm_f32.hip::gemm_skinny_kernel: one 32 x 32 tile of the exact fp32 matrix
  * instruction per workgroup, K split over the waves, operands straight into registers; the engine takes it for GEMMs of
- * 9 .. 192 operand rows).  m > 8, k >= 32, k / lda / ldw multiples of 4, 16-byte aligned operands.  Test entry. */
+ * 9 .. 384 operand rows and K <= 1024).  k >= 32, k / lda / ldw multiples of 4, 16-byte aligned operands.  Test entry. */
 int32_t lram_gemm_skinny(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                          int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                          int32_t k, void* stream);

@@ -151,6 +151,7 @@ struct lram_engine {
                                // x 128 / head dim) take the one-launch sLSTM token kernel (0 = never)
   int slstm_fused_min = 1;     // LRAM_SLSTM_FUSED_MIN
   int gemm_skinny_rows = 384;  // LRAM_GEMM_SKINNY_ROWS: GEMMs with 9 .. this many operand rows (half of it for weights above 600k elements) ...
+  int gemm_skinny_min = 5;     // LRAM_GEMM_SKINNY_MIN: fewest operand rows (below: the GEMV path; 16M at 1 env 0.372 vs 0.410 ms, at 2 envs 0.443 vs 0.418)
   int gemm_skinny_k = 1024;    // LRAM_GEMM_SKINNY_K: ... and K up to this take the few-row kernel (rows 0 = never)
   int stream_prio = 0;      // LRAM_STREAM_PRIO: 1 slice streams highest / state-pass stream lowest priority, 2 slices highest only,
                             // 3 the reverse of 1 (measured: see profiles/EXPERIMENTS.md)
@@ -779,7 +780,7 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
   // envs) -- and up to 192 operand rows, 384 for weights of at most 600k elements (every 32-row tile re-reads the weight).
   // 16M at 4 / 12 / 32 / 64 / 128 envs: +17 / +17 / +16 / +12 / +10 %; C1 (2 blocks, D = 128) at 32 envs: 0.130 -> 0.093 ms.
   const bool skinny_shape = g.k <= e->gemm_skinny_k && (g.m <= e->gemm_skinny_rows / 2 || (int64_t)g.n * g.k <= 600000);
-  if (g.m <= e->gemm_skinny_rows && skinny_shape && gemm_skinny_supported(g)) {
+  if (g.m >= e->gemm_skinny_min && g.m <= e->gemm_skinny_rows && skinny_shape && gemm_skinny_supported(g)) {
     launch_gemm_skinny(g, s);
     return;
   }
@@ -1707,6 +1708,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_MIN")) e->slstm_fused_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_ROWS")) e->gemm_skinny_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_K")) e->gemm_skinny_k = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_MIN")) e->gemm_skinny_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_STREAM_PRIO")) e->stream_prio = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_FOLD_FUSED")) e->fold_fused = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_FUSED_STREAM")) e->fold_fused_stream = std::atoi(v) != 0;

@@ -398,7 +398,7 @@ void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream) {
 bool gemm_small_m(const GemmArgs& g) { return g.m <= kGemvMaxM; }
 
 bool gemm_skinny_supported(const GemmArgs& g) {
-  return g.m > kGemvMaxM && g.k >= 32 && (g.k & 3) == 0 && (g.lda & 3) == 0 && (g.ldw & 3) == 0 &&
+  return g.m >= 1 && g.k >= 32 && (g.k & 3) == 0 && (g.lda & 3) == 0 && (g.ldw & 3) == 0 &&
          ((g.sA1 | g.sA2 | g.sW1 | g.sW2) & 3) == 0 && g.gate == nullptr && g.act_silu_from < 0 && g.a3 == nullptr &&
          (reinterpret_cast<uintptr_t>(g.a) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.w) & 15) == 0;
 }
