@@ -79,6 +79,13 @@ struct GemmArgs {
   // slabs are written by S x tiles workgroups and summed, in fixed order, by a second tiny kernel (deterministic)
   float* splitk_ws = nullptr;
   int64_t splitk_ws_elems = 0;
+  // optional (few-row kernel, K <= 512): A is the UN-normalised input; every workgroup normalises its 32 rows in registers
+  // before the products -- LayerNorm (x - mean) / sqrt(var + eps) * norm_g (+ norm_b), biased variance, two pass; RMSNorm
+  // x * rsqrt(mean(x^2) + eps) * norm_g -- as row_norm_kernel does: no norm launch, no [rows, K] round trip
+  const float* norm_g = nullptr;
+  const float* norm_b = nullptr;
+  float norm_eps = 0.f;
+  int norm_rms = 0;
   int mfma_prio = 0;      // set by the launcher (LRAM_GEMM_PRIO): raise the wave's issue priority around the MFMA block
   int split_k = 1;        // set by the launcher
   int k_tiles_per_split = 0;
@@ -88,6 +95,7 @@ void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream);  // C = sum_s 
 void launch_gemm_f32(const GemmArgs& g, hipStream_t stream);      // exact fp32 MFMA (k-ordered fma chain)
 bool gemm_small_m(const GemmArgs& g);                             // M <= 8: launch_gemm_f32 takes the GEMV path
 bool gemm_skinny_supported(const GemmArgs& g);                    // few-row kernel: 32 x 32 fp32 MFMA tile per workgroup, K over the waves
+bool gemm_skinny_norm_supported(const GemmArgs& g);               // ... with the row norm of A in its prologue (K <= 512)
 void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream);
 bool gemm_bf16x3_supported(const GemmArgs& g);
 void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t stream);   // fp32-accurate, 3 x bf16 split operands

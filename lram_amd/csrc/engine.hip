@@ -151,6 +151,7 @@ struct lram_engine {
                                // x 128 / head dim) take the one-launch sLSTM token kernel (0 = never)
   int slstm_fused_min = 1;     // LRAM_SLSTM_FUSED_MIN
   int gemm_skinny_rows = 384;  // LRAM_GEMM_SKINNY_ROWS: GEMMs with 9 .. this many operand rows (half of it for weights above 600k elements) ...
+  bool gemm_skinny_norm = true;  // LRAM_GEMM_SKINNY_NORM: the row norm ahead of proj_up / ffn_up inside the few-row kernel's prologue
   int gemm_skinny_min = 5;     // LRAM_GEMM_SKINNY_MIN: fewest operand rows (below: the GEMV path; 16M at 1 env 0.372 vs 0.410 ms, at 2 envs 0.443 vs 0.418)
   int gemm_skinny_k = 1024;    // LRAM_GEMM_SKINNY_K: ... and K up to this take the few-row kernel (rows 0 = never)
   int stream_prio = 0;      // LRAM_STREAM_PRIO: 1 slice streams highest / state-pass stream lowest priority, 2 slices highest only,
@@ -734,6 +735,17 @@ void state_alloc(lram_engine* e, int B) {
 // ---------------------------------------------------------------------------------------------
 // block stack on X [B*T, D] (in place residual stream) -> HID [B*T, D]
 // ---------------------------------------------------------------------------------------------
+// The few-row kernel's share of the dispatch (see gemm()).
+bool takes_skinny(const lram_engine* e, const GemmArgs& g) {
+  const bool shape = g.k <= e->gemm_skinny_k && (g.m <= e->gemm_skinny_rows / 2 || (int64_t)g.n * g.k <= 600000);
+  return g.m >= e->gemm_skinny_min && g.m <= e->gemm_skinny_rows && shape && gemm_skinny_supported(g);
+}
+// ... and may the norm ahead of this projection move into its prologue?  (Then the caller skips the norm launch and hands
+// the un-normalised rows over with norm_g / norm_b / norm_eps / norm_rms set.)
+bool takes_skinny_with_norm(const lram_engine* e, const GemmArgs& g) {
+  return e->gemm_skinny_norm && takes_skinny(e, g) && gemm_skinny_norm_supported(g);
+}
+
 // GEMM dispatch: bf16x3 (fp32-accurate on the bf16 matrix cores) when the weight has split planes and the shape
 // allows 16-byte bf16 loads, else the exact fp32-MFMA kernel.
 void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
@@ -779,8 +791,7 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
   // over workgroups (Mamba x_proj / out_proj, K = 1536: -3 % each at 32 envs; the 206M stack's K = 1280 / 2560: -7 % at 64
   // envs) -- and up to 192 operand rows, 384 for weights of at most 600k elements (every 32-row tile re-reads the weight).
   // 16M at 4 / 12 / 32 / 64 / 128 envs: +17 / +17 / +16 / +12 / +10 %; C1 (2 blocks, D = 128) at 32 envs: 0.130 -> 0.093 ms.
-  const bool skinny_shape = g.k <= e->gemm_skinny_k && (g.m <= e->gemm_skinny_rows / 2 || (int64_t)g.n * g.k <= 600000);
-  if (g.m >= e->gemm_skinny_min && g.m <= e->gemm_skinny_rows && skinny_shape && gemm_skinny_supported(g)) {
+  if (takes_skinny(e, g)) {
     launch_gemm_skinny(g, s);
     return;
   }
@@ -946,17 +957,23 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   BlockState& st = e->st[i];
   const bool a3 = a3_for(e, w.proj_up, rows, D, D);  // the norm then writes the GEMM's operand planes, no fp32 copy
   float* amx = e->use_f16x2 ? e->AMX_XN.p + r0 : nullptr;  // the norm hands proj_up's operand row maxima over
-  launch_row_norm(e->X.p + r0 * D, D, a3 ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
-                  c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, amx);
   // proj_up in two halves: the x_m half feeds the conv / q / k / v front end and is on the block's critical path; the
   // z half is only needed by the output gate after the state pass and is issued beside it (mlstm_up_z)
   GemmArgs up;
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p + r0 * e->ucols, up.ldc = 2 * inner;
   up.m = rows, up.n = split_up_now(e) ? inner : 2 * inner, up.k = D;
-  up.a_amax = amx;
-  if (a3) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
   if (gn_fused(e, T) && !split_up_now(e)) up.act_silu_from = inner;  // the z half is stored as silu(z)
-  gemm(e, up, sl.s);
+  if (!a3 && !split_up_now(e) && takes_skinny_with_norm(e, up)) {
+    // few rows: the norm runs in the projection's prologue (each workgroup normalises its 32 rows in registers)
+    up.a = e->X.p + r0 * D, up.norm_g = w.norm_g, up.norm_b = w.norm_b, up.norm_eps = c.ln_eps, up.norm_rms = c.norm_is_rms;
+    launch_gemm_skinny(up, sl.s);
+  } else {
+    launch_row_norm(e->X.p + r0 * D, D, a3 ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
+                    c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, amx);
+    up.a_amax = amx;
+    if (a3) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
+    gemm(e, up, sl.s);
+  }
   MlstmPreArgs pa;
   pa.u = e->U.p + r0 * e->ucols, pa.conv_state = st.conv.p + b0 * c.conv_k * inner, pa.n_state = st.n.p + b0 * inner;
   pa.m_state = st.m.p + b0 * NH;
@@ -1103,11 +1120,17 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   gn.mode = 1, gn.eps = c.ln_eps, gn.skip = nullptr, gn.xa = nullptr, gn.u = nullptr;
   launch_group_norm(gn, s);
   float* amx = e->use_f16x2 ? e->AMX_XN.p + r0 : nullptr;
-  launch_row_norm(X, D, XN, D, w.ffn_norm_g, w.ffn_norm_b, rows, D, c.ln_eps, c.norm_is_rms, s, nullptr, nullptr, 0, amx);
   GemmArgs up;
   up.a = XN, up.lda = D, up.w = w.ffn_up, up.ldw = D, up.c = Ubuf, up.ldc = 2 * F;
-  up.m = rows, up.n = 2 * F, up.k = D, up.a_amax = amx;
-  gemm(e, up, s);
+  up.m = rows, up.n = 2 * F, up.k = D;
+  if (takes_skinny_with_norm(e, up)) {  // few rows: the FFN's norm inside the projection's prologue
+    up.a = X, up.norm_g = w.ffn_norm_g, up.norm_b = w.ffn_norm_b, up.norm_eps = c.ln_eps, up.norm_rms = c.norm_is_rms;
+    launch_gemm_skinny(up, s);
+  } else {
+    launch_row_norm(X, D, XN, D, w.ffn_norm_g, w.ffn_norm_b, rows, D, c.ln_eps, c.norm_is_rms, s, nullptr, nullptr, 0, amx);
+    up.a_amax = amx;
+    gemm(e, up, s);
+  }
   launch_gelu_gate(Ubuf, Gbuf, rows, F, s);
   GemmArgs dn;
   dn.a = Gbuf, dn.lda = F, dn.w = w.ffn_down, dn.ldw = F, dn.c = X, dn.ldc = D, dn.residual = X;
@@ -1708,6 +1731,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_MIN")) e->slstm_fused_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_ROWS")) e->gemm_skinny_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_K")) e->gemm_skinny_k = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_NORM")) e->gemm_skinny_norm = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_MIN")) e->gemm_skinny_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_STREAM_PRIO")) e->stream_prio = std::max(0, std::min(3, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_FOLD_FUSED")) e->fold_fused = std::atoi(v) != 0;

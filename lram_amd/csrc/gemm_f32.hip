@@ -237,9 +237,11 @@ __global__ __launch_bounds__(256) void gemv_small_m_kernel(GemmArgs g) {
 // with bias / residual applied.  Same arithmetic class as gemm_f32_kernel (fp32 products, fp32 accumulation).
 // Instances: NW waves x Q float4 per operand per lane and round.  ONE round where it fits -- K <= 256: <4, 8>, K <= 512:
 // <4, 16> (+1..2 % over two rounds) -- else <4, 8> with a second register set for the next round.
-template <bool HAS_BIAS, bool HAS_RES, int NW, int Q, bool MULTI>
+template <bool HAS_BIAS, bool HAS_RES, int NW, int Q, bool MULTI, bool NORM = false>
 __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmArgs g) {
+  static_assert(!(NORM && MULTI), "the norm prologue needs the whole row slice in registers");
   __shared__ float part[NW][32][33];
+  __shared__ float stat[NORM ? 2 * NW : 1][32];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int z = blockIdx.z;
   const int z1 = z / g.nb2, z2 = z - z1 * g.nb2;
@@ -308,7 +310,55 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmArgs g) {
     }
   }
   if (!MULTI) {
-    __builtin_amdgcn_sched_barrier(0);  // every request above is issued before the first matrix instruction
+    float4 gv[NORM ? Q : 1], ov[NORM ? Q : 1];
+    if (NORM) {  // norm weights of the lane's K range (the same for every row: 32 lanes share an address)
+      const float4* gp = reinterpret_cast<const float4*>(g.norm_g);
+      const float4* op = reinterpret_cast<const float4*>(g.norm_b);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const int qi = min(q0 + i, nq - 1);
+        gv[i] = gp[qi];
+        ov[i] = op != nullptr ? op[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every request above is issued before the first use
+    if (NORM) {
+      // row statistics over the 2 * NW lane groups: two passes (mean, then centred squares), as row_norm_kernel
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < Q; ++i)
+        if (q0 + i < q1) s1 += (av0[i].x + av0[i].y) + (av0[i].z + av0[i].w);
+      stat[grp][li] = s1;
+      __syncthreads();
+      float mean = 0.f;
+      if (!g.norm_rms) {
+#pragma unroll
+        for (int x = 0; x < 2 * NW; ++x) mean += stat[x][li];
+        mean /= (float)g.k;
+      }
+      __syncthreads();
+      float s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < Q; ++i)
+        if (q0 + i < q1) {
+          const float dx = av0[i].x - mean, dy = av0[i].y - mean, dz = av0[i].z - mean, dw = av0[i].w - mean;
+          s2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+      stat[grp][li] = s2;
+      __syncthreads();
+      float var = 0.f;
+#pragma unroll
+      for (int x = 0; x < 2 * NW; ++x) var += stat[x][li];
+      var /= (float)g.k;
+      const float rstd = g.norm_rms ? rsqrtf(var + g.norm_eps) : 1.f / sqrtf(var + g.norm_eps);
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        av0[i].x = (av0[i].x - mean) * rstd * gv[i].x + ov[i].x;
+        av0[i].y = (av0[i].y - mean) * rstd * gv[i].y + ov[i].y;
+        av0[i].z = (av0[i].z - mean) * rstd * gv[i].z + ov[i].z;
+        av0[i].w = (av0[i].w - mean) * rstd * gv[i].w + ov[i].w;
+      }
+    }
     products(av0, bv0, q0);
   } else {
     // every lane group runs the same number of rounds (the matrix instruction is wave-wide; the groups' ranges differ by
@@ -407,6 +457,14 @@ template <int NW, int Q, bool MULTI>
 void launch_gemm_skinny_inst(const GemmArgs& g, hipStream_t stream) {
   dim3 grid((g.n + 31) / 32, (g.m + 31) / 32, g.nb1 * g.nb2), block(64 * NW);
   const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
+  if constexpr (!MULTI) {
+    if (g.norm_g != nullptr) {  // (the projections that follow a norm have neither bias nor residual)
+      LRAM_REQUIRE(!hb && !hr && g.nb1 * g.nb2 == 1, "gemm: the norm prologue serves un-batched GEMMs without bias / residual");
+      hipLaunchKernelGGL((gemm_skinny_kernel<false, false, NW, Q, false, true>), grid, block, 0, stream, g);
+      LRAM_HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   if (hb && hr)
     hipLaunchKernelGGL((gemm_skinny_kernel<true, true, NW, Q, MULTI>), grid, block, 0, stream, g);
   else if (hb)
@@ -418,15 +476,21 @@ void launch_gemm_skinny_inst(const GemmArgs& g, hipStream_t stream) {
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
+bool gemm_skinny_norm_supported(const GemmArgs& g) {
+  return gemm_skinny_supported(g) && (((g.k >> 2) + 7) / 8) <= 16 && g.bias == nullptr && g.residual == nullptr &&
+         g.nb1 * g.nb2 == 1;
+}
+
 void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream) {
   LRAM_REQUIRE(gemm_skinny_supported(g), "gemm: shape not supported by the few-row kernel");
+  LRAM_REQUIRE(g.norm_g == nullptr || gemm_skinny_norm_supported(g), "gemm: norm prologue needs K <= 512, no bias / residual / batch");
   // LRAM_GEMM_SKINNY_FORM (measurement knob): 0 = always the multi-round <4, 8> instance, 1 = one round where it fits
   static const int form = [] {
     const char* v = std::getenv("LRAM_GEMM_SKINNY_FORM");
     return v ? std::atoi(v) : 1;
   }();
   const int nq = g.k >> 2;
-  if (form == 0) return launch_gemm_skinny_inst<4, 8, true>(g, stream);
+  if (form == 0 && g.norm_g == nullptr) return launch_gemm_skinny_inst<4, 8, true>(g, stream);
   if ((nq + 7) / 8 <= 8) return launch_gemm_skinny_inst<4, 8, false>(g, stream);
   if ((nq + 7) / 8 <= 16) return launch_gemm_skinny_inst<4, 16, false>(g, stream);
   // (an 8-wave instance with one round up to K = 1024 measured slower: Mamba-48M at 16 envs 0.887 -> 0.948 ms)
