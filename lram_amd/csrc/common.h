@@ -114,10 +114,16 @@ void launch_split_f16x2(const float* w, int rows, int k, uint16_t* planes, float
 // out[r, :] = norm(in[r, :]) * gamma (+ beta);  rms != 0 -> RMSNorm (no mean subtraction).
 // (out2: optional second copy of the result, same row stride as out)
 // (amax: optional [rows] largest output magnitude per row, the f16x2 GEMM's a_amax)
+// scalar tokens built inside the norm launch (token front end of one timestep): rows b * T + 1 / + 2 = Linear(1, D) of rtg[b] / rew[b]
+struct ScalarTokens {
+  const float *rtg = nullptr, *rew = nullptr, *w_rtg = nullptr, *b_rtg = nullptr, *w_rew = nullptr, *b_rew = nullptr;
+  int64_t in_stride = 1;
+  int T = 3;
+};
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2 = nullptr,
                      uint16_t* planes = nullptr, int64_t plane_stride = 0,   // planes: bf16x3 GEMM operand (row stride
-                     float* amax = nullptr);                                 // out_stride); out may then be null
+                     float* amax = nullptr, const ScalarTokens* st = nullptr);                                 // out_stride); out may then be null
 // Mamba block entry: res_out = hidden (+ res_in);  normed = RMSNorm(res_out) * gamma.
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
                          const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes = nullptr,

@@ -151,6 +151,7 @@ struct lram_engine {
                                // x 128 / head dim) take the one-launch sLSTM token kernel (0 = never)
   int slstm_fused_min = 1;     // LRAM_SLSTM_FUSED_MIN
   int gemm_skinny_rows = 384;  // LRAM_GEMM_SKINNY_ROWS: GEMMs with 9 .. this many operand rows (half of it for weights above 600k elements) ...
+  bool embed_fuse = true;        // LRAM_EMBED_FUSE: the scalar-token embeddings inside the embed_ln launch (single timesteps)
   bool gemm_skinny_norm = true;  // LRAM_GEMM_SKINNY_NORM: the row norm ahead of proj_up / ffn_up inside the few-row kernel's prologue
   int gemm_skinny_min = 5;     // LRAM_GEMM_SKINNY_MIN: fewest operand rows (below: the GEMV path; 16M at 1 env 0.372 vs 0.410 ms, at 2 envs 0.443 vs 0.418)
   int gemm_skinny_k = 1024;    // LRAM_GEMM_SKINNY_K: ... and K up to this take the few-row kernel (rows 0 = never)
@@ -1602,12 +1603,21 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
           ge.ldc = (int64_t)Tc * D, ge.bias = e->b_state, ge.m = x.nb, ge.n = D, ge.k = c.state_dim;
           gemm(e, ge, x.s);
         }
-        launch_embed_scalars(Xj, rtg + b0 * L + l + j, rew + b0 * L + l + j, L, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew,
-                             x.nb, Tc, D, x.s);
+        // (a single timestep per call: the scalar tokens are built by the embed_ln launch below)
+        if (Lc > 1 || T != 3 || !e->embed_fuse)
+          launch_embed_scalars(Xj, rtg + b0 * L + l + j, rew + b0 * L + l + j, L, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew,
+                               x.nb, Tc, D, x.s);
       }
       // embed_ln in place; single env-steps of small batches also keep a copy for lram_get_taps (written by the same launch)
+      ScalarTokens stok;
+      const bool stok_on = Lc == 1 && T == 3 && e->embed_fuse;
+      if (stok_on) {
+        stok.rtg = rtg + b0 * L + l, stok.rew = rew + b0 * L + l, stok.in_stride = L, stok.T = T;
+        stok.w_rtg = e->w_rtg, stok.b_rtg = e->b_rtg, stok.w_rew = e->w_rew, stok.b_rew = e->b_rew;
+      }
       launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s,
-                      (L == 1 && e->B <= kTokenTapMaxBatch) ? e->TOK.p + r0 * D : nullptr);
+                      (L == 1 && e->B <= kTokenTapMaxBatch) ? e->TOK.p + r0 * D : nullptr, nullptr, 0, nullptr,
+                      stok_on ? &stok : nullptr);
     }
     run_stack(e, Tc, l == 0 ? reset : nullptr, sl, hbm);
   }
@@ -1731,6 +1741,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_MIN")) e->slstm_fused_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_ROWS")) e->gemm_skinny_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_K")) e->gemm_skinny_k = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_EMBED_FUSE")) e->embed_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_NORM")) e->gemm_skinny_norm = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_MIN")) e->gemm_skinny_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_STREAM_PRIO")) e->stream_prio = std::max(0, std::min(3, std::atoi(v)));

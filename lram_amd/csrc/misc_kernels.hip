@@ -17,21 +17,39 @@ constexpr int kNormMaxV = 8;  // float4 per lane: d <= 2048
 
 // One wave per row.  LayerNorm: (x - mean) / sqrt(var + eps) * gamma + beta (biased variance, two pass);
 // RMSNorm: gamma * (x * rsqrt(mean(x^2) + eps)).
+// st.rtg given (the token front end of a single timestep): rows with token index 1 / 2 are not read but built here as
+// Linear(1, D) of the env's return-to-go / reward (embed_rtg / embed_rewards, online_decision_transformer_model.py:509-521),
+// so the scalar embeddings need no launch of their own.
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t in_stride, float* out,
                                                        int64_t out_stride, const float* gamma, const float* beta,
                                                        int rows, int d, float eps, int rms, float* out2,
-                                                       uint16_t* planes, int64_t plane_stride, float* amax) {
+                                                       uint16_t* planes, int64_t plane_stride, float* amax,
+                                                       ScalarTokens st) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nv = d >> 2;
   const float* src = in + (int64_t)row * in_stride;
+  int tok = 0;
+  float sx = 0.f;
+  const float *sw = nullptr, *sb = nullptr;
+  if (st.rtg != nullptr) {
+    const int b = row / st.T;
+    tok = row - b * st.T;
+    if (tok == 1) sx = st.rtg[(int64_t)b * st.in_stride], sw = st.w_rtg, sb = st.b_rtg;
+    if (tok == 2) sx = st.rew[(int64_t)b * st.in_stride], sw = st.w_rew, sb = st.b_rew;
+  }
   float4 v[kNormMaxV];
   float s = 0.f;
 #pragma unroll
   for (int j = 0; j < kNormMaxV; ++j) {
     const int i = lane + 64 * j;
-    v[j] = i < nv ? *reinterpret_cast<const float4*>(src + 4 * i) : f4_zero();
+    if (sw != nullptr && i < nv) {  // (wave-uniform branch: one row per wave)
+      const float4 w4 = *reinterpret_cast<const float4*>(sw + 4 * i), b4 = *reinterpret_cast<const float4*>(sb + 4 * i);
+      v[j] = make_float4(sx * w4.x + b4.x, sx * w4.y + b4.y, sx * w4.z + b4.z, sx * w4.w + b4.w);
+    } else {
+      v[j] = i < nv ? *reinterpret_cast<const float4*>(src + 4 * i) : f4_zero();
+    }
     s += v[j].x + v[j].y + v[j].z + v[j].w;
   }
   const float mean = rms ? 0.f : wave_sum(s) / (float)d;
@@ -294,10 +312,10 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* buf, const uint8_
 
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2,
-                     uint16_t* planes, int64_t plane_stride, float* amax) {
+                     uint16_t* planes, int64_t plane_stride, float* amax, const ScalarTokens* st) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "row norm: d must be a multiple of 4 and <= 2048");
   hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, in_stride, out, out_stride,
-                     gamma, beta, rows, d, eps, rms, out2, planes, plane_stride, amax);
+                     gamma, beta, rows, d, eps, rms, out2, planes, plane_stride, amax, st ? *st : ScalarTokens());
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
