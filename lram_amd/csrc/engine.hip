@@ -151,6 +151,7 @@ struct lram_engine {
                                // x 128 / head dim) take the one-launch sLSTM token kernel (0 = never)
   int slstm_fused_min = 1;     // LRAM_SLSTM_FUSED_MIN
   int gemm_skinny_rows = 384;  // LRAM_GEMM_SKINNY_ROWS: GEMMs with 9 .. this many operand rows (half of it for weights above 600k elements) ...
+  bool slstm_gates_one = true;   // LRAM_SLSTM_GATES_ONE: the four sLSTM gate projections as one few-row GEMM launch (operand tables)
   bool embed_fuse = true;        // LRAM_EMBED_FUSE: the scalar-token embeddings inside the embed_ln launch (single timesteps)
   bool gemm_skinny_norm = true;  // LRAM_GEMM_SKINNY_NORM: the row norm ahead of proj_up / ffn_up inside the few-row kernel's prologue
   int gemm_skinny_min = 5;     // LRAM_GEMM_SKINNY_MIN: fewest operand rows (below: the GEMV path; 16M at 1 env 0.372 vs 0.410 ms, at 2 envs 0.443 vs 0.418)
@@ -1081,13 +1082,22 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   sa.conv_b = w.conv_b, sa.xc = XC, sa.reset = reset ? reset + b0 : nullptr, sa.B = sl.nb, sa.T = T, sa.D = D;
   sa.K = c.conv_k, sa.state_B = e->B;
   launch_slstm_conv(sa, s);
-  for (int g = 0; g < 4; ++g) {
-    GemmArgs ga;
-    ga.a = (g < 2) ? XC : XN, ga.lda = D, ga.sA1 = SDH;
-    ga.w = w.gate_w[g], ga.ldw = SDH, ga.sW1 = (int64_t)SDH * SDH;
-    ga.c = gates + (int64_t)g * Hs, ga.ldc = 4 * Hs, ga.sC1 = SDH;
-    ga.m = rows, ga.n = SDH, ga.k = SDH, ga.nb1 = NH;
-    gemm(e, ga, s);
+  GemmArgs g4;  // few rows: the four gate projections (per-head blocks, i / f on the conv branch, z / o on the norm) as ONE launch
+  g4.a = XC, g4.lda = D, g4.sA1 = SDH, g4.w = w.gate_w[0], g4.ldw = SDH, g4.sW1 = (int64_t)SDH * SDH;
+  g4.c = gates, g4.ldc = 4 * Hs, g4.sC1 = SDH, g4.m = rows, g4.n = SDH, g4.k = SDH, g4.nb1 = NH, g4.nb2 = 4;
+  if (e->slstm_gates_one && takes_skinny(e, g4)) {
+    for (int g = 0; g < 4; ++g)
+      g4.a_tab[g] = (g < 2) ? XC : XN, g4.w_tab[g] = w.gate_w[g], g4.c_tab[g] = gates + (int64_t)g * Hs;
+    launch_gemm_skinny(g4, s);
+  } else {
+    for (int g = 0; g < 4; ++g) {
+      GemmArgs ga;
+      ga.a = (g < 2) ? XC : XN, ga.lda = D, ga.sA1 = SDH;
+      ga.w = w.gate_w[g], ga.ldw = SDH, ga.sW1 = (int64_t)SDH * SDH;
+      ga.c = gates + (int64_t)g * Hs, ga.ldc = 4 * Hs, ga.sC1 = SDH;
+      ga.m = rows, ga.n = SDH, ga.k = SDH, ga.nb1 = NH;
+      gemm(e, ga, s);
+    }
   }
   // few env rows (slstm_fused_min .. slstm_fused_rows): recurrent projection + pointwise cell as ONE lean launch per token instead of a
   // batched matrix-core GEMM (fixed latency of a 128-row tile) and the pointwise kernel
@@ -1741,6 +1751,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_MIN")) e->slstm_fused_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_ROWS")) e->gemm_skinny_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_K")) e->gemm_skinny_k = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_SLSTM_GATES_ONE")) e->slstm_gates_one = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_EMBED_FUSE")) e->embed_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_NORM")) e->gemm_skinny_norm = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_MIN")) e->gemm_skinny_min = std::max(1, std::atoi(v));

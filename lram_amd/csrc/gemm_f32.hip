@@ -245,9 +245,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
   const int z = blockIdx.z;
   const int z1 = z / g.nb2, z2 = z - z1 * g.nb2;
-  const float* A = g.a + z1 * g.sA1 + z2 * g.sA2;
-  const float* W = g.w + z1 * g.sW1 + z2 * g.sW2;
-  float* C = g.c + z1 * g.sC1 + z2 * g.sC2;
+  const bool tab = g.a_tab[0] != nullptr;
+  const float* A = tab ? g.a_tab[z2] + z1 * g.sA1 : g.a + z1 * g.sA1 + z2 * g.sA2;
+  const float* W = tab ? g.w_tab[z2] + z1 * g.sW1 : g.w + z1 * g.sW1 + z2 * g.sW2;
+  float* C = tab ? g.c_tab[z2] + z1 * g.sC1 : g.c + z1 * g.sC1 + z2 * g.sC2;
   const float* R = HAS_RES ? g.residual + z1 * g.sC1 + z2 * g.sC2 : nullptr;
   const float* bias = HAS_BIAS ? g.bias + z1 * g.sBias1 + z2 * g.sBias2 : nullptr;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
