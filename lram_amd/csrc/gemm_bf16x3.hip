@@ -303,8 +303,17 @@ void launch_gemm_bf16x3(const GemmArgs& g_in, hipStream_t stream) {
     const char* v = std::getenv("LRAM_GEMM_BM");
     return v ? std::atoi(v) : 0;
   }();
-  const bool small = force_bm == 64 || (force_bm == 0 && S == 1 && g.nb1 * g.nb2 == 1 && tiles128 < 512 && tiles_n <= 4 &&
-                                        g.m > 64);
+  // ... and every GEMM of at most LRAM_BF16_BM64_ROWS operand rows (default 1024: slices of up to 341 envs, where a step is a
+  // chain of short launches and twice the workgroups per launch shorten each: 16M at 192 / 256 / 341 envs +1.6 / +2.1 / +6 %,
+  // Mamba-48M at 64 / 256 envs +4.7 / +7.3 %; weights above 2.5M elements -- the 206M stack -- keep the 128-row tile's reuse:
+  // 128 envs -3.8 % otherwise)
+  static const int bm64_rows = [] {
+    const char* v = std::getenv("LRAM_BF16_BM64_ROWS");
+    return v ? std::atoi(v) : 1024;
+  }();
+  const bool small = force_bm == 64 || (force_bm == 0 && g.m > 64 &&
+                                        ((S == 1 && g.nb1 * g.nb2 == 1 && tiles128 < 512 && tiles_n <= 4) ||
+                                         (g.m <= bm64_rows && (int64_t)g.n * g.k <= 2500000)));
   const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;
   dim3 grid(tiles, g.nb1 * g.nb2, S);
   if (g.gate != nullptr) {
