@@ -485,6 +485,14 @@ bool gemm_skinny_norm_supported(const GemmArgs& g) {
 void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream) {
   LRAM_REQUIRE(gemm_skinny_supported(g), "gemm: shape not supported by the few-row kernel");
   LRAM_REQUIRE(g.norm_g == nullptr || gemm_skinny_norm_supported(g), "gemm: norm prologue needs K <= 512, no bias / residual / batch");
+  if (g.a_tab[0] != nullptr) {
+    LRAM_REQUIRE(g.nb2 >= 1 && g.nb2 <= 4 && g.bias == nullptr && g.residual == nullptr,
+                 "gemm: operand tables serve up to four projections without bias / residual");
+    for (int i = 0; i < g.nb2; ++i)
+      LRAM_REQUIRE(g.a_tab[i] != nullptr && g.w_tab[i] != nullptr && g.c_tab[i] != nullptr &&
+                       ((reinterpret_cast<uintptr_t>(g.a_tab[i]) | reinterpret_cast<uintptr_t>(g.w_tab[i])) & 15) == 0,
+                   "gemm: operand tables need 16-byte aligned operands for every entry");
+  }
   // LRAM_GEMM_SKINNY_FORM (measurement knob): 0 = always the multi-round <4, 8> instance, 1 = one round where it fits
   static const int form = [] {
     const char* v = std::getenv("LRAM_GEMM_SKINNY_FORM");
