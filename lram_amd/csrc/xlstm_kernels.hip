@@ -40,7 +40,11 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
   const int inner = a.inner;
   const int DH = inner / NH;
   const int ngroups = inner >> 2;
-  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+  // (the flag is read through a pointer select, not under a branch on a.reset: a conditional load is waited for on the
+  // spot, ahead of every other request of the workgroup)
+  const uint8_t* rsp = a.reset != nullptr ? a.reset + b : reinterpret_cast<const uint8_t*>(a.conv_w);
+  const uint8_t rsb = *rsp;
+  const bool rs = a.reset != nullptr && rsb != 0;
 
   float pi[T][NH], pf[T][NH];
 #pragma unroll
@@ -51,7 +55,15 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
   // phase 3 and the recurrent scalars / the normaliser state are requested before the block reductions instead of after
   // them -- one dependent memory round trip per workgroup instead of three (beside a read pass each costs microseconds).
   constexpr bool single = SINGLE;  // the launcher guarantees ngroups <= kPreThreads
-  const float m_pre = (single && tid < NH && !rs) ? a.m_state[(int64_t)b * NH + tid] : 0.f;
+  // (state is requested whether or not the env restarts and zeroed afterwards: a load that waits for the reset flag's own
+  // round trip puts one more dependent memory round trip at the head of every workgroup)
+  // (zeroed by a bit mask, not a branch or a multiply: no control flow on the flag -- the compiler otherwise waits for it
+  // before issuing anything else -- and no NaN * 0)
+  auto masked = [](float v, unsigned keep) { return __uint_as_float(__float_as_uint(v) & keep); };
+  auto masked4 = [&](const float4& v, unsigned keep) {
+    return make_float4(masked(v.x, keep), masked(v.y, keep), masked(v.z, keep), masked(v.w, keep));
+  };
+  float m_pre = single ? a.m_state[(int64_t)b * NH + min(tid, NH - 1)] : 0.f;  // (every lane: no branch; masked below)
   float4 q_keep[T], k_keep[T], n_pre = f4_zero();
 #pragma unroll
   for (int t = 0; t < T; ++t) q_keep[t] = k_keep[t] = f4_zero();
@@ -63,8 +75,9 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
     float4 win[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      win[k] = (rs || k >= a.K) ? f4_zero()
-                                : *reinterpret_cast<const float4*>(a.conv_state + ((int64_t)b * a.K + k) * inner + c0);
+      win[k] = (k >= a.K) ? f4_zero()
+                          : *reinterpret_cast<const float4*>(a.conv_state + ((int64_t)b * a.K + k) * inner + c0);
+    if (single) n_pre = *reinterpret_cast<const float4*>(a.n_state + (int64_t)b * inner + c0);
     // conv weights [inner, K] (K == 4 taps contiguous per channel)
     float4 cw[4];
 #pragma unroll
@@ -76,6 +89,17 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
       wq[o] = *reinterpret_cast<const float4*>(a.wq + (int64_t)cg * 16 + o * 4);
       wk[o] = *reinterpret_cast<const float4*>(a.wk + (int64_t)cg * 16 + o * 4);
       wv[o] = *reinterpret_cast<const float4*>(a.wv + (int64_t)cg * 16 + o * 4);
+    }
+    {  // the restart mask is applied only now, with every request above already issued (the scheduler otherwise resolves
+       // the flag first and the workgroup starts with a round trip for one byte)
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned flag = rsb;
+      asm volatile("" : "+v"(flag));  // opaque here: the comparison cannot be hoisted (with its wait) above the requests
+      const unsigned keep = (a.reset != nullptr && flag != 0) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) win[k] = masked4(win[k], keep);
+      n_pre = masked4(n_pre, keep);
+      m_pre = masked(m_pre, keep);
     }
     float4 qt[T], kt[T], vt[T];
 #pragma unroll
@@ -119,7 +143,6 @@ __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int 
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (k < a.K) *reinterpret_cast<float4*>(a.conv_state + ((int64_t)b * a.K + k) * inner + c0) = win[k];
-    if (single && !rs) n_pre = *reinterpret_cast<const float4*>(a.n_state + (int64_t)b * inner + c0);
     // gate partial sums over this thread's 4 channels of q, k and v
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
