@@ -45,10 +45,27 @@ struct LazyView {
 // without touching HBM: the next fold simply writes the window instead of accumulating into the stale C_base)
 constexpr int kZeroBit = 1 << 16;
 
-__device__ __forceinline__ LazyView lazy_view(const MlstmLazyArgs& a, int b) {
+// the two words an env's view derives from, requested apart from their use: a kernel can issue them first and look at them
+// after its other requests (lazy_view_of), instead of starting with a memory round trip for five bytes
+struct LazyRaw {
+  unsigned rb;
+  int word;
+};
+__device__ __forceinline__ LazyRaw lazy_raw(const MlstmLazyArgs& a, int b) {
+  // (flag read through a pointer select: a load under a branch on a.reset is waited for on the spot)
+  const uint8_t* rp = a.reset != nullptr ? a.reset + b : reinterpret_cast<const uint8_t*>(a.count_in);
+  LazyRaw r;
+  r.rb = *rp;
+  r.word = a.count_in[b];
+  return r;
+}
+__device__ __forceinline__ LazyView lazy_view_of(const MlstmLazyArgs& a, int b, const LazyRaw& raw);
+__device__ __forceinline__ LazyView lazy_view(const MlstmLazyArgs& a, int b) { return lazy_view_of(a, b, lazy_raw(a, b)); }
+__device__ __forceinline__ LazyView lazy_view_of(const MlstmLazyArgs& a, int b, const LazyRaw& raw) {
   LazyView v;
-  v.rs = a.reset != nullptr && a.reset[b] != 0;
-  const int word = a.count_in[b];
+  const unsigned rb = raw.rb;
+  const int word = raw.word;
+  v.rs = a.reset != nullptr && rb != 0;
   v.n_in = word & 0xFFFF;
   v.zero_in = (word & kZeroBit) != 0;
   v.fold = !v.rs && v.n_in > 0 && (a.force != 0 || ((a.phase + b) % a.period) == 0 || v.n_in + a.T > W);
@@ -349,11 +366,12 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cl = tid % LPR, rg = tid / LPR;
   const int NH = a.NH, inner = NH * DH;
-  const LazyView lv = lazy_view(a, b);
-  const int n = lv.n;
+  // the env's count / restart words and its scale are requested here and looked at after the q / k / v operands below
+  // are under way (lv_now): the workgroup otherwise starts with two dependent round trips for a few bytes
+  LazyRaw raw = lazy_raw(a, b);
+  const float g_raw = a.g_in[(int64_t)b * NH + h];
 
   float den[T], G[T], f[T], ig[T], F[T];
-  const float g0 = (lv.rs || lv.fold) ? 1.f : a.g_in[(int64_t)b * NH + h];
   {
     float Fc = 1.f;
 #pragma unroll
@@ -364,29 +382,57 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       den[t] = s.z;
       Fc *= s.x;
       F[t] = Fc;          // f_1 .. f_t
-      G[t] = g0 * Fc;     // g f_1 .. f_t
     }
   }
   const float sqrt_dh = sqrtf((float)DH);
   const bool lean = KPL >= 0 && a.lean_wq != nullptr;
-  auto bd_row = [](const float* w, const float4& x) { return w[0] * x.x + w[1] * x.y + w[2] * x.z + w[3] * x.w; };
-  for (int r = tid; r < DH; r += 256) {
+  // (the window coefficient is requested with everything above and kept or dropped once the pending count is known)
+  const float coef_raw = tid < W ? a.coef_in[((int64_t)b * NH + h) * W + tid] : 0.f;
+  // (head dims up to 256: one channel per thread, written without a loop -- at a loop header the compiler drains every
+  // request issued before it, the env's count / restart words included)
+  auto stage_qk = [&](int r) {
     const int ch = h * DH + r;  // channel; its 4 x 4 block is ch / 4, its row in the block ch % 4
+    // every request of this channel -- the 4 x 4 block rows of wq / wk once, the T tokens' operands -- before the first LDS
+    // store (token by token the compiler emitted load -> wait -> store: 3 T dependent round trips at the head of the workgroup)
+    if (lean) {
+      const float4 wq4 = *reinterpret_cast<const float4*>(a.lean_wq + (int64_t)ch * 4);
+      const float4 wk4 = *reinterpret_cast<const float4*>(a.lean_wk + (int64_t)ch * 4);
+      float4 xa[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int64_t off = ((int64_t)b * T + t) * inner + ch;
-      if (lean) {
-        const float4 xa = *reinterpret_cast<const float4*>(a.lean_xa + ((int64_t)b * T + t) * inner + (ch & ~3));
-        qs[t * DH + r] = bd_row(a.lean_wq + (int64_t)ch * 4, xa);
-        ks[t * DH + r] = bd_row(a.lean_wk + (int64_t)ch * 4, xa) / sqrt_dh;
-      } else {
-        qs[t * DH + r] = a.q[off];
-        ks[t * DH + r] = a.k[off] / sqrt_dh;
+      for (int t = 0; t < T; ++t)
+        xa[t] = *reinterpret_cast<const float4*>(a.lean_xa + ((int64_t)b * T + t) * inner + (ch & ~3));
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        qs[t * DH + r] = wq4.x * xa[t].x + wq4.y * xa[t].y + wq4.z * xa[t].z + wq4.w * xa[t].w;
+        ks[t * DH + r] = (wk4.x * xa[t].x + wk4.y * xa[t].y + wk4.z * xa[t].z + wk4.w * xa[t].w) / sqrt_dh;
+      }
+    } else {
+      float qv[T], kv[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int64_t off = ((int64_t)b * T + t) * inner + ch;
+        qv[t] = a.q[off];
+        kv[t] = a.k[off];
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        qs[t * DH + r] = qv[t];
+        ks[t * DH + r] = kv[t] / sqrt_dh;
       }
     }
-  }
+  };
+  if (tid < DH) stage_qk(tid);
+  for (int r = tid + 256; r < DH; r += 256) stage_qk(r);
+  // the view is resolved only here, with the q / k operands requested and stored
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" : "+v"(raw.rb), "+v"(raw.word));  // opaque: its consumers (and their wait) stay behind the requests above
+  const LazyView lv = lazy_view_of(a, b, raw);
+  const int n = lv.n;
+  const float g0 = (lv.rs || lv.fold) ? 1.f : g_raw;
+#pragma unroll
+  for (int t = 0; t < T; ++t) G[t] = g0 * F[t];  // g f_1 .. f_t
   const int64_t base = ((int64_t)b * NH + h) * W;
-  if (tid < W) s_coef[tid] = tid < n ? a.coef_in[base + tid] : 0.f;
+  if (tid < W) s_coef[tid] = tid < n ? coef_raw : 0.f;
   if (KPL < 0) {  // scores and bookkeeping come from mlstm_lazy_score_kernel
     const float* pwi = a.pw + (((int64_t)b * NH + h) * T) * WT;
     for (int idx = tid; idx < T * WT; idx += 256) pw[idx] = pwi[idx];
@@ -399,16 +445,22 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
 #pragma unroll
   for (int j = 0; j < WP; ++j) vw[j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
   float vcur[T];
+  {
+    const int ch = h * DH + slice * CW + (tid < CW ? tid : 0);  // (threads >= CW request channel 0's operands and drop them)
+    if (lean) {  // v from the pre-conv branch (x half of u)
+      const float4 wv4 = *reinterpret_cast<const float4*>(a.lean_wv + (int64_t)ch * 4);
+      float4 xm[T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int ch = h * DH + slice * CW + tid;
-    if (tid >= CW) {
-      vcur[t] = 0.f;
-    } else if (lean) {  // v from the pre-conv branch (x half of u)
-      const float4 xm = *reinterpret_cast<const float4*>(a.lean_u + ((int64_t)b * T + t) * 2 * inner + (ch & ~3));
-      vcur[t] = bd_row(a.lean_wv + (int64_t)ch * 4, xm);
+      for (int t = 0; t < T; ++t) xm[t] = *reinterpret_cast<const float4*>(a.lean_u + ((int64_t)b * T + t) * 2 * inner + (ch & ~3));
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        vcur[t] = tid < CW ? wv4.x * xm[t].x + wv4.y * xm[t].y + wv4.z * xm[t].z + wv4.w * xm[t].w : 0.f;
     } else {
-      vcur[t] = a.v[((int64_t)b * T + t) * inner + ch];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float v = a.v[((int64_t)b * T + t) * inner + ch];
+        vcur[t] = tid < CW ? v : 0.f;
+      }
     }
   }
   // window khat rows of this wave (rows wave, wave + 4, ...), KPL values per lane and row
