@@ -444,6 +444,19 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   float vw[WP];
 #pragma unroll
   for (int j = 0; j < WP; ++j) vw[j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
+  // window khat rows of this wave (rows wave, wave + 4, ...), KPL values per lane and row
+  const float* wkb = a.wk + base * DH;
+  float kreg[KPL > 0 ? kRowsPerWave : 1][KPL > 0 ? KPL : 1];
+  (void)kreg;
+  if (KPL > 0) {
+#pragma unroll
+    for (int i = 0; i < kRowsPerWave; ++i) {
+      const int j = wave + 4 * i;
+#pragma unroll
+      for (int c = 0; c < KPL; ++c) kreg[i][c] = j < n ? wkb[(int64_t)j * DH + lane + 64 * c] : 0.f;
+    }
+  }
+  // (this step's v operands last: their combination waits for everything requested above, the window rows included)
   float vcur[T];
   {
     const int ch = h * DH + slice * CW + (tid < CW ? tid : 0);  // (threads >= CW request channel 0's operands and drop them)
@@ -461,18 +474,6 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
         const float v = a.v[((int64_t)b * T + t) * inner + ch];
         vcur[t] = tid < CW ? v : 0.f;
       }
-    }
-  }
-  // window khat rows of this wave (rows wave, wave + 4, ...), KPL values per lane and row
-  const float* wkb = a.wk + base * DH;
-  float kreg[KPL > 0 ? kRowsPerWave : 1][KPL > 0 ? KPL : 1];
-  (void)kreg;
-  if (KPL > 0) {
-#pragma unroll
-    for (int i = 0; i < kRowsPerWave; ++i) {
-      const int j = wave + 4 * i;
-#pragma unroll
-      for (int c = 0; c < KPL; ++c) kreg[i][c] = j < n ? wkb[(int64_t)j * DH + lane + 64 * c] : 0.f;
     }
   }
   __syncthreads();
