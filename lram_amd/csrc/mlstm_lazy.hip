@@ -241,8 +241,12 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
   const int NH = a.NH, DH = a.DH, inner = NH * DH;
   float* qs = qk;
   float* ks = qk + T * DH;
-  const LazyView lv = lazy_view(a, b);
-  const int n = lv.n;
+  // Requests first, looks later (as in the read pass): the env's count / restart words, the gate scalars, the window
+  // coefficient and up to three channels' q / k operands per thread are all issued before anything is waited for or
+  // stored; the staging of head dims <= 768 has no loop (a loop header drains every outstanding request).
+  LazyRaw raw = lazy_raw(a, b);
+  const int64_t base = ((int64_t)b * NH + h) * W;
+  const float coef_raw = tid < W ? a.coef_in[base + tid] : 0.f;
   float f[T], ig[T], F[T];
   float Fc = 1.f;
 #pragma unroll
@@ -254,16 +258,44 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
     F[t] = Fc;
   }
   const float sqrt_dh = sqrtf((float)DH);
-  for (int r = tid; r < DH; r += 256) {
+  {
+    constexpr int kIt = 3;
+    float qv[kIt][T], kv[kIt][T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r;
-      qs[t * DH + r] = a.q[off];
-      ks[t * DH + r] = a.k[off] / sqrt_dh;
+    for (int it = 0; it < kIt; ++it) {
+      const int r = min(tid + 256 * it, DH - 1);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r;
+        qv[it][t] = a.q[off];
+        kv[it][t] = a.k[off];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int r = tid + 256 * it;
+      if (r < DH) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          qs[t * DH + r] = qv[it][t];
+          ks[t * DH + r] = kv[it][t] / sqrt_dh;
+        }
+      }
+    }
+    for (int r = tid + 256 * kIt; r < DH; r += 256) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r;
+        qs[t * DH + r] = a.q[off];
+        ks[t * DH + r] = a.k[off] / sqrt_dh;
+      }
     }
   }
-  const int64_t base = ((int64_t)b * NH + h) * W;
-  if (tid < W) s_coef[tid] = tid < n ? a.coef_in[base + tid] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" : "+v"(raw.rb), "+v"(raw.word));  // opaque: the view (and its wait) stays behind the requests above
+  const LazyView lv = lazy_view_of(a, b, raw);
+  const int n = lv.n;
+  if (tid < W) s_coef[tid] = tid < n ? coef_raw : 0.f;
   __syncthreads();
   // ---- bookkeeping for the next step ----
   if (tid < n) a.coef_out[base + tid] = s_coef[tid] * F[T - 1];
@@ -290,17 +322,40 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int t = 0; t < T; ++t) p[i][t] = 0.f;
-    for (int r = lane; r < DH; r += 64) {
-      float kv[4];
+    // all of the four rows' window values of this lane (head dims <= 768: 12 per row) are requested before the first fma
+    // (per 64 channels the loop compiled to load -> wait -> fma: DH / 64 dependent round trips per row group)
+    constexpr int kSIt = 12;
+    float kv[4][kSIt];
+#pragma unroll
+    for (int it = 0; it < kSIt; ++it) {
+      const int r = lane + 64 * it;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = j0 + i;
-        kv[i] = j < n ? wkb[(int64_t)j * DH + r] : (j < n + T ? ks[(j - n) * DH + r] : 0.f);
+        kv[i][it] = (r < DH && j < n) ? wkb[(int64_t)j * DH + r] : 0.f;
       }
+    }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int it = 0; it < kSIt; ++it) {
+      const int r = lane + 64 * it;
+      if (r < DH) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) p[i][t] += qs[t * DH + r] * kv[i];
+        for (int i = 0; i < 4; ++i) {
+          const int j = j0 + i;
+          const float kx = j < n ? kv[i][it] : (j < n + T ? ks[(j - n) * DH + r] : 0.f);
+#pragma unroll
+          for (int t = 0; t < T; ++t) p[i][t] += qs[t * DH + r] * kx;
+        }
+      }
+    }
+    for (int r = lane + 64 * kSIt; r < DH; r += 64) {  // (head dims beyond 768)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = j0 + i;
+        const float kx = j < n ? wkb[(int64_t)j * DH + r] : (j < n + T ? ks[(j - n) * DH + r] : 0.f);
+#pragma unroll
+        for (int t = 0; t < T; ++t) p[i][t] += qs[t * DH + r] * kx;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
