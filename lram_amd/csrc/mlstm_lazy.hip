@@ -110,14 +110,30 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
   // compact grid: only the envs whose fold phase comes up this step (b = first, first + period, ...)
   const int b = a.compact ? a.first + (bh / NH) * a.period : bh / NH;
   if (b >= a.B) return;
-  const LazyView lv = lazy_view(a, b);
-  if (!lv.fold) return;
+  // Compact launches (every workgroup's env folds): the env's count / restart words, its scale and the workgroup's tile of
+  // C_base are requested together and the view is looked at afterwards -- the tile's 32 KB no longer wait behind a round trip
+  // for five bytes.  (Other launches look first: most of their workgroups leave at once.)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
-  const int n = lv.n_in;
-  const int kt8 = (n + 7) >> 3;
-  const float g = lv.zero_in ? 0.f : a.g_in[(int64_t)b * NH + h];
   const int row0 = rsplit * kFR;
   float* Cg = a.C + (((int64_t)b * NH + h) * DH) * DH + slice * kFC;
+  float* cp0 = Cg + (int64_t)(row0 + 4 * lh) * DH + 32 * w + li;
+  float cold[kFR / 32][16];
+  LazyRaw raw = lazy_raw(a, b);
+  const float g_raw = a.g_in[(int64_t)b * NH + h];
+  const bool early = a.compact != 0;
+  if (early) {
+#pragma unroll
+    for (int t = 0; t < kFR / 32; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cold[t][r] = cp0[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * DH];
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(raw.rb), "+v"(raw.word));  // opaque: the view (and its wait) stays behind the requests above
+  }
+  const LazyView lv = lazy_view_of(a, b, raw);
+  if (!lv.fold) return;
+  const int n = lv.n_in;
+  const int kt8 = (n + 7) >> 3;
+  const float g = lv.zero_in ? 0.f : g_raw;
   const float* wkb = a.wk + (((int64_t)b * NH + h) * W) * DH + row0;
   const float* wvb = a.wv + (((int64_t)b * NH + h) * W) * DH + slice * kFC;
   const float* cfb = a.coef_in + ((int64_t)b * NH + h) * W;
@@ -136,13 +152,18 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
     Qs[t * kFR + r] = qv;
   }
   // every global load of the workgroup is issued before the first use: one memory round trip, not one per phase
-  float* cp0 = Cg + (int64_t)(row0 + 4 * lh) * DH + 32 * w + li;
-  float cold[kFR / 32][16];
+  if (!early) {
 #pragma unroll
-  for (int t = 0; t < kFR / 32; ++t)
+    for (int t = 0; t < kFR / 32; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      cold[t][r] = lv.zero_in ? 0.f : cp0[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * DH];
+      for (int r = 0; r < 16; ++r)
+        cold[t][r] = lv.zero_in ? 0.f : cp0[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * DH];
+  } else if (lv.zero_in) {
+#pragma unroll
+    for (int t = 0; t < kFR / 32; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cold[t][r] = 0.f;
+  }
   float4 rv[(WF * (kFC / 4) + 255) / 256];
 #pragma unroll
   for (int i = 0; i < (WF * (kFC / 4) + 255) / 256; ++i) {
