@@ -519,7 +519,7 @@ def main(argv=None, engine_factory=None, device=None):
         eng.set_micro_batches(args.micro)
     # HBM bytes per launch come from a separate rocprofv3 --pmc pass (scripts/pmc_pass.sh -> profiles/): a constant
     # read from a committed file, labelled as such
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         pmc_file = os.path.join(ROOT, "profiles", "%s_cell_kernel_hbm_traffic%s.json" % (rnd, "_lazy" if lazy else ""))
         if not os.path.exists(pmc_file):
             continue
@@ -532,6 +532,7 @@ def main(argv=None, engine_factory=None, device=None):
                 roofline["traffic_source"] = ("%s (separate rocprofv3 --pmc pass of the same command, FETCH_SIZE x2 + "
                                               "WRITE_SIZE per MI355X_MICROARCH.md; not measured in this process)"
                                               % os.path.relpath(pmc_file, ROOT))
+                roofline["traffic_over_algorithmic"] = roofline["traffic"] / roofline["algorithmic_bytes_per_launch"]
                 if roofline.get("avg_launch_ms"):
                     roofline["traffic_GBps"] = roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
                 break

@@ -181,6 +181,29 @@ struct MlstmPreArgs {
   float* vec = nullptr;    // [B, NH, 3, 64] out   fcum_t | w_s | denom_t
 };
 void launch_mlstm_pre(const MlstmPreArgs& a, hipStream_t stream);
+
+// The same front end for large launches of the lazy ("lean") path, several env slots per workgroup with the block's
+// weights held in registers (mlstm_front.hip): inner = 1024, 4 heads, 3 tokens.  q / k / v are not written.
+struct MlstmFrontArgs {
+  const float* u = nullptr;   // [B*T, ldu]  x_m half of proj_up's output
+  int64_t ldu = 0;
+  float* conv_state = nullptr;  // [B, 4, inner] in/out
+  float* n_state = nullptr;     // [B, NH, DH]   in/out
+  float* m_state = nullptr;     // [B, NH]       in/out
+  const float *conv_w = nullptr, *conv_b = nullptr, *wq = nullptr, *wk = nullptr;
+  const float* gc = nullptr;    // [inner/4, 4*NH, 4] folded gate coefficients (launch_gate_coef)
+  const float *bi = nullptr, *bf = nullptr;
+  float* xa = nullptr;          // [B*T, inner] out  silu(conv)
+  float* scal = nullptr;        // [B*T, NH, 4] out  (f_t, i_t, denom_t, m_t)
+  const uint8_t* reset = nullptr;
+  int B = 0, T = 0, inner = 0, NH = 0, K = 0;
+  int epw = 0;                  // env slots per workgroup (0 = default)
+};
+bool mlstm_front_supported(int inner, int NH, int K, int T);
+void launch_mlstm_front(const MlstmFrontArgs& a, hipStream_t stream);
+// gc[cg][j][c] (j < 2 NH: coefficient of xa[4 cg + c], else of x_m[4 cg + c]) for the i / f gates of every head
+void launch_gate_coef(const float* wq, const float* wk, const float* wv, const float* wi, const float* wf, int inner, int NH,
+                      float* gc, hipStream_t stream);
 // chunkwise path: front end + gate scan / A matrix (two launches), then the cell contraction
 bool mlstm_chunk_supported(int inner, int NH, int K);
 void launch_mlstm_chunk_pre(const MlstmPreArgs& a, hipStream_t stream);

@@ -103,6 +103,9 @@ struct lram_engine {
     size_t rows, k;
   };
   std::map<const float*, Split16> split16;
+  std::vector<DevBuf> gate_coef;  // mLSTM: folded i / f gate coefficients per block (mlstm_front.hip), geometries it covers
+  bool front_multi = true;     // LRAM_FRONT_MULTI=0: keep the one-workgroup-per-env front end for large launches too
+  int front_min_envs = 256;    // LRAM_FRONT_MIN_ENVS: slices of at least this many env slots take the multi-env front end
   std::vector<DevBuf> dt_wt;   // Mamba: dt_proj.weight transposed to [dt_rank, d_inner] per block (state-update kernel's operand)
   DevBuf ASCALE;  // per-row maxima of a GEMM's A operand computed by launch_row_amax, one region per stream slot (like
   size_t ascale_rows = 0;  // the split-K slabs)
@@ -254,6 +257,8 @@ struct lram_engine {
     split16.clear();
     for (DevBuf& b : dt_wt) b.release();
     dt_wt.clear();
+    for (DevBuf& b : gate_coef) b.release();
+    gate_coef.clear();
   }
   void drop_graph() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -278,8 +283,9 @@ struct lram_engine {
     lazy_ready = false;
     st.clear();
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
-                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T})
+                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &YPART, &X0, &U0})
       b->release();
+    ascale_rows = 0;
     if (XN3) (void)hipFree(XN3);
     if (G3) (void)hipFree(G3);
     XN3 = G3 = nullptr;
@@ -496,6 +502,16 @@ void finalize(lram_engine* e) {
         ws.push_back(p);
     for (const float* p : ws)
       if (p != nullptr) make_split(e, p, numel(p));
+    LRAM_HIP_CHECK(hipDeviceSynchronize());
+  }
+  e->gate_coef.assign(e->bw.size(), DevBuf());
+  if (c.backbone == LRAM_BACKBONE_XLSTM && mlstm_front_supported(c.inner, c.n_heads, c.conv_k, c.tokens_per_step)) {
+    for (size_t i = 0; i < e->bw.size(); ++i) {
+      if (c.block_is_slstm[i]) continue;
+      const BlockWeights& w = e->bw[i];
+      e->gate_coef[i].alloc((size_t)c.inner * 4 * c.n_heads);
+      launch_gate_coef(w.wq, w.wk, w.wv, w.wi, w.wf, c.inner, c.n_heads, e->gate_coef[i].p, nullptr);
+    }
     LRAM_HIP_CHECK(hipDeviceSynchronize());
   }
   e->dt_wt.assign(e->bw.size(), DevBuf());
@@ -976,6 +992,18 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     up.a_amax = amx;
     if (a3) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
     gemm(e, up, sl.s);
+  }
+  if (e->front_multi && lean_front(e, T) && sl.nb >= e->front_min_envs && e->gate_coef[i].p != nullptr &&
+      mlstm_front_supported(inner, NH, c.conv_k, T)) {
+    // large launches of the lean path: several env slots per workgroup, weights in registers (mlstm_front.hip)
+    MlstmFrontArgs fa;
+    fa.u = e->U.p + r0 * e->ucols, fa.ldu = 2 * inner, fa.conv_state = st.conv.p + b0 * c.conv_k * inner;
+    fa.n_state = st.n.p + b0 * inner, fa.m_state = st.m.p + b0 * NH;
+    fa.conv_w = w.conv_w, fa.conv_b = w.conv_b, fa.wq = w.wq, fa.wk = w.wk, fa.gc = e->gate_coef[i].p, fa.bi = w.bi, fa.bf = w.bf;
+    fa.xa = e->XA.p + r0 * e->icols, fa.scal = e->SCAL.p + r0 * NH * 4, fa.reset = reset ? reset + b0 : nullptr;
+    fa.B = sl.nb, fa.T = T, fa.inner = inner, fa.NH = NH, fa.K = c.conv_k;
+    launch_mlstm_front(fa, sl.s);
+    return;
   }
   MlstmPreArgs pa;
   pa.u = e->U.p + r0 * e->ucols, pa.conv_state = st.conv.p + b0 * c.conv_k * inner, pa.n_state = st.n.p + b0 * inner;
@@ -1764,6 +1792,8 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_FOLD_FUSED_STREAM")) e->fold_fused_stream = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_GAPS")) e->fold_gaps = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_FRONT_STAGGER")) e->front_stagger = std::atoi(v);
+    if (const char* v = std::getenv("LRAM_FRONT_MULTI")) e->front_multi = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_FRONT_MIN_ENVS")) e->front_min_envs = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
     *out = e.release();
   });

@@ -7,8 +7,8 @@ OUT=$R/gpurun_out/pmc
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 3 --warmup 1 \
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 26 --warmup 4 \
       --no-cpu-baseline --no-kernel-timing --host-io-steps 0 ${BENCH_ARGS:-} > $OUT/$C.json 2> $OUT/$C.err
   echo "$C rc=$?"
 done
-cd $R && python3 scripts/parse_pmc.py $OUT ${PMC_TAG:-xlstm_16m} ${PMC_BATCH:-4096} ${PMC_MICRO:-2}
+cd $R && python3 scripts/parse_pmc.py $OUT ${PMC_TAG:-xlstm_16m} ${PMC_BATCH:-4096} ${PMC_MICRO:-2} ${PMC_FIRST:-20}

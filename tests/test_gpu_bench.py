@@ -24,6 +24,8 @@ def test_bench_line_contract_and_physical_roofline(hip_lib, capsys):
     assert r["launches_per_step"] == 14 and r["fold_launches_timed"] == 7 * 4      # 7 mLSTM blocks x 2 slices; 7 folds
     assert r["effective_8d_GBps"] > r["achieved"]                                   # the 8d figure prices more bytes
     assert (r["traffic"] is None) == (r["traffic_source"] is None)                  # a replayed constant is labelled
+    if r["traffic"] is not None:                                                    # ... and agrees with the byte model
+        assert 0.95 <= r["traffic"] / r["algorithmic_bytes_per_launch"] <= 1.10
     h = out["host_io"]
     assert h["steps"] == 3 and h["value"] > 0 and h["bytes_h2d_per_step"] == 512 * (204 * 4 + 4 + 1)
     assert "cpu_baseline" not in out
