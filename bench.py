@@ -54,6 +54,20 @@ GEMM_KINDS = {   # LRAM_GEMM (engine.hip::finalize); every kind is fp32-accurate
 MFMA_PEAK_PFLOPS = 2.5   # dense f16 / bf16 matrix-core peak of MI355X (MI355X_MICROARCH.md; the 2:1-sparsity figure is not used)
 
 
+def projection_label(ran, env_kind):
+    """Which projection kernels served the timed region, from the engine's own dispatch counters (lram_gemm_counts) --
+    the dispatcher takes f16x2 only from 1024 operand rows (512 for wide weights), bf16x3 for the batched per-head
+    GEMMs of the sLSTM block and for fewer rows, the fp32 few-row / GEMV kernels below 385 rows -- not from LRAM_GEMM."""
+    if not ran:
+        return GEMM_KINDS[env_kind]
+    tot = sum(v["flop"] for v in ran.values()) or 1.0
+    main = max(ran, key=lambda k: ran[k]["flop"])
+    desc = {"f16x2": GEMM_KINDS["f16x2"], "bf16x3": GEMM_KINDS["bf16x3"], "f32": GEMM_KINDS["f32"],
+            "few_row_f32": "on the exact fp32 MFMA (few-row kernel: one 32 x 32 tile per workgroup, operands in registers)"}[main]
+    rest = ", ".join(f"{k} {100.0 * v['flop'] / tot:.0f} %" for k, v in ran.items() if v["flop"] > 0 and k != main)
+    return desc + f" ({100.0 * ran[main]['flop'] / tot:.0f} % of the projection FLOPs" + (f"; {rest}" if rest else "") + ")"
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -390,7 +404,10 @@ def main(argv=None, engine_factory=None, device=None):
     if timing:
         sync()
         eng.profile_begin()
+    if not stub:
+        eng.gemm_counts(reset=True)
     wall, last = timed_region(one_step, W, K, sync, ldist, dev)
+    gemm_ran = None if stub else eng.gemm_counts()
     if timing:
         kern_ms, kern_n, fold_ms, fold_n = eng.profile_end_split()
     else:
@@ -404,10 +421,10 @@ def main(argv=None, engine_factory=None, device=None):
         "scaling": "strong" if args.global_batch > 0 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"{args.config}: xLSTM[7:1] 16M rollout, {B} env slots per GPU, 3 tokens/timestep, "
                                 "cheetah-run-shaped obs (17 of 204 dims), continuous 8x274 head; fp32 state and "
-                                f"accumulation, dense projections {GEMM_KINDS[gemm_kind]}"
+                                f"accumulation, dense projections {projection_label(gemm_ran, gemm_kind)}"
                                 if args.config == "xlstm_16m" and args.obs == "state"
                                 else f"{args.config}, {B} env slots per GPU, {args.obs} observations; fp32 state, "
-                                     f"projections {GEMM_KINDS[gemm_kind]}"),
+                                     f"projections {projection_label(gemm_ran, gemm_kind)}"),
                    "batch_per_gpu": B, "global_batch": global_batch, "tokens_per_step": T,
                    "state_bytes_per_env": spec.state_bytes_per_env(), "parallelism": f"env-shard x{world}",
                    "graph": bool(args.graph), "micro_batches": args.micro, "state_mode": state_mode,
@@ -416,6 +433,14 @@ def main(argv=None, engine_factory=None, device=None):
                                       "one state advance per env-step, full reset"},
         "inputs": "resident in HBM before the timed region (obs ring, per-step rtg and reset masks)",
     }
+    if world > 1:   # (every rank takes part; rank 0 logs it and carries it on the line)
+        out["collective"] = ldist.collective_report(torch.zeros(B, last.shape[-1], dtype=last.dtype, device=last.device),
+                                                    args.global_batch if args.global_batch > 0 else None)
+        if rank == 0:
+            log("[bench] collective:", json.dumps(out["collective"]))
+    if gemm_ran:
+        out["gemm_dispatch_per_step"] = {k: {"launches": v["launches"] / K, "gflop": v["flop"] / K / 1e9}
+                                         for k, v in gemm_ran.items() if v["launches"]}
     if stub:
         if cli_stub and rank == 0:
             print(json.dumps(dict(out, last_actions=last.tolist())), flush=True)
@@ -545,26 +570,29 @@ def main(argv=None, engine_factory=None, device=None):
         # whole-step average (the projections occupy ~58 % of the device time, profiles/r03_kernel_stats_mamba48m_*), so
         # the in-kernel rate is higher; the matrix-pipe busy share of the projection kernels themselves comes from a
         # separate rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES), a constant read from profiles/.
-        rows = B * T
-        di, D, N, R = spec.d_inner, spec.d_model, spec.d_state, spec.dt_rank
-        per_layer = 2.0 * rows * (2 * di * D + (R + 2 * N) * di + di * R + D * di)
-        head = 2.0 * B * spec.act_dim * spec.n_vocab * D
-        products = {"f16x2": 3, "bf16x3": 6, "f32": 1}[gemm_kind]
-        passes = compat["mamba_repeat"] if args.mamba_compat else 1
-        flops = passes * (spec.n_blocks * per_layer + head)
-        issued = flops * products
+        # (what ran, from the dispatch counters: dt_proj inside the state-update kernel runs on the vector ALUs and is not
+        # counted; each family issues its own number of matrix-core products per fp32 product)
+        per_product = {"f16x2": 3, "bf16x3": 6, "f32": 1, "few_row_f32": 1}
+        flops = sum(v["flop"] for v in gemm_ran.values()) / K
+        issued = sum(v["flop"] * per_product[k] for k, v in gemm_ran.items()) / K
+        products = issued / max(flops, 1.0)
         m = {"bound": "mfma", "fp32_equiv_flop_per_step": flops, "mfma_products_per_fp32_product": products,
              "issued_flop_per_step": issued, "issued_PFLOPs_over_step": issued / (wall / K) / 1e15,
              "peak": MFMA_PEAK_PFLOPS, "unit": "PFLOP/s", "frac_over_step": issued / (wall / K) / 1e15 / MFMA_PEAK_PFLOPS,
              "note": "matrix-core work of the projections averaged over the WHOLE env-step (state update, conv, norms "
                      "included in the time); f32 kind: peak is 0.157 PFLOP/s, frac not comparable"}
-        pmc = os.path.join(ROOT, "profiles", "r03_gemm_mfma_busy.json")
-        if os.path.exists(pmc):
+        for rnd in ("r04", "r03"):
+            pmc = os.path.join(ROOT, "profiles", "%s_gemm_mfma_busy.json" % rnd)
+            if not os.path.exists(pmc):
+                continue
             try:
                 with open(pmc) as fh:
                     pj = json.load(fh)
-                m["mfma_busy_in_projection_kernels"] = pj.get(gemm_kind)
-                m["mfma_busy_source"] = "profiles/r03_gemm_mfma_busy.json (separate rocprofv3 --pmc pass over scripts/bench_gemm.py)"
+                main = max(gemm_ran, key=lambda k: gemm_ran[k]["flop"])
+                m["mfma_busy_in_projection_kernels"] = pj.get(main)
+                m["mfma_busy_source"] = ("profiles/%s_gemm_mfma_busy.json (separate rocprofv3 --pmc pass over "
+                                         "scripts/bench_gemm.py)" % rnd)
+                break
             except Exception:
                 pass
         out["mfma"] = m

@@ -241,6 +241,13 @@ int32_t lram_profile_end(lram_engine* e, double* total_ms, int64_t* n_launches);
  * launches, so that each figure can be held against the per-kernel averages of a rocprofv3 --kernel-trace run. */
 int32_t lram_profile_end_split(lram_engine* e, double* main_ms, int64_t* n_main, double* aux_ms, int64_t* n_aux);
 
+/* Measurement aid: how many projection launches each kernel family of the dispatcher (engine.hip::gemm) has served since
+ * lram_create or the last call with `reset` != 0 -- out[0] f16x2, out[1] bf16x3, out[2] exact fp32 MFMA (tile / GEMV),
+ * out[3] few-row fp32 kernel, and out[4..7] the fp32-equivalent FLOPs (2 M N K, summed) of the same four.  bench.py labels
+ * its workload line from these instead of from the LRAM_GEMM environment variable.  (The reference has no counterpart:
+ * nn.Linear calls at src/algos/models/decision_mamba.py:78-93 / [3P] xlstm proj_up / proj_down go to the vendor BLAS.) */
+int32_t lram_gemm_counts(lram_engine* e, double* out8, int32_t reset);
+
 /* Standalone kernel entry points used by tests and micro-benchmarks. */
 /* C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) (+ residual C_in)   fp32, MFMA 32x32x2 f32 (exact k-ordered fma chain) */
 int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,

@@ -28,7 +28,6 @@ import torch
 
 from .config import ModelSpec
 from .engine import Engine
-from .image_encoder import ImageEncoder
 
 
 class _InferenceParams:
@@ -50,7 +49,7 @@ class RecurrentAgent:
                  discrete: bool = False, state_mean: Optional[torch.Tensor] = None,
                  state_std: Optional[torch.Tensor] = None, target_return: float = 0.0, reward_scale: float = 1.0,
                  graph: bool = False, reprime_context: bool = False, persist_context: bool = False,
-                 torch_image_encoder: bool = False, compat_mamba_repeat: bool = False,
+                 compat_mamba_repeat: bool = False,
                  compat_stale_state: bool = False):
         self.spec = spec
         # host copy of the weights: lets the agent cross a process boundary (make_pickleable / reinit_cuda_kernels)
@@ -63,12 +62,9 @@ class RecurrentAgent:
         self.policy = self  # `model.predict(model.policy, ...)`: the policy argument is accepted and ignored
         self.state_mean = None if state_mean is None else state_mean.to(self.device, torch.float32)
         self.state_std = None if state_std is None else state_std.to(self.device, torch.float32)
-        # image observations go through the engine's own IMPALA-CNN kernels (lram_embed_images); the PyTorch / MIOpen
-        # module (image_encoder.ImageEncoder) is only built on request, as a cross-check
+        # image observations go through the engine's own IMPALA-CNN kernels (lram_embed_images): one backend in the package
+        # (the PyTorch / MIOpen module that cross-checks them lives with the tests: tests/torch_image_encoder.py)
         self.has_image_encoder = any(k.startswith("embed_image.") for k in state_dict) and spec.image_shape is not None
-        self.image_encoder = None
-        if torch_image_encoder and self.has_image_encoder:
-            self.image_encoder = ImageEncoder.from_state_dict(state_dict, spec.image_shape, spec.d_model).to(self.device)
         # attributes read by the evaluation loop
         self.eval_context_len = spec.max_length
         self.use_inference_cache = True
@@ -160,8 +156,6 @@ class RecurrentAgent:
         if obs.dim() == 4:
             if not self.has_image_encoder:
                 raise RuntimeError("image observation given but the state dict has no embed_image.* weights")
-            if self.image_encoder is not None:
-                return self.image_encoder(obs).contiguous(), True
             return self.engine.embed_images(obs.to(torch.uint8).contiguous()), True
         obs = obs.to(torch.float32)
         pad = self.spec.state_dim - obs.shape[-1]

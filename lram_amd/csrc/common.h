@@ -253,6 +253,13 @@ struct MlstmLazyArgs {
   // GN(h) * gn_g (+ gn_b) + gn_skip * xa, the output gate silu(z) is applied by proj_down while it stages its operand
   const float *gn_g = nullptr, *gn_b = nullptr, *gn_skip = nullptr;
   float gn_eps = 0.f;
+  // ... and the output gate as well (gn_gate != nullptr, with gn_g): gn_gate[row * gn_ldg + channel] holds silu(z), written
+  // by the un-split proj_up's epilogue BEFORE this pass; h is stored gated, and the largest magnitude of each (row, head)
+  // slice of it goes to gn_amax[row * NH + head] -- proj_down's f16x2 row scales (a_amax with amax_parts = NH): no
+  // row-maximum launch, no second read of h and z ahead of the GEMM
+  const float* gn_gate = nullptr;
+  int64_t gn_ldg = 0;
+  float* gn_amax = nullptr;
   // fold + readout in one pass over the due envs' matrix memory: the fold kernel, run AFTER this step's front end, also
   // leaves the partial readouts y_t[c] = sum_r q_t[r] C_new[r][c] of its 64 rows in ypart [B, NH, DH / 64, T, DH]; the
   // read pass then sums them (fixed order) instead of streaming C_base again for the envs that just folded

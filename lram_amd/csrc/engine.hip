@@ -103,6 +103,7 @@ struct lram_engine {
     size_t rows, k;
   };
   std::map<const float*, Split16> split16;
+  double gemm_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // launches / fp32-equivalent FLOPs per dispatcher family (lram_gemm_counts)
   std::vector<DevBuf> gate_coef;  // mLSTM: folded i / f gate coefficients per block (mlstm_front.hip), geometries it covers
   bool front_multi = true;     // LRAM_FRONT_MULTI=0: keep the one-workgroup-per-env front end for large launches too
   int front_min_envs = 256;    // LRAM_FRONT_MIN_ENVS: slices of at least this many env slots take the multi-env front end
@@ -138,6 +139,10 @@ struct lram_engine {
                             // rounds: 391.1k / 393.5k off vs 395.8k / 397.5k on at 4096 slots; 1024 slots: -0.4 %)
                             // operand staging (measured: +0.7 % at 4096 env slots, -0.3 % at 1024: opt-in)
   bool split_up = true;     // LRAM_SPLIT_UP=0: proj_up as one GEMM ahead of the front end
+  bool gate_in_pass = false;  // LRAM_GATE_IN_PASS=1: output gate + proj_down's row maxima in the read pass's epilogue, proj_up un-split.
+                              // Correct (front / full-size / real-batch / lazy suites green with it) and SLOWER: 436.5k / 433.0k ->
+                              // 428.9k / 424.5k env-steps/s on one box (profiles/r04_ab_gate_in_pass.txt) -- the row-maximum launches and
+                              // 0.7 GB of chain reads go, but the read pass, the critical queue, gets 14 us longer (0.516 -> 0.530 ms)
   // fold + readout (mlstm_lazy.hip, LRAM_FOLD_FUSED=1): an env's fold runs right ahead of its slice's read pass, after the
   // front end, and hands the read pass q . C_new for the 64-row strips it has just rewritten -- the due envs' matrix memory
   // is then read once per fold step instead of twice (-2.3 GB of 48 per step).  Correct (lazy / real-batch / full-size
@@ -544,6 +549,7 @@ void alloc_workspace(lram_engine* e, int tokens) {
   const size_t parts = c.backbone == LRAM_BACKBONE_MAMBA ? std::max<size_t>(1, c.d_inner / 64) : 0;
   e->AMX_XN.alloc(BT);
   if (parts) e->AMX_XA.alloc(BT * parts), e->AMX_H.alloc(BT * parts);
+  if (c.backbone == LRAM_BACKBONE_XLSTM) e->AMX_H.alloc(BT * (size_t)c.n_heads);  // read pass -> proj_down (gate_in_pass)
   e->X.alloc(BT * D);
   e->XN.alloc(BT * D);
   e->TOK.alloc(BT * D);
@@ -765,6 +771,11 @@ bool takes_skinny_with_norm(const lram_engine* e, const GemmArgs& g) {
   return e->gemm_skinny_norm && takes_skinny(e, g) && gemm_skinny_norm_supported(g);
 }
 
+void count_gemm(lram_engine* e, int family, const GemmArgs& g) {
+  e->gemm_counts[family] += 1.0;
+  e->gemm_counts[4 + family] += 2.0 * g.m * g.n * g.k * g.nb1 * g.nb2;
+}
+
 // GEMM dispatch: bf16x3 (fp32-accurate on the bf16 matrix cores) when the weight has split planes and the shape
 // allows 16-byte bf16 loads, else the exact fp32-MFMA kernel.
 void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
@@ -798,6 +809,7 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
           g.a_amax = sc, g.amax_parts = 1;
         }
         launch_gemm_f16x2(g, s);
+        count_gemm(e, 0, g);
         return;
       }
       g.w2 = nullptr, g.w_inv = nullptr;
@@ -812,6 +824,7 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
   // 16M at 4 / 12 / 32 / 64 / 128 envs: +17 / +17 / +16 / +12 / +10 %; C1 (2 blocks, D = 128) at 32 envs: 0.130 -> 0.093 ms.
   if (takes_skinny(e, g)) {
     launch_gemm_skinny(g, s);
+    count_gemm(e, 3, g);
     return;
   }
   if (e->use_bf16x3 && !gemm_small_m(g)) {
@@ -822,6 +835,7 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
       g.w3_plane = (int64_t)it->second.n;
       if (gemm_bf16x3_supported(g)) {
         launch_gemm_bf16x3(g, s);
+        count_gemm(e, 1, g);
         return;
       }
     }
@@ -829,6 +843,7 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
   LRAM_REQUIRE(g.a3 == nullptr, "gemm: a pre-split A operand was produced for a GEMM that does not take the bf16x3 kernel");
   LRAM_REQUIRE(g.gate == nullptr && g.act_silu_from < 0, "gemm: gated operand / output activation need the bf16x3 kernel");
   launch_gemm_f32(g, s);
+  count_gemm(e, 2, g);
 }
 
 // Does the projection `rows x k` against weight w take the bf16x3 kernel with a pre-split A operand?  (Same conditions
@@ -957,7 +972,15 @@ bool lean_front(const lram_engine* e, int T) {
   return e->lean_front && lazy_active(e, T) && mlstm_lazy_fused_scores(e->cfg.inner / e->cfg.n_heads);
 }
 
-bool split_up_now(const lram_engine* e) { return e->split_up && e->B >= 2048 && !e->graph_mode; }
+bool gn_fused(const lram_engine* e, int T);
+// Output gate inside the read pass too (its epilogue multiplies by silu(z) and hands proj_down the row maxima of the gated
+// rows): z must then be there before the pass -- proj_up runs un-split -- and proj_down loses its gate operand and the
+// row-maximum launch ahead of it (-50 MB of reads and one launch per slice and block at 4096 env slots).
+bool gate_in_pass(const lram_engine* e, int T) { return e->gate_in_pass && gn_fused(e, T); }
+
+bool split_up_now(const lram_engine* e) {
+  return e->split_up && e->B >= 2048 && !e->graph_mode && !gate_in_pass(e, e->cfg.tokens_per_step);
+}
 
 // Output group norm + learnable skip inside the lazy read pass's epilogue (its workgroup holds a head's whole output
 // row), silu(z) written by proj_up's epilogue and multiplied onto proj_down's operand while that GEMM stages it: no
@@ -986,6 +1009,7 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     // few rows: the norm runs in the projection's prologue (each workgroup normalises its 32 rows in registers)
     up.a = e->X.p + r0 * D, up.norm_g = w.norm_g, up.norm_b = w.norm_b, up.norm_eps = c.ln_eps, up.norm_rms = c.norm_is_rms;
     launch_gemm_skinny(up, sl.s);
+    count_gemm(e, 3, up);
   } else {
     launch_row_norm(e->X.p + r0 * D, D, a3 ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
                     c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, amx);
@@ -1070,7 +1094,11 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
   if (gn_fused(e, T)) {  // H holds GN(h) + skip * xa, U's z half silu(z)
     GemmArgs dn;
     dn.a = e->H.p + r0 * e->icols, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
-    dn.gate = e->U.p + r0 * e->ucols + inner, dn.ldg = 2 * inner;
+    if (gate_in_pass(e, T)) {  // H is gated already; its row maxima came with it, one per head
+      if (e->use_f16x2) dn.a_amax = e->AMX_H.p + r0 * NH, dn.amax_parts = NH;
+    } else {
+      dn.gate = e->U.p + r0 * e->ucols + inner, dn.ldg = 2 * inner;
+    }
     dn.m = rows, dn.n = D, dn.k = inner;
     gemm(e, dn, sl.s);
     return;
@@ -1116,10 +1144,16 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   g4.c = gates, g4.ldc = 4 * Hs, g4.sC1 = SDH, g4.m = rows, g4.n = SDH, g4.k = SDH, g4.nb1 = NH, g4.nb2 = 4;
   // (head dim <= 128: up to 768 rows as well -- 16M at 256 envs +2.6 %; at 6144 rows -1.5 %, 206M's 320-wide heads at 768 rows -1 %)
   const bool gates_big = rows <= e->slstm_gates_rows && gemm_skinny_supported(g4) && g4.k <= 128;
-  if (e->slstm_gates_one && (takes_skinny(e, g4) || gates_big)) {
+  // (every table entry must meet the few-row kernel's 16-byte alignment, not only entry 0 that g4.a / g4.w stand for: a
+  // misaligned later entry falls back to the four separate launches instead of failing inside launch_gemm_skinny)
+  bool tab_aligned = true;
+  for (int g = 0; g < 4; ++g)
+    tab_aligned = tab_aligned && ((reinterpret_cast<uintptr_t>((g < 2) ? XC : XN) | reinterpret_cast<uintptr_t>(w.gate_w[g])) & 15) == 0;
+  if (e->slstm_gates_one && tab_aligned && (takes_skinny(e, g4) || gates_big)) {
     for (int g = 0; g < 4; ++g)
       g4.a_tab[g] = (g < 2) ? XC : XN, g4.w_tab[g] = w.gate_w[g], g4.c_tab[g] = gates + (int64_t)g * Hs;
     launch_gemm_skinny(g4, s);
+    count_gemm(e, 3, g4);
   } else {
     for (int g = 0; g < 4; ++g) {
       GemmArgs ga;
@@ -1168,6 +1202,7 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   if (takes_skinny_with_norm(e, up)) {  // few rows: the FFN's norm inside the projection's prologue
     up.a = X, up.norm_g = w.ffn_norm_g, up.norm_b = w.ffn_norm_b, up.norm_eps = c.ln_eps, up.norm_rms = c.norm_is_rms;
     launch_gemm_skinny(up, s);
+    count_gemm(e, 3, up);
   } else {
     launch_row_norm(X, D, XN, D, w.ffn_norm_g, w.ffn_norm_b, rows, D, c.ln_eps, c.norm_is_rms, s, nullptr, nullptr, 0, amx);
     up.a_amax = amx;
@@ -1310,6 +1345,10 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
           la.lean_xa = e->XA.p + r0 * e->icols, la.lean_u = e->U.p + r0 * e->ucols;
           la.lean_wq = w.wq, la.lean_wk = w.wk, la.lean_wv = w.wv;
           if (gn_fused(e, T)) la.gn_g = w.on_g, la.gn_b = w.on_b, la.gn_skip = w.skip, la.gn_eps = c.ln_eps;
+          if (gate_in_pass(e, T)) {
+            la.gn_gate = e->U.p + r0 * e->ucols + c.inner, la.gn_ldg = 2 * c.inner;
+            la.gn_amax = e->AMX_H.p + r0 * c.n_heads;
+          }
         }
         if (fused) {  // this slice's due envs: C_base <- g C_base + window, and q . C_new for the read pass, in one pass
           la.ypart = e->YPART.p + (size_t)x.b0 * c.n_heads * (la.DH / 64) * T * la.DH;
@@ -1684,17 +1723,31 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   if (multi) join_slices(e, sl, hbm, s);
 }
 
+// Do the repeated forwards of the Mamba reference-trajectory mode share the token front end and layer 0's in_proj?
+bool compat_shares(const lram_engine* e, int discrete) {
+  const int passes = discrete ? 1 : std::max(1, std::min(e->compat_repeat, e->cfg.act_dim));
+  return passes > 1 && e->cfg.backbone == LRAM_BACKBONE_MAMBA && e->compat_share && e->cfg.n_blocks >= 2;
+}
+// ... then pass 0 keeps them in X0 / U0.  Called by lram_step BEFORE any stream capture begins: hipMalloc on a thread with
+// an active capture fails with hipErrorStreamCaptureUnsupported and invalidates the capture (graph mode + repeated forwards).
+void compat_prepare(lram_engine* e, int discrete) {
+  if (e->B <= 0 || !compat_shares(e, discrete)) return;
+  const size_t bt = (size_t)e->B * e->cfg.tokens_per_step;
+  if (e->X0.n < bt * e->cfg.d_model) e->X0.alloc(bt * e->cfg.d_model);
+  if (e->U0.n < bt * 2 * e->cfg.d_inner) e->U0.alloc(bt * 2 * e->cfg.d_inner);
+}
+
 void step_launches(lram_engine* e, const float* obs, int emb, const float* rtg, const float* rew,
                    const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s) {
   // compat_repeat (reference DiscreteDecisionMamba.get_action_pred, src/algos/decision_mamba.py:107-122): the same
   // (state, rtg, reward) tokens go through the stack once per action dim with the cache on, and action dim i is the
   // prediction of forward i.  Forward p writes action columns >= p, so column i keeps forward min(i, repeat - 1).
   const int passes = discrete ? 1 : std::max(1, std::min(e->compat_repeat, e->cfg.act_dim));
-  const bool share = passes > 1 && e->cfg.backbone == LRAM_BACKBONE_MAMBA && e->compat_share && e->cfg.n_blocks >= 2;
-  if (share) {
+  const bool share = compat_shares(e, discrete);
+  if (share) {  // (allocated by compat_prepare ahead of this call: never inside a stream capture)
     const size_t bt = (size_t)e->B * e->cfg.tokens_per_step;
-    if (e->X0.n < bt * e->cfg.d_model) e->X0.alloc(bt * e->cfg.d_model);
-    if (e->U0.n < bt * 2 * e->cfg.d_inner) e->U0.alloc(bt * 2 * e->cfg.d_inner);
+    LRAM_REQUIRE(e->X0.n >= bt * e->cfg.d_model && e->U0.n >= bt * 2 * e->cfg.d_inner,
+                 "shared repeated forwards: workspace not prepared");
   }
   e->compat_passes = share ? passes : 1;
   for (int p = 0; p < passes; ++p) {
@@ -1775,6 +1828,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_LEAN_FRONT")) e->lean_front = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_A3")) e->use_a3 = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SPLIT_UP")) e->split_up = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_GATE_IN_PASS")) e->gate_in_pass = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FOLD_BUBBLES")) e->fold_bubbles = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_FOLD_SPREAD")) e->fold_spread = std::atoi(v) != 0;
@@ -1895,6 +1949,7 @@ int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding
       persist_step(e, path, dev_obs, obs_is_embedding, dev_rtg, dev_reward, dev_reset_mask, discrete, dev_actions, dev_tokens, s);
       return;
     }
+    compat_prepare(e, discrete);  // (workspace of the shared repeated forwards: outside any capture)
     if (e->graph_mode && !e->prof_on) {
       GraphKey key{};
       key.obs = dev_obs, key.rtg = dev_rtg, key.rew = dev_reward, key.mask = dev_reset_mask, key.act = dev_actions;
@@ -2163,6 +2218,14 @@ int32_t lram_profile_end_split(lram_engine* e, double* main_ms, int64_t* n_main,
     e->prof_on = false;
     e->prof_used = 0;
   });
+}
+
+int32_t lram_gemm_counts(lram_engine* e, double* out8, int32_t reset) {
+  if (e == nullptr || out8 == nullptr) return 1;
+  for (int i = 0; i < 8; ++i) out8[i] = e->gemm_counts[i];
+  if (reset)
+    for (int i = 0; i < 8; ++i) e->gemm_counts[i] = 0.0;
+  return 0;
 }
 
 int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,

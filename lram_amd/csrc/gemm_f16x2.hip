@@ -19,8 +19,8 @@
 //
 // W is split once when the weights are finalised (two [N,K] f16 planes + the per-row inverse scale); A is split on
 // the fly while its fp32 tile is staged into LDS; its per-row scale is derived from the row's largest magnitude, which
-// the kernel that produced A hands over (norm kernels: one wave per row; the Mamba conv / state-update kernels: an
-// atomic max per wave) or `launch_row_amax` computes.  Scales are powers of two: un-scaling the accumulator is exact.
+// the kernel that produced A hands over (norm kernels: one wave per row; the Mamba conv / state-update kernels: one
+// partial maximum per wave, plain stores, reduced in this kernel's prologue via `amax_parts`) or `launch_row_amax` computes.  Scales are powers of two: un-scaling the accumulator is exact.
 #include <algorithm>
 #include <cstdlib>
 

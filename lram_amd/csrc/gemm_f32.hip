@@ -292,7 +292,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_kernel(GemmArgs g) {
   const int row = m0 + er, col = n0 + ec;
   const bool ok = tid < 256 && row < g.m && col < g.n;
   float4 bz = make_float4(0.f, 0.f, 0.f, 0.f), rz = bz;
-  const bool vec = ok && col + 3 < g.n && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+  // (the residual shares C's row pitch; its base must be 16-byte aligned too for the float4 load below)
+  const bool vec = ok && col + 3 < g.n && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+                   (!HAS_RES || (reinterpret_cast<uintptr_t>(R) & 15) == 0);
   if (HAS_BIAS && ok) {
     bz.x = bias[col];
     if (col + 1 < g.n) bz.y = bias[col + 1];

@@ -223,7 +223,9 @@ void launch_mlstm_front(const MlstmFrontArgs& a_in, hipStream_t stream) {
     const char* v = std::getenv("LRAM_FRONT_EPW");
     return v ? std::atoi(v) : 0;
   }();
-  a.epw = epw_env > 0 ? epw_env : (a.epw > 0 ? a.epw : 4);
+  // (same box, 4096 env slots: 2 envs per workgroup 426.2k env-steps/s, 4: 429.4k, 8: 431.1k / 429.7k, 16: 430.8k / 431.9k;
+  // the one-workgroup-per-env kernel 420.3k / 419.0k -- profiles/r04_ab_front_kernel.txt)
+  a.epw = epw_env > 0 ? epw_env : (a.epw > 0 ? a.epw : 8);
   const int nwg = (a.B + a.epw - 1) / a.epw;
   hipLaunchKernelGGL(mlstm_front_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, stream, a);
   LRAM_HIP_CHECK(hipGetLastError());

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   float* red = ks + T * DH;         // [RP][T][CW]
   float* pw = red + RP * T * CW;    // [T][WT]
   float* s_coef = pw + T * WT;      // [W]
-  float* gnred = s_coef + W;        // [2][4][T] group-norm partial sums (mean, then variance) per wave
+  float* gnred = s_coef + W;        // [3][4][T] group-norm partial sums (mean, then variance) and output maxima per wave
 
   const int b = blockIdx.z, h = blockIdx.y, slice = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -754,17 +754,42 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       if (lane == 0) gnred[4 * T + wave * T + t] = sq;
     }
     __syncthreads();
+    float gmx[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) gmx[t] = 0.f;
     if (tid < CW) {
       const int ch = h * DH + tid;
       const float gg = a.gn_g[ch], bb = a.gn_b != nullptr ? a.gn_b[ch] : 0.f, sk = a.gn_skip[ch];
+      // (all of the epilogue's operands requested before the first store)
+      float xs[T], zs[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int64_t row = (int64_t)b * T + t;
+        xs[t] = a.lean_xa[row * inner + ch];
+        zs[t] = a.gn_gate != nullptr ? a.gn_gate[row * a.gn_ldg + ch] : 1.f;
+      }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float* q4 = gnred + 4 * T;
         const float var = (q4[t] + q4[T + t] + q4[2 * T + t] + q4[3 * T + t]) / (float)DH;
         const float rstd = 1.f / sqrtf(var + a.gn_eps);
         const int64_t off = ((int64_t)b * T + t) * inner + ch;
-        a.h[off] = dv[t] * rstd * gg + bb + sk * a.lean_xa[off];
+        float o = dv[t] * rstd * gg + bb + sk * xs[t];
+        if (a.gn_gate != nullptr) o *= zs[t];
+        gmx[t] = fabsf(o);
+        a.h[off] = o;
       }
+    }
+    if (a.gn_amax != nullptr) {  // (uniform) largest magnitude of this (row, head) slice of the gated output
+      float* mxs = gnred + 8 * T;  // [4][T]
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float mx = wave_max(gmx[t]);
+        if (lane == 0) mxs[wave * T + t] = mx;
+      }
+      __syncthreads();
+      if (tid < T)
+        a.gn_amax[((int64_t)b * T + tid) * NH + h] = fmaxf(fmaxf(mxs[tid], mxs[T + tid]), fmaxf(mxs[2 * T + tid], mxs[3 * T + tid]));
     }
   }
   if (slice == 0) {
@@ -803,7 +828,7 @@ template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false, bool EA
 void launch_cell_tluk(const MlstmLazyArgs& a, hipStream_t s) {
   constexpr int CW = 4 * LPR, RP = 256 / LPR;
   dim3 grid(a.DH / CW, a.NH, a.B), block(256);
-  size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW + T * kLazyWT + W + 8 * T);
+  size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW + T * kLazyWT + W + 12 * T);
   shmem = std::max(shmem, (size_t)a.min_lds_bytes);
   // 116 VGPRs would let four workgroups share a CU; three (41 KB of LDS each) leave 152 registers per SIMD lane free,
   // so the slice streams' front-end and 64-row GEMM workgroups start beside them at once and a 128-row GEMM

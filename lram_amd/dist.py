@@ -85,3 +85,38 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def collective_report(sample: torch.Tensor, total: Optional[int] = None, iters: int = 20) -> dict:
+    """What the one data-path collective costs on this job, for the first multi-GPU run to explain itself: backend and its
+    library version (RCCL reports through torch.cuda.nccl.version()), the all-gather of one action tensor timed over
+    `iters` back-to-back calls between device synchronisations (latency-bound: 128 KB per rank at 4096 env slots).  Every rank
+    must call it; {} without a process group."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return {}
+    import time
+    backend = dist.get_backend()
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            version = None
+    on_gpu = sample.device.type == "cuda"
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize(sample.device)
+
+    for _ in range(3):
+        all_gather_actions(sample, total)
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        all_gather_actions(sample, total)
+    sync()
+    dt = (time.perf_counter() - t0) / iters
+    return {"backend": backend, "library_version": version, "world_size": dist.get_world_size(),
+            "all_gather_us": max_over_ranks(dt, sample.device) * 1e6,
+            "all_gather_bytes_per_rank": sample.numel() * sample.element_size(), "iters": iters}

@@ -82,6 +82,7 @@ _SYMBOLS = {
     "lram_get_state_mode": (ctypes.c_int32, [_VP]),
     "lram_stream_rmw": (ctypes.c_int32, [_VP, ctypes.c_size_t, _VP]),
     "lram_stream_read": (ctypes.c_int32, [_VP, ctypes.c_size_t, _VP, _VP]),
+    "lram_gemm_counts": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.c_int32]),
     "lram_pad_obs": (ctypes.c_int32, [_VP, ctypes.c_int32, _VP, _VP, _VP, _VP, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_selftest_concurrent": (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]),
     "lram_stream_copy": (ctypes.c_int32, [_VP, _VP, ctypes.c_size_t, _VP]),
@@ -420,6 +421,14 @@ class Engine:
         _check(self.lib, self.lib.lram_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
 
+
+    def gemm_counts(self, reset: bool = False) -> dict:
+        """Projection launches and fp32-equivalent FLOPs per kernel family of the dispatcher since the last reset
+        (lram_gemm_counts): what the engine actually ran, whatever LRAM_GEMM says."""
+        buf = (ctypes.c_double * 8)()
+        _check(self.lib, self.lib.lram_gemm_counts(self._h, buf, 1 if reset else 0))
+        names = ("f16x2", "bf16x3", "f32", "few_row_f32")
+        return {n: {"launches": int(buf[i]), "flop": float(buf[4 + i])} for i, n in enumerate(names)}
 
     def profile_end_split(self):
         """(state-pass ms, state-pass launches, fold ms, fold launches) -- lram_profile_end_split."""

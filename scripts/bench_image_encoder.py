@@ -5,7 +5,7 @@ import torch
 from lram_amd import init_state_dict
 from lram_amd.config import ModelSpec
 from lram_amd.engine import Engine
-from lram_amd.image_encoder import ImageEncoder
+from tests.torch_image_encoder import ImageEncoder
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 1280

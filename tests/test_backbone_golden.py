@@ -178,3 +178,92 @@ def test_engine_equals_the_xlstm_package(hip_lib):
 @pytest.mark.gpu
 def test_engine_equals_the_mamba_ssm_package(hip_lib):
     check_mamba_on_engine(_package_fixture("backbone_mamba.npz"))
+
+
+# ---- the kit must DISCRIMINATE: a wrong axis / gate order in the layouts it is there to pin has to turn it red ------------
+# Until a package-made fixture exists, the sLSTM `_recurrent_kernel_` (head, in, gate, out) axis order, the `_bias_`
+# (head, gate, dh) gate order and the i / f gate wiring are recalled (reference call sites
+# src/algos/models/decision_xlstm.py:29-38,71-101; lram_amd/weights.py::engine_layout).  With the tiny config's sLSTM
+# head dim the recurrent kernel is 32 x 32 per gate: a transposed in / out axis has the SAME shape and loads silently, so the
+# comparison -- not a shape check -- is what has to catch it.  These tests take an oracle-made fixture with asymmetric
+# weights (every slice along every axis statistically distinct, as the package generator makes them), corrupt ONE layout
+# convention in the stored state dict, and require the check to FAIL.
+def _asymmetric_fixture(d):
+    """Oracle-made fixture whose backbone weights are the kit's asymmetric values (not the near-symmetric initialiser's)."""
+    from lram_amd import init_state_dict
+    spec = kit.spec_from_xlstm_cfg(kit.XLSTM_CFG)
+    sd = {k: v for k, v in init_state_dict(spec, seed=3).items() if k.startswith("encoder.layers.")}
+    g = torch.Generator().manual_seed(11)
+    for name in sorted(sd):
+        p = sd[name]
+        scale = 0.1 if ("norm" in name and p.dim() == 1) else (0.5 if p.dim() == 1 else 1.5 / max(p.shape[-1], 1) ** 0.5)
+        v = torch.randn(p.shape, generator=g) * scale
+        if p.dim() >= 1 and p.shape[-1] > 1:
+            v = v * torch.linspace(0.7, 1.3, p.shape[-1])
+        sd[name] = v.to(p.dtype)
+    x = torch.randn(kit.B, kit.STEPS, spec.d_model, generator=torch.Generator().manual_seed(12))
+    ys, state = [], None
+    for t in range(kit.STEPS):
+        y, state = xlstm_ref.stack_step(spec, sd, x[:, t].unsqueeze(1), state)
+        ys.append(y)
+    arrays = {"x": x.numpy(), "y": torch.cat(ys, dim=1).numpy()}
+    kit._flatten_state("state", state, arrays)
+    for k, v in sd.items():
+        arrays["sd/" + k[len("encoder.layers."):]] = v.numpy()
+    path = os.path.join(d, "backbone_xlstm.npz")
+    kit._save(path, {"source": "oracle", "package": "xlstm", "version": None, "config": kit.XLSTM_CFG, "B": kit.B,
+                     "steps": kit.STEPS}, arrays)
+    return path
+
+
+def _corrupt(path, out_path, key_suffix, fn):
+    z = np.load(path)
+    arrays = {k: z[k] for k in z.files if k != "meta"}
+    hits = [k for k in arrays if k.startswith("sd/") and k.endswith(key_suffix)]
+    assert hits, key_suffix
+    for k in hits:
+        new = fn(arrays[k])
+        assert new.shape == arrays[k].shape and not np.array_equal(new, arrays[k]), k   # same shape: nothing but values can tell
+        arrays[k] = np.ascontiguousarray(new)
+    np.savez_compressed(out_path, meta=z["meta"], **arrays)
+    return out_path
+
+
+NEGATIVE_CASES = {
+    "recurrent kernel: in / out axes transposed": ("slstm_cell._recurrent_kernel_", lambda a: a.transpose(0, 3, 2, 1)),
+    "recurrent kernel: gate order rotated": ("slstm_cell._recurrent_kernel_", lambda a: np.roll(a, 1, axis=2)),
+    "recurrent bias: gate order rotated": ("slstm_cell._bias_", lambda a: np.roll(a, 1, axis=1)),
+    "recurrent bias: head / gate axes exchanged": ("slstm_cell._bias_",
+                                                   lambda a: a.reshape(a.shape[1], a.shape[0], a.shape[2]).transpose(1, 0, 2)
+                                                   if a.shape[0] != a.shape[1] else np.roll(a, 1, axis=0)),
+}
+
+
+def test_asymmetric_oracle_fixture_is_green_before_it_is_corrupted(tmp_path):
+    check_xlstm_against_oracle(_asymmetric_fixture(str(tmp_path)))
+
+
+@pytest.mark.parametrize("case", sorted(NEGATIVE_CASES))
+def test_backbone_kit_turns_red_on_a_wrong_slstm_layout(tmp_path, case):
+    good = _asymmetric_fixture(str(tmp_path))
+    suffix, fn = NEGATIVE_CASES[case]
+    bad = _corrupt(good, os.path.join(str(tmp_path), "corrupt.npz"), suffix, fn)
+    with pytest.raises(AssertionError, match=r"(xlstm step|slstm|conv|mlstm)"):
+        check_xlstm_against_oracle(bad)
+
+
+def test_backbone_kit_turns_red_on_swapped_slstm_gate_projections(tmp_path):
+    """igate <-> fgate weights of the sLSTM block exchanged (the package wires module `fgate` into the cell's input-gate
+    slot: lram_amd/weights.py keeps that; a 'fix' of it must not pass)."""
+    good = _asymmetric_fixture(str(tmp_path))
+    z = np.load(good)
+    arrays = {k: z[k] for k in z.files if k != "meta"}
+    ik = [k for k in arrays if k.endswith("xlstm.igate.weight") and "mlstm_cell" not in k]
+    assert ik
+    for k in ik:
+        fk = k.replace("igate", "fgate")
+        arrays[k], arrays[fk] = arrays[fk], arrays[k]
+    bad = os.path.join(str(tmp_path), "swapped.npz")
+    np.savez_compressed(bad, meta=z["meta"], **arrays)
+    with pytest.raises(AssertionError, match=r"(xlstm step|slstm)"):
+        check_xlstm_against_oracle(bad)

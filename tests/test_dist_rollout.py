@@ -140,6 +140,8 @@ def test_bench_starts_its_own_ranks_from_a_plain_process(tmp_path):
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
     assert line["config"]["global_batch"] == 12 and line["config"]["batch_per_gpu"] == 6
     assert torch.tensor(line["last_actions"]).shape == (12, 4)
+    col = line["collective"]    # the one data-path collective explains itself: backend, version, measured latency
+    assert col["backend"] == "gloo" and col["world_size"] == 2 and col["all_gather_us"] > 0 and col["iters"] == 20
     # same through bench.main from a plain process (no WORLD_SIZE): the parsed line comes back
     import bench
     saved = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}

@@ -14,7 +14,12 @@ def test_bench_line_contract_and_physical_roofline(hip_lib, capsys):
         assert key in out, key
     assert out["metric"].startswith("env-steps/sec") and out["unit"] == "env-steps/s" and out["dtype"] == "f32"
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["vs_baseline"] is None
-    assert out["config"]["state_mode"] == "lazy" and "f16x2" in out["config"]["workload"]
+    assert out["config"]["state_mode"] == "lazy"
+    # the workload line names the projection kernel that actually served most of the FLOPs (engine dispatch counters), not
+    # the LRAM_GEMM default: at 512 env slots the slices hold 768 operand rows, below the f16x2 kernel's 1024-row threshold
+    disp = out["gemm_dispatch_per_step"]
+    main = max(disp, key=lambda k: disp[k]["gflop"])
+    assert main == "bf16x3" and "bf16x3" in out["config"]["workload"] and disp[main]["launches"] > 0
     assert out["ranks_seen"] == 1
     assert abs(out["value"] - 512 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
     r = out["roofline"]

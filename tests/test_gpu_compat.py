@@ -156,3 +156,29 @@ def test_shared_repeated_forwards_equal_the_unshared_ones(hip_lib, monkeypatch):
     monkeypatch.delenv("LRAM_COMPAT_SHARE")
     assert float((outs["1"][0][..., :R] - outs["0"][0][..., :R]).abs().max()) <= 1e-4
     assert rel_err(outs["1"][1], outs["0"][1]) < 1e-5 and rel_err(outs["1"][2], outs["0"][2]) < 1e-5
+
+
+def test_graph_replay_with_shared_repeated_forwards(hip_lib):
+    """hipGraph decode + the reference-trajectory mode (repeated forwards sharing the front end): the X0 / U0 workspace is
+    allocated BEFORE the capture begins (a hipMalloc inside a capture would invalidate it and every later call would retry
+    and fail -- round-3 advisor finding).  Same actions and state as the un-captured engine, over a second and third replay."""
+    from lram_amd.engine import Engine
+    spec = preset("mamba_tiny")
+    sd = init_state_dict(spec, seed=5)
+    B, R = 3, 3
+    seq = make_inputs(spec, B, 5, seed=78, reset_prob=0.0)
+    eager = Engine(spec, sd, B, device="cuda:0")
+    eager.set_compat_mode(R, True)
+    graph = Engine(spec, sd, B, device="cuda:0")
+    graph.set_compat_mode(R, True)
+    graph.set_graph_mode(True)
+    d_obs, d_rtg = torch.empty(B, spec.state_dim, device="cuda"), torch.empty(B, device="cuda")
+    d_rew = torch.zeros(B, device="cuda")
+    for obs, rtg, rew, _ in seq:
+        a_e, _ = eager.step(obs.cuda(), rtg.cuda(), rew.cuda(), None)
+        d_obs.copy_(obs), d_rtg.copy_(rtg)
+        a_g, _ = graph.step(d_obs, d_rtg, d_rew, None)      # fixed device buffers: one capture, then replays
+        torch.cuda.synchronize()
+        assert float((a_e[:, :R] - a_g[:, :R]).abs().max()) <= 1e-4
+    assert rel_err(graph.export_state_tensor(0, 0), eager.export_state_tensor(0, 0)) < 1e-5
+    eager.close(), graph.close()

@@ -120,7 +120,7 @@ def test_image_encoder_kernels_match_oracle(hip_lib, d_model, B):
     (image_encoders.py:10-131) == the PyTorch/MIOpen module, on uint8 frames; odd batch, both model widths."""
     from lram_amd.config import ModelSpec
     from lram_amd.engine import Engine
-    from lram_amd.image_encoder import ImageEncoder
+    from tests.torch_image_encoder import ImageEncoder
     from oracle.dt_ref import impala_cnn
     spec = ModelSpec(backbone="xlstm", d_model=d_model, n_blocks=2, slstm_at=[1])
     sd = init_state_dict(spec, seed=7, with_image_encoder=True)

@@ -125,7 +125,7 @@ def test_impala_cnn_shapes_and_image_path():
     a = pol.step(img, torch.ones(2), torch.zeros(2), discrete=True)
     assert a.shape == (2, 1) and a.dtype == torch.int64 and int(a.max()) < spec.n_discrete
     # the product's torch image encoder computes the same embedding as the oracle's functional restatement
-    from lram_amd.image_encoder import ImageEncoder
+    from tests.torch_image_encoder import ImageEncoder
     enc = ImageEncoder.from_state_dict(sd, spec.image_shape, spec.d_model)
     ref = dt_ref.impala_cnn(sd, "embed_image.", img.float() / 255.0)
     assert rel_err(enc(img), ref) < 1e-6

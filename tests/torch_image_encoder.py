@@ -1,6 +1,6 @@
-"""IMPALA-style image observation encoder in PyTorch-ROCm / MIOpen: a cross-check of the engine's own kernels
-(`lram_embed_images`, csrc/impala_cnn.hip), which are what `RecurrentAgent` uses; built only on request
-(`RecurrentAgent(torch_image_encoder=True)`, tests, scripts/bench_image_encoder.py).
+"""TEST INFRASTRUCTURE (not part of the product package): IMPALA-style image observation encoder in PyTorch-ROCm / MIOpen,
+an independent cross-check of the engine's own kernels (`lram_embed_images`, csrc/impala_cnn.hip), which are the only
+image backend `RecurrentAgent` has.  Used by tests/ and scripts/bench_image_encoder.py.
 
 
 Front end of the hot path for image domains (Atari / Procgen / Mimicgen-vision): uint8 [B,3,64,64] ->
