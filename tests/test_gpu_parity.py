@@ -124,14 +124,19 @@ def test_gemm_f16x2_matches_fp64(hip_lib, m, n, k, spread):
     assert torch.isfinite(out2).all()
     e2 = ((out2.cpu().double() - ref).abs() / scale)[1:].max().item()
     e1 = ((out1.cpu().double() - ref).abs() / scale)[1:].max().item()
-    assert e2 < 1.5 * e1 + 1e-7, (m, n, k, spread, e2, e1)
+    # measured (profiles/r04_f16x2_accuracy.txt, scripts/f16x2_accuracy.py): on every shape with K >= 32 the split kernel
+    # is CLOSER to fp64 than the fp32 fma chain (0.41 ... 0.97 x its error: it rounds 22-bit products into an fp32
+    # accumulator, the chain rounds after every fma); with a single 8-deep K tile the chain is all but exact
+    # (e1 ~ 1e-7) and the ratio is 1.4 ... 1.8.  No additive slack: round 3's `+ 1e-7` let it be 2-4 x worse unnoticed.
+    assert e2 < (1.25 if k >= 32 else 2.5) * e1, (m, n, k, spread, e2, e1, e2 / e1)
     if spread == "tiny":
         assert torch.equal(out2[0].cpu(), bias)                                        # zero row: bias only, exactly
     base = torch.randn(m, n, generator=g)
     out3 = gemm_f32(a.cuda(), w.cuda(), None, out=base.clone().cuda(), accumulate=True, kernel="f16x2")
     torch.cuda.synchronize()
     ref3 = base.double() + a.double() @ w.double().t()
-    assert ((out3.cpu().double() - ref3).abs() / (scale + 1)).max().item() < 1.5 * e1 + 1e-7
+    # (accumulating into a base tensor adds one fp32 rounding of |base| ~ 1 per output: 6e-8 on the (scale + 1) metric)
+    assert ((out3.cpu().double() - ref3).abs() / (scale + 1)).max().item() < (1.25 if k >= 32 else 2.5) * e1 + 6e-8
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 80, 1536), (4096, 512, 1024), (257, 129, 48)])
