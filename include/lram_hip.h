@@ -273,6 +273,14 @@ int32_t lram_gemm_skinny(const float* dev_a, int64_t lda, const float* dev_w, in
 int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                         int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                         int32_t k, void* stream);
+/* The f16x2 arithmetic with the activation operand pre-split too (gemm_f16x2p.hip): A goes through the row-split kernel
+ * (two f16 planes of the row-scaled rows + inverse scales -- what the engine's norm kernels write directly), both operands
+ * are then staged global -> LDS by DMA and the inner loop is MFMAs only.  k a multiple of 32, <= 3072.  Same accuracy
+ * contract as lram_gemm_f16x2 (the pieces and the products are the same; the result is bit-identical to it).
+ * Test / micro-benchmark entry. */
+int32_t lram_gemm_f16x2_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
+                                 int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
+                                 int32_t k, void* stream);
 /* The same with the activation operand pre-split into three bf16 planes first (the form in which the engine's norm /
  * gate / state-update kernels hand their results to the big projections): bit-identical to lram_gemm_bf16x3. */
 int32_t lram_gemm_bf16x3_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,

@@ -75,6 +75,12 @@ struct GemmArgs {
   const float* w_inv = nullptr;
   const float* a_amax = nullptr;
   int amax_parts = 1;  // row r's maximum = max of a_amax[r * amax_parts + 0 .. amax_parts - 1]
+  // optional (f16x2 kernel with pre-split operands, gemm_f16x2p.hip): A pre-split by its producer into two f16 planes (hi, lo)
+  // of the row-scaled value, laid out like a (row stride lda), `a2_plane` elements apart, with a2_inv[r] = the exact inverse
+  // of row r's power-of-two scale (`a` may then be null; K a multiple of 32)
+  const uint16_t* a2 = nullptr;
+  int64_t a2_plane = 0;
+  const float* a2_inv = nullptr;
   // optional split-K workspace (un-batched GEMMs with few output tiles: skinny N or small M): partial [S][M][N]
   // slabs are written by S x tiles workgroups and summed, in fixed order, by a second tiny kernel (deterministic)
   float* splitk_ws = nullptr;
@@ -91,11 +97,34 @@ struct GemmArgs {
   const float* norm_b = nullptr;
   float norm_eps = 0.f;
   int norm_rms = 0;
+  // set by the launcher (gemm_choose_xcd_split): the 8 XCDs (each with its own 4 MB L2) take an xcd_gm x xcd_gn grid of
+  // output blocks, xcd_gm * xcd_gn == 8; 0 = the one-dimensional map (each XCD a contiguous run of tiles, M-major)
+  int xcd_gm = 0, xcd_gn = 0;
   int mfma_prio = 0;      // set by the launcher (LRAM_GEMM_PRIO): raise the wave's issue priority around the MFMA block
   int split_k = 1;        // set by the launcher
   int k_tiles_per_split = 0;
 };
 int gemm_choose_split_k(GemmArgs& g);                             // fills split_k / k_tiles_per_split, returns S
+// Output-tile -> XCD map of the 128-column-tile projection kernels (bm = their tile height, bytes_per_elem = operand bytes
+// per element as staged: 4 for fp32 / two f16 planes).  Hardware hands consecutive workgroup ids to the 8 XCDs in turn, so
+// workgroups b, b + 8, ... share an L2.  Every XCD streams its M band of A once and wants its N band of W resident in
+// its 4 MB L2: the split (gm, gn) minimises M * gn + N * gm over the splits whose W band fits and that divide the tile grid.
+void gemm_choose_xcd_split(GemmArgs& g, int bm, int bn, int bytes_per_elem);
+// the tile a workgroup id maps to under that split (device side)
+__device__ __forceinline__ void gemm_tile_of(const GemmArgs& g, int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  if (g.xcd_gm > 0) {
+    const int x = bid & 7, idx = bid >> 3;                    // XCD, position in that XCD's stream of workgroups
+    const int bm_t = tiles_m / g.xcd_gm, bn_t = tiles_n / g.xcd_gn;   // tiles per band
+    const int xm = x / g.xcd_gn, xn = x - xm * g.xcd_gn;
+    tm = xm * bm_t + idx / bn_t;                              // M outer, N inner: the band's N tiles of one M tile run together
+    tn = xn * bn_t + idx % bn_t;
+    return;
+  }
+  if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);
+  tm = bid / tiles_n;
+  tn = bid - tm * tiles_n;
+}
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream);  // C = sum_s ws[s] (+ bias) (+ residual)
 void launch_gemm_f32(const GemmArgs& g, hipStream_t stream);      // exact fp32 MFMA (k-ordered fma chain)
 bool gemm_small_m(const GemmArgs& g);                             // M <= 8: launch_gemm_f32 takes the GEMV path
@@ -107,6 +136,11 @@ void launch_gemm_bf16x3(const GemmArgs& g, hipStream_t stream);   // fp32-accura
 void launch_split_bf16x3(const float* w, uint16_t* out, size_t n, hipStream_t stream);
 bool gemm_f16x2_supported(const GemmArgs& g);
 void launch_gemm_f16x2(const GemmArgs& g, hipStream_t stream);    // fp32-accurate, 2 x f16 split operands, row-scaled
+bool gemm_f16x2p_supported(const GemmArgs& g);
+void launch_gemm_f16x2p(const GemmArgs& g, hipStream_t stream);   // the same with A pre-split too: DMA staging, MFMA-only loop
+// planes[0 / 1][r][k] (row pitch ldp, `plane` elements apart) = hi / lo of scale_r * a[r][k] (* gate[r][k]), inv[r] = 1 / scale_r
+void launch_row_split_f16x2(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, uint16_t* planes,
+                            int64_t ldp, int64_t plane, float* inv, hipStream_t stream);
 // amax[r] = max_k |a[r][k] (* gate[r][k])|
 void launch_row_amax(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* amax,
                      hipStream_t stream);
@@ -128,12 +162,15 @@ struct ScalarTokens {
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2 = nullptr,
                      uint16_t* planes = nullptr, int64_t plane_stride = 0,   // planes: bf16x3 GEMM operand (row stride
-                     float* amax = nullptr, const ScalarTokens* st = nullptr);                                 // out_stride); out may then be null
+                     float* amax = nullptr, const ScalarTokens* st = nullptr,                                  // out_stride); out may then be null
+                     uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr);  // f16x2 operand planes (hi, lo) of the
+                                                                                             // row-scaled result + inverse row scales
 // Mamba block entry: res_out = hidden (+ res_in);  normed = RMSNorm(res_out) * gamma.
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
                          const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes = nullptr,
                          int64_t plane_stride = 0,  // planes: `normed` as a bf16x3 GEMM operand (normed may be null)
-                         float* amax = nullptr);    // [rows] largest |normed| per row (f16x2 GEMM's a_amax)
+                         float* amax = nullptr,     // [rows] largest |normed| per row (f16x2 GEMM's a_amax)
+                         uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr);  // f16x2 operand planes of `normed`
 
 // ---------------------------------------------------------------------------------------------
 // front end / head

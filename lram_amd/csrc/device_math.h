@@ -65,6 +65,21 @@ __device__ __forceinline__ float pow2_scale(float mx) {
   se = se > 254 ? 254 : (se < 1 ? 1 : se);
   return __uint_as_float((unsigned)se << 23);
 }
+// Exact 2-way f16 split of s * v (the operand format of gemm_f16x2p.hip): p points at the element in the hi plane, the lo
+// plane is `plane` elements on.  s is the row's power-of-two scale (pow2_scale of its largest magnitude).
+__device__ __forceinline__ void split2_store4(const float4& v, float s, _Float16* p, int64_t plane) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const float xs[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+  h4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const _Float16 h = (_Float16)xs[e];
+    hi[e] = h;
+    lo[e] = (_Float16)(xs[e] - (float)h);
+  }
+  *reinterpret_cast<h4*>(p) = hi;
+  *reinterpret_cast<h4*>(p + plane) = lo;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

@@ -2303,6 +2303,36 @@ int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int
   });
 }
 
+int32_t lram_gemm_f16x2_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
+                                 const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(ldw == k, "lram_gemm_f16x2_presplit: W must be contiguous [n, k]");
+    LRAM_REQUIRE(k % 32 == 0 && k <= 3072, "lram_gemm_f16x2_presplit: k must be a multiple of 32, <= 3072");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t wn = (size_t)n * k, an = (size_t)m * k;
+    uint16_t *wp = nullptr, *ap = nullptr;
+    float* scales = nullptr;  // [n] inverse weight scales, then [m] inverse activation scales
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&wp), 2 * wn * sizeof(uint16_t)));
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&ap), 2 * an * sizeof(uint16_t)));
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scales), ((size_t)n + m) * sizeof(float)));
+    try {
+      launch_split_f16x2(dev_w, n, k, wp, scales, s);
+      launch_row_split_f16x2(dev_a, lda, nullptr, 0, m, k, ap, k, (int64_t)an, scales + n, s);
+      GemmArgs g;
+      g.lda = k, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
+      g.residual = accumulate ? dev_c : nullptr;
+      g.m = m, g.n = n, g.k = k, g.w2 = wp, g.w2_plane = (int64_t)wn, g.w_inv = scales;
+      g.a2 = ap, g.a2_plane = (int64_t)an, g.a2_inv = scales + n;
+      launch_gemm_f16x2p(g, s);
+      LRAM_HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      (void)hipFree(wp), (void)hipFree(ap), (void)hipFree(scales);
+      throw;
+    }
+    (void)hipFree(wp), (void)hipFree(ap), (void)hipFree(scales);
+  });
+}
+
 int32_t lram_gemm_bf16x3_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
                                   const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
   return guarded([&] {

@@ -72,11 +72,8 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
 
   const int tiles_n = (g.n + BN - 1) / BN;
   const int tiles_m = (g.m + BM - 1) / BM;
-  const int nwg = tiles_n * tiles_m;
-  int bid = blockIdx.x;
-  if ((nwg & 7) == 0) bid = (bid & 7) * (nwg >> 3) + (bid >> 3);  // XCD-aware tile order (see gemm_f32.hip)
-  const int tm_idx = bid / tiles_n;
-  const int tn_idx = bid - tm_idx * tiles_n;
+  int tm_idx, tn_idx;
+  gemm_tile_of(g, blockIdx.x, tiles_m, tiles_n, tm_idx, tn_idx);  // XCD-aware tile order (common.h)
   const int m0 = tm_idx * BM, n0 = tn_idx * BN;
 
   // row scales from the producers' row maxima: a row's maximum may arrive in `amax_parts` partial maxima (one per wave
@@ -460,6 +457,7 @@ void launch_gemm_f16x2(const GemmArgs& g_in, hipStream_t stream) {
   const bool small = force_bm == 64 || (force_bm == 0 && S == 1 && tiles128 < 768 && tiles_n <= 6 && g.m > 64);
   const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;
   dim3 grid(tiles, 1, S);
+  gemm_choose_xcd_split(g, small ? 64 : 128, BN, 4);
   if (g.gate != nullptr) {
     if (small) launch_bm<64, true>(g, grid, stream); else launch_bm<128, true>(g, grid, stream);
   } else {

@@ -1,0 +1,273 @@
+// f16x2 projection GEMM with BOTH operands pre-split: C[M,N] = A[M,K] * W[N,K]^T, fp32-accurate on the f16 matrix cores.
+//
+// Same arithmetic as gemm_f16x2.hip (rows scaled by a power of two, every scaled element split exactly into two
+// binary16 pieces, hi*hi + hi*lo + lo*hi accumulated in fp32, exact un-scaling) -- what changes is WHERE the A operand is
+// split.  gemm_f16x2_kernel converts its fp32 A tile while it stages it: ~10 vector instructions per element, in every
+// workgroup that touches the tile, i.e. N / 128 times per element (16M proj_up: 16 times, Mamba in_proj: 24 times) -- as
+// many vector cycles per K tile as the tile's 24 MFMAs take, behind barriers that keep the two from overlapping inside a
+// workgroup (matrix pipe 0.27-0.33 busy, profiles/r03_gemm_mfma_busy.json).  Two f16 planes are 4 bytes per element: the
+// same bytes as the fp32 value.  So the kernel that PRODUCES A -- a row norm, which holds the whole row and its maximum in
+// one wave -- writes the two planes and the row's inverse scale instead of fp32 (launch_row_norm / launch_add_rms_norm,
+// `h2`), or launch_row_split_f16x2 does it once per row where the producer cannot, and this kernel's staging is a pure copy
+// for both operands: global -> LDS directly (`global_load_lds_dwordx4`, 1 KiB per wave instruction, no VGPR round trip, no
+// conversion, no LDS-write instructions), an MFMA-only inner loop, two LDS stages with the next tile's DMA in flight
+// under the current tile's MFMAs and ONE barrier per K tile.  110 VGPRs.
+//
+// LDS image of a stage: [A hi][A lo][W hi][W lo], each 128 rows x 32 f16 (64-byte rows, un-padded: the DMA writes 1 KiB
+// contiguously = 16 rows).  A ds_read_b128 fragment read of rows r, r + 4, r + 8, r + 12 would hit the same banks, so
+// the 16-byte chunk index is XOR-ed with (row >> 2) & 3 -- applied on the SOURCE address of the DMA (the lane that fills
+// linear position (row, c) fetches logical chunk c ^ ((row >> 2) & 3)) and on the fragment read, the same involution on
+// both sides (cdna_hip_programming.md section 5.4 rule 21).
+//
+// Replaces on the reference path: nn.Linear in_proj / out_proj of mamba_ssm.Mamba (src/algos/models/decision_mamba.py:78-93),
+// xlstm proj_up / proj_down / FFN projections ([3P], call site src/algos/models/decision_xlstm.py:159-163).
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "device_math.h"
+
+namespace lram {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int PLANE = 128 * BK;      // f16 elements of one 128-row plane tile (8 KiB)
+constexpr int STAGE = 4 * PLANE;     // A hi, A lo, W hi, W lo (32 KiB)
+
+template <bool HAS_BIAS, bool HAS_RES, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) _Float16 lds[NSTAGE * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_n = (g.n + BN - 1) / BN;
+  const int tiles_m = (g.m + BM - 1) / BM;
+  int tm_idx, tn_idx;
+  gemm_tile_of(g, blockIdx.x, tiles_m, tiles_n, tm_idx, tn_idx);  // XCD-aware tile order (common.h)
+  const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+
+  // ---- DMA sources: 32 pieces of 1 KiB per stage (4 planes x 8 row blocks of 16 rows), 8 per wave.  Wave w takes
+  // pieces w, w + 4, ...: piece p = plane (p >> 3), row block (p & 7).  Lane l fills linear position (row = 16 rb + l / 4,
+  // chunk position l & 3) and fetches logical chunk (l & 3) ^ ((row >> 2) & 3) of that row.  Rows beyond M / N are clamped
+  // (their products land in rows / columns the epilogue drops).
+  const _Float16* A2 = reinterpret_cast<const _Float16*>(g.a2);
+  const _Float16* W2 = reinterpret_cast<const _Float16*>(g.w2);
+  const _Float16* src[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = wave + 4 * i;
+    const int plane = p >> 3, rb = p & 7;
+    const int row = 16 * rb + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    if (plane < 2) {
+      const int gm = min(m0 + row, g.m - 1);
+      src[i] = A2 + (int64_t)plane * g.a2_plane + (int64_t)gm * g.lda + 8 * chunk;
+    } else {
+      const int gn = min(n0 + row, g.n - 1);
+      src[i] = W2 + (int64_t)(plane - 2) * g.w2_plane + (int64_t)gn * g.ldw + 8 * chunk;
+    }
+  }
+  auto dma_tile = [&](int stage, int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int p = wave + 4 * i;
+      // (LDS destination: wave-uniform base of the piece; the hardware adds lane * 16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
+                                       (__attribute__((address_space(3))) void*)(lds + stage * STAGE + p * 512), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int sw = (li >> 2) & 3;  // chunk swizzle of this lane's rows (tile row offsets are multiples of 32)
+  const _Float16* a_base = lds + (64 * wm + li) * BK;
+  const _Float16* b_base = lds + 2 * PLANE + (64 * wn + li) * BK;
+
+  const int nk_all = g.k / BK;
+  const int kt0 = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
+  const int nk = g.split_k > 1 ? min(nk_all, kt0 + g.k_tiles_per_split) : nk_all;
+
+  auto mfma_tile = [&](int stage) {
+    if (g.mfma_prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int ko = ((2 * ks + lh) ^ sw) << 3;
+      f16x8 af[2][2], bf[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          af[t][p] = *reinterpret_cast<const f16x8*>(a_base + stage * STAGE + p * PLANE + 32 * t * BK + ko);
+          bf[t][p] = *reinterpret_cast<const f16x8*>(b_base + stage * STAGE + p * PLANE + 32 * t * BK + ko);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);  // lo * hi
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);  // hi * lo
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);  // hi * hi
+        }
+    }
+    if (g.mfma_prio) __builtin_amdgcn_s_setprio(0);
+  };
+
+  if (NSTAGE == 2) {
+    // tile kt sits in stage kt & 1 once the barrier at the top of its iteration is passed (__syncthreads drains the issuing
+    // waves' DMAs: an LDS-DMA is a pending LDS write on the VM counter); the DMA of tile kt + 1 is issued right behind that
+    // barrier -- every wave has then finished reading that stage (tile kt - 1) -- and is in flight under tile kt's MFMAs
+    dma_tile(0, kt0 * BK);
+    for (int kt = kt0; kt < nk; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      __syncthreads();
+      if (kt + 1 < nk) dma_tile(cur ^ 1, (kt + 1) * BK);
+      mfma_tile(cur);
+    }
+  } else {
+    for (int kt = kt0; kt < nk; ++kt) {
+      dma_tile(0, kt * BK);
+      __syncthreads();
+      mfma_tile(0);
+      __syncthreads();
+    }
+  }
+
+  // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5));
+  // un-scale with the exact inverse powers of two of the row (A) and column (W) scales
+  float* C = g.c;
+  float* S = g.split_k > 1 ? g.splitk_ws + (int64_t)blockIdx.z * g.m * g.n : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float ainv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      ainv[r] = g.a2_inv[min(row, g.m - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + 64 * wn + 32 * j + li;
+      if (col >= g.n) continue;
+      const float wi = g.w_inv[col];
+      const float bv = HAS_BIAS ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < g.m) {
+          float v = acc[i][j][r] * (wi * ainv[r]);
+          if (S != nullptr) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
+            S[(int64_t)row * g.n + col] = v;
+            continue;
+          }
+          v += bv;
+          if (HAS_RES) v += g.residual[(int64_t)row * g.ldc + col];
+          if (g.act_silu_from >= 0 && col >= g.act_silu_from) v = silu_f(v);
+          C[(int64_t)row * g.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// One wave per row (K <= 3072): planes[0][r][k] = hi, planes[1][r][k] = lo of scale * a[r][k] (* gate[r][k]);
+// inv[r] = 1 / scale (exact power of two).  The stand-alone form of what the norm kernels do in their epilogue.
+constexpr int kSplitMaxV = 12;
+__global__ __launch_bounds__(256) void row_split_f16x2_kernel(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows,
+                                                              int k, _Float16* planes, int64_t ldp, int64_t plane, float* inv) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int nv = k >> 2;
+  const float* ar = a + (int64_t)row * lda;
+  const float* gr = gate != nullptr ? gate + (int64_t)row * ldg : nullptr;
+  float4 v[kSplitMaxV];
+  float mx = 0.f;
+#pragma unroll
+  for (int j = 0; j < kSplitMaxV; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = i < nv ? *reinterpret_cast<const float4*>(ar + 4 * i) : f4_zero();
+    if (gr != nullptr && i < nv) {
+      const float4 z = *reinterpret_cast<const float4*>(gr + 4 * i);
+      v[j].x *= z.x, v[j].y *= z.y, v[j].z *= z.z, v[j].w *= z.w;
+    }
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+  }
+  const float s = pow2_scale(wave_max(mx));
+#pragma unroll
+  for (int j = 0; j < kSplitMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) split2_store4(v[j], s, planes + (int64_t)row * ldp + 4 * i, plane);
+  }
+  if (lane == 0) inv[row] = 1.f / s;
+}
+}  // namespace
+
+bool gemm_f16x2p_supported(const GemmArgs& g) {
+  return g.a2 != nullptr && g.a2_inv != nullptr && g.w2 != nullptr && g.w_inv != nullptr && g.nb1 * g.nb2 == 1 &&
+         (g.k % BK) == 0 && (g.ldw & 7) == 0 && (g.lda & 7) == 0 && (g.w2_plane & 7) == 0 && (g.a2_plane & 7) == 0 &&
+         g.gate == nullptr && g.a3 == nullptr && (reinterpret_cast<uintptr_t>(g.a2) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(g.w2) & 15) == 0;
+}
+
+void launch_row_split_f16x2(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, uint16_t* planes,
+                            int64_t ldp, int64_t plane, float* inv, hipStream_t stream) {
+  LRAM_REQUIRE((k & 3) == 0 && k <= 4 * 64 * kSplitMaxV && (lda & 3) == 0 && (ldp & 3) == 0 && (gate == nullptr || (ldg & 3) == 0),
+               "row split: K must be a multiple of 4, <= 3072; row pitches multiples of 4");
+  hipLaunchKernelGGL(row_split_f16x2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a, lda, gate, ldg, rows, k,
+                     reinterpret_cast<_Float16*>(planes), ldp, plane, inv);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+template <int NSTAGE>
+static void launch_stage(const GemmArgs& g, dim3 grid, hipStream_t stream) {
+  const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
+  dim3 block(256);
+  if (hb && hr)
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, true, NSTAGE>), grid, block, 0, stream, g);
+  else if (hb)
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, false, NSTAGE>), grid, block, 0, stream, g);
+  else if (hr)
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, true, NSTAGE>), grid, block, 0, stream, g);
+  else
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, false, NSTAGE>), grid, block, 0, stream, g);
+}
+
+void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
+  GemmArgs g = g_in;
+  static const int prio = [] {
+    const char* v = std::getenv("LRAM_GEMM_PRIO");
+    return v ? std::atoi(v) : 1;
+  }();
+  // LRAM_F16P_STAGES (measurement knob): 1 = one LDS stage, two barriers per K tile, up to four workgroups per CU;
+  // 2 = two stages, the next tile's DMA under the current tile's MFMAs, one barrier per K tile, two workgroups per CU
+  static const int stages = [] {
+    const char* v = std::getenv("LRAM_F16P_STAGES");
+    return v ? std::atoi(v) : 2;
+  }();
+  g.mfma_prio = prio;
+  LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
+  LRAM_REQUIRE(gemm_f16x2p_supported(g), "gemm f16x2 (pre-split operands): unsupported operand layout");
+  int S = 1;
+  if (g.act_silu_from >= 0)
+    g.split_k = 1, g.k_tiles_per_split = 0;  // output activation: K unsplit
+  else
+    S = gemm_choose_split_k(g);
+  const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
+  dim3 grid(tiles, 1, S);
+  gemm_choose_xcd_split(g, BM, BN, 4);
+  if (stages == 1) launch_stage<1>(g, grid, stream); else launch_stage<2>(g, grid, stream);
+  LRAM_HIP_CHECK(hipGetLastError());
+  if (S > 1) launch_splitk_reduce(g, stream);
+}
+
+}  // namespace lram

@@ -441,6 +441,26 @@ int gemm_choose_split_k(GemmArgs& g) {
   return S;
 }
 
+void gemm_choose_xcd_split(GemmArgs& g, int bm, int bn, int bytes_per_elem) {
+  // LRAM_GEMM_XCD2D (measurement knob): 0 keeps the one-dimensional map
+  static const int on = [] {
+    const char* v = std::getenv("LRAM_GEMM_XCD2D");
+    return v ? std::atoi(v) : 1;
+  }();
+  g.xcd_gm = g.xcd_gn = 0;
+  if (!on || g.nb1 * g.nb2 != 1) return;
+  const int tiles_m = (g.m + bm - 1) / bm, tiles_n = (g.n + bn - 1) / bn;
+  double best = 0.0;
+  for (int gm = 8; gm >= 1; gm >>= 1) {
+    const int gn = 8 / gm;
+    if (tiles_m % gm != 0 || tiles_n % gn != 0) continue;
+    const double w_band = (double)(tiles_n / gn) * bn * g.k * bytes_per_elem;
+    if (w_band > 3.0e6) continue;                       // the W band must stay resident beside the A tiles in flight
+    const double cost = (double)g.m * gn + (double)g.n * gm;
+    if (g.xcd_gm == 0 || cost < best) best = cost, g.xcd_gm = gm, g.xcd_gn = gn;
+  }
+}
+
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream) {
   const int64_t total = (int64_t)g.m * g.n;
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);

@@ -4,6 +4,8 @@
 // selective_state_update (Triton) as called from [3P] mamba_ssm Mamba.step via
 // src/algos/models/decision_mamba.py:130-147.  State layouts are the reference's:
 // conv_state [B, d_inner, d_conv], ssm_state [B, d_inner, d_state], fp32.
+#include <cstdlib>
+
 #include "common.h"
 #include "device_math.h"
 
@@ -213,6 +215,119 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// selective_state_update, lane = channel form (d_state 16, dt_proj fused, T tokens of an env-step; round 4).
+//
+// mamba_ssm_kernel above spreads a channel's 16 states over 4 lanes and rebuilds everything per workgroup of 4 envs x 64
+// channels: 32 KB of state per workgroup against two barriers, an LDS staging pass full of index arithmetic, a 4-lane
+// shuffle reduction per output and 12 KB of dt_proj weights pulled in again for every 4 envs -- 168 us per 1024-env launch
+// of Mamba-48M for 277 MB = 1.65 TB/s, 21 % of HBM peak (profiles/r03_kernel_stats_mamba48m_b2048.csv): latency-, not
+// bandwidth- or ALU-bound.  Here one LANE owns one channel with all of its 16 states in registers (64 contiguous bytes per
+// lane: a wave reads 4 KB runs), one WAVE owns 64 channels and loops over `epw` env slots with the next env's state / x / z
+// already requested; the per-channel constants -- dt_proj's R weights, A = -exp(A_log), D, dt_bias -- are loaded once per
+// wave, not once per 4 envs.  Everything that is per (env, token) and shared by the channels -- the raw dt row, B_t, C_t
+// -- has a wave-uniform address: scalar loads, SGPR operands, no LDS, no barrier, no cross-lane reduction (y_t is a
+// 16-term in-lane dot).  Same arithmetic as the 4-lane form (dt bit for bit: same k-ordered fma chain); y sums its 16
+// terms in lane order instead of 4 + shuffle tree.  Reference: selective_state_update as called from Mamba.step
+// (src/algos/models/decision_mamba.py:136-138, [3P] mamba_ssm 2.1.0).
+template <int T, int R, bool ILP, int OCC>
+__global__ __launch_bounds__(256, OCC) void mamba_ssm_lane_kernel(float* __restrict__ ssm_state, const float* __restrict__ xc,
+                                                             const float* __restrict__ xz, const float* __restrict__ xdb,
+                                                             const float* __restrict__ dt_wt, const float* __restrict__ dt_bias,
+                                                             const float* __restrict__ A_log, const float* __restrict__ Dp,
+                                                             const uint8_t* __restrict__ reset, float* __restrict__ y,
+                                                             float* __restrict__ amax, int B, int di, int epw) {
+  constexpr int N = 16, LDX = R + 2 * N;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int ncb = di >> 6;
+  const int cb = wv % ncb, eg = wv / ncb;
+  const int e_begin = eg * epw, e_end = min(B, e_begin + epw);
+  if (e_begin >= e_end) return;
+  const int d = cb * 64 + lane;
+  // per-channel constants, once per wave
+  float wt[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) wt[r] = dt_wt[(int64_t)r * di + d];
+  float A[N];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 al = *reinterpret_cast<const float4*>(A_log + (int64_t)d * N + 4 * q);
+    A[4 * q] = -expf(al.x), A[4 * q + 1] = -expf(al.y), A[4 * q + 2] = -expf(al.z), A[4 * q + 3] = -expf(al.w);
+  }
+  const float Dd = Dp[d], bias = dt_bias[d];
+  // operands of one env: its 16 states, x and z of the T tokens (requested one env ahead)
+  v4f_t sn[4];
+  float xn[T], zn[T];
+  auto request = [&](int b) {
+    const float* sp = ssm_state + ((int64_t)b * di + d) * N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sn[q] = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(sp + 4 * q));
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int64_t row = (int64_t)b * T + t;
+      xn[t] = xc[row * di + d];
+      zn[t] = xz[row * 2 * di + di + d];
+    }
+  };
+  request(e_begin);
+  for (int b = e_begin; b < e_end; ++b) {
+    float s[N], x[T], z[T];
+    const bool rs = reset != nullptr && reset[b] != 0;  // (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s[4 * q] = rs ? 0.f : sn[q].x, s[4 * q + 1] = rs ? 0.f : sn[q].y, s[4 * q + 2] = rs ? 0.f : sn[q].z, s[4 * q + 3] = rs ? 0.f : sn[q].w;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) x[t] = xn[t], z[t] = zn[t];
+    request(min(b + 1, e_end - 1));  // (unconditional: past the last env it re-requests the last one and drops it)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int64_t row = (int64_t)b * T + t;
+      const float* __restrict__ xr = xdb + row * LDX;  // wave-uniform: dt_raw[R] | B[16] | C[16]
+      float acc;
+      if (ILP) {  // four interleaved partial sums: a 48-long dependent fma chain leaves the SIMD idle between issues
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; r += 4) p0 += wt[r] * xr[r], p1 += wt[r + 1] * xr[r + 1], p2 += wt[r + 2] * xr[r + 2], p3 += wt[r + 3] * xr[r + 3];
+        acc = (p0 + p1) + (p2 + p3);
+      } else {
+        acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc += wt[r] * xr[r];
+      }
+      const float dt = softplus_f(acc + bias);
+      const float xv = x[t], dx = dt * xv;
+      float yv = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        // decay via the hardware exp2 (v_exp_f32): |dt * A| is O(1), relative error ~1e-7
+        s[n] = s[n] * __expf(dt * A[n]) + dx * xr[R + n];
+        const float term = s[n] * xr[R + N + n];
+        if (!ILP || (n & 3) == 0) yv += term;
+        else if ((n & 3) == 1) y1 += term;
+        else if ((n & 3) == 2) y2 += term;
+        else y3 += term;
+      }
+      if (ILP) yv = (yv + y1) + (y2 + y3);
+      yv = (yv + Dd * xv) * silu_f(z[t]);
+      y[row * di + d] = yv;
+      if (amax != nullptr) {
+        const float m = wave_max(fabsf(yv));
+        if (lane == 0) amax[row * ncb + cb] = m;
+      }
+    }
+    float* sp = ssm_state + ((int64_t)b * di + d) * N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v4f_t v;
+      v.x = s[4 * q], v.y = s[4 * q + 1], v.z = s[4 * q + 2], v.w = s[4 * q + 3];
+      __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(sp + 4 * q));
+    }
+  }
+}
+
 }  // namespace
 
 void launch_transpose_f32(const float* src, int rows, int cols, float* dst, hipStream_t stream) {
@@ -245,6 +360,39 @@ void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream) {
   LRAM_REQUIRE(a.dt_wt == nullptr || mamba_ssm_dt_fusable(a.N, a.R), "fused dt_proj needs d_state 16 and dt_rank <= 128");
   LRAM_REQUIRE(a.dt_wt != nullptr || a.dtp != nullptr, "selective state update needs dtp or dt_w");
   dim3 block(256);
+  // lane = channel form: env-steps of the d_state-16 geometries with dt_proj fused (Mamba-48M: dt_rank 48)
+  static const int lane_form = [] {   // LRAM_MAMBA_SSM_LANE (measurement knob): 0 keeps the 4-lanes-per-channel kernel
+    const char* v = std::getenv("LRAM_MAMBA_SSM_LANE");
+    return v ? std::atoi(v) : 1;
+  }();
+  static const int epw_env = [] {     // LRAM_MAMBA_SSM_EPW (measurement knob): env slots per wave
+    const char* v = std::getenv("LRAM_MAMBA_SSM_EPW");
+    return v ? std::atoi(v) : 0;
+  }();
+  if (lane_form && a.T == 3 && a.N == 16 && a.R == 48 && a.dt_wt != nullptr && a.y3 == nullptr && a.y != nullptr &&
+      a.d_inner % 64 == 0 && a.B >= 64) {
+    static const int ilp = [] {   // LRAM_MAMBA_SSM_ILP (measurement knob): 0 = one dependent chain per dot product
+      const char* v = std::getenv("LRAM_MAMBA_SSM_ILP");
+      return v ? std::atoi(v) : 1;
+    }();
+    const int epw = epw_env > 0 ? epw_env : 8;
+    const long waves = (long)(a.d_inner / 64) * ((a.B + epw - 1) / epw);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    static const int occ = [] {   // LRAM_MAMBA_SSM_OCC (measurement knob): waves per SIMD the register budget is cut for (3: 138 VGPRs, 4: 128 + 5 spilled)
+      const char* v = std::getenv("LRAM_MAMBA_SSM_OCC");
+      return v ? std::atoi(v) : 3;
+    }();
+#define LRAM_SSM_LANE(ILPV, OCCV)                                                                                              \
+  hipLaunchKernelGGL((mamba_ssm_lane_kernel<3, 48, ILPV, OCCV>), grid, block, 0, stream, a.ssm_state, a.xc, a.xz, a.xdb, a.dt_wt, \
+                     a.dt_bias, a.A_log, a.Dp, a.reset, a.y, a.amax, a.B, a.d_inner, epw)
+    if (ilp && occ == 4) LRAM_SSM_LANE(true, 4);
+    else if (ilp) LRAM_SSM_LANE(true, 3);
+    else if (occ == 4) LRAM_SSM_LANE(false, 4);
+    else LRAM_SSM_LANE(false, 3);
+#undef LRAM_SSM_LANE
+    LRAM_HIP_CHECK(hipGetLastError());
+    return;
+  }
   dim3 g4(gx, (unsigned)((a.B + 3) / 4)), g1(gx, (unsigned)a.B);
   switch (a.T) {
     case 1: hipLaunchKernelGGL((mamba_ssm_kernel<1, 4>), g4, block, 0, stream, a); break;

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
                                                        int64_t out_stride, const float* gamma, const float* beta,
                                                        int rows, int d, float eps, int rms, float* out2,
                                                        uint16_t* planes, int64_t plane_stride, float* amax,
-                                                       ScalarTokens st) {
+                                                       ScalarTokens st, _Float16* h2, int64_t h2_plane, float* h2_inv) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -87,10 +87,18 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
     if (out != nullptr) *reinterpret_cast<float4*>(dst + 4 * i) = o;
     if (out2 != nullptr) *reinterpret_cast<float4*>(out2 + (int64_t)row * out_stride + 4 * i) = o;  // second copy (taps)
     if (planes != nullptr) split3_store4(o, planes + (int64_t)row * out_stride + 4 * i, plane_stride);  // GEMM operand
+    v[j] = o;
   }
-  if (amax != nullptr) {  // (uniform) the row's largest magnitude: the f16x2 GEMM derives its operand scale from it
-    mx = wave_max(mx);
-    if (lane == 0) amax[row] = mx;
+  if (amax != nullptr || h2 != nullptr) mx = wave_max(mx);  // (uniform) the row's largest magnitude
+  if (amax != nullptr && lane == 0) amax[row] = mx;         // the f16x2 GEMM derives its operand scale from it
+  if (h2 != nullptr) {  // ... or takes the operand already scaled and split: two f16 planes + the inverse scale (gemm_f16x2p.hip)
+    const float sc = pow2_scale(mx);
+#pragma unroll
+    for (int j = 0; j < kNormMaxV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) split2_store4(v[j], sc, h2 + (int64_t)row * out_stride + 4 * i, h2_plane);
+    }
+    if (lane == 0) h2_inv[row] = 1.f / sc;
   }
 }
 
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
 __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, const float* res_in, float* res_out,
                                                            float* normed, const float* gamma, int rows, int d,
                                                            float eps, uint16_t* planes, int64_t plane_stride,
-                                                           float* amax) {
+                                                           float* amax, _Float16* h2, int64_t h2_plane, float* h2_inv) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -141,10 +149,18 @@ __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, 
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     if (normed != nullptr) *reinterpret_cast<float4*>(normed + base + 4 * i) = o;
     if (planes != nullptr) split3_store4(o, planes + base + 4 * i, plane_stride);
+    v[j] = o;
   }
-  if (amax != nullptr) {
-    mx = wave_max(mx);
-    if (lane == 0) amax[row] = mx;
+  if (amax != nullptr || h2 != nullptr) mx = wave_max(mx);
+  if (amax != nullptr && lane == 0) amax[row] = mx;
+  if (h2 != nullptr) {  // operand planes of the pre-split f16x2 GEMM (see row_norm_kernel)
+    const float sc = pow2_scale(mx);
+#pragma unroll
+    for (int j = 0; j < kNormMaxV; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nv) split2_store4(v[j], sc, h2 + base + 4 * i, h2_plane);
+    }
+    if (lane == 0) h2_inv[row] = 1.f / sc;
   }
 }
 
@@ -312,19 +328,23 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* buf, const uint8_
 
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2,
-                     uint16_t* planes, int64_t plane_stride, float* amax, const ScalarTokens* st) {
+                     uint16_t* planes, int64_t plane_stride, float* amax, const ScalarTokens* st, uint16_t* h2, int64_t h2_plane,
+                     float* h2_inv) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "row norm: d must be a multiple of 4 and <= 2048");
+  LRAM_REQUIRE(h2 == nullptr || h2_inv != nullptr, "row norm: f16x2 operand planes need the inverse-scale output");
   hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, in_stride, out, out_stride,
-                     gamma, beta, rows, d, eps, rms, out2, planes, plane_stride, amax, st ? *st : ScalarTokens());
+                     gamma, beta, rows, d, eps, rms, out2, planes, plane_stride, amax, st ? *st : ScalarTokens(),
+                     reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
                          const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes,
-                         int64_t plane_stride, float* amax) {
+                         int64_t plane_stride, float* amax, uint16_t* h2, int64_t h2_plane, float* h2_inv) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "rms norm: d must be a multiple of 4 and <= 2048");
+  LRAM_REQUIRE(h2 == nullptr || h2_inv != nullptr, "rms norm: f16x2 operand planes need the inverse-scale output");
   hipLaunchKernelGGL(add_rms_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, hidden, res_in, res_out,
-                     normed, gamma, rows, d, eps, planes, plane_stride, amax);
+                     normed, gamma, rows, d, eps, planes, plane_stride, amax, reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

@@ -75,6 +75,8 @@ _SYMBOLS = {
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_f16x2": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
+    "lram_gemm_f16x2_presplit": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
+                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_bf16x3_presplit": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_embed_images": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
@@ -445,7 +447,7 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
     bf16x3 kernel (kernel="bf16x3") the engine uses for its projections."""
     lib = load_library()
     fn = {"f32": lib.lram_gemm_f32, "bf16x3": lib.lram_gemm_bf16x3, "bf16x3_presplit": lib.lram_gemm_bf16x3_presplit,
-          "f16x2": lib.lram_gemm_f16x2, "skinny": lib.lram_gemm_skinny}[kernel]
+          "f16x2": lib.lram_gemm_f16x2, "f16x2p": lib.lram_gemm_f16x2_presplit, "skinny": lib.lram_gemm_skinny}[kernel]
     M, K = a.shape
     N = w.shape[0]
     if out is None:

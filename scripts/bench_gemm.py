@@ -32,6 +32,8 @@ if __name__ == "__main__":
         a = torch.randn(M, K, device=dev, generator=g)
         w = torch.randn(N, K, device=dev, generator=g) * 0.05
         for kern in kernels:
+            if kern == "f16x2p" and K % 32 != 0:
+                continue
             for _ in range(REPS):
                 gemm_f32(a, w, kernel=kern)
             order.append({"tag": tag, "kernel": kern, "m": M, "n": N, "k": K, "reps": REPS})

@@ -139,6 +139,30 @@ def test_gemm_f16x2_matches_fp64(hip_lib, m, n, k, spread):
     assert ((out3.cpu().double() - ref3).abs() / (scale + 1)).max().item() < (1.25 if k >= 32 else 2.5) * e1 + 6e-8
 
 
+@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 80, 1536), (4096, 512, 1024), (3072, 3072, 768), (6144, 2048, 512),
+                                   (65, 8, 64), (257, 129, 96)])
+def test_gemm_f16x2_presplit_operands_are_bit_identical(hip_lib, m, n, k):
+    """gemm_f16x2p.hip (A split once by its producer -- here the row-split kernel --, both operands staged global -> LDS by
+    DMA, MFMA-only loop) forms the same pieces and the same products in the same order as the kernel that splits A while
+    staging it: results are bit-identical, for ragged M / N tiles, with bias, and when accumulating into the output."""
+    from lram_amd.engine import gemm_f32
+    g = torch.Generator().manual_seed(m * 17 + n)
+    a = torch.randn(m, k, generator=g) * torch.exp(torch.randn(m, 1, generator=g))
+    a[m // 2] = 0.0                                                                    # an all-zero row
+    w = torch.randn(n, k, generator=g) * torch.exp(torch.randn(n, 1, generator=g) * 0.5)
+    bias = torch.randn(n, generator=g)
+    want = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="f16x2")
+    got = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="f16x2p")
+    torch.cuda.synchronize()
+    assert torch.equal(want, got), float((want - got).abs().max())
+    assert torch.equal(got[m // 2].cpu(), bias)
+    base = torch.randn(m, n, generator=g).cuda()
+    want2 = gemm_f32(a.cuda(), w.cuda(), None, out=base.clone(), accumulate=True, kernel="f16x2")
+    got2 = gemm_f32(a.cuda(), w.cuda(), None, out=base.clone(), accumulate=True, kernel="f16x2p")
+    torch.cuda.synchronize()
+    assert torch.equal(want2, got2)
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 80, 1536), (4096, 512, 1024), (257, 129, 48)])
 def test_gemm_bf16x3_presplit_operand_is_bit_identical(hip_lib, m, n, k):
     """The projection kernel fed with pre-split A planes (what the norm / gate / state-update kernels write) gives
