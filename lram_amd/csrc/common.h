@@ -418,6 +418,19 @@ struct SlstmTokenArgs {
 bool slstm_token_supported(int H, int NH);
 void launch_slstm_token(const SlstmTokenArgs& a, hipStream_t stream);
 
+// recurrent projection + pointwise cell of ALL T tokens of an env-step in one launch (head dim 128, any slice size; slstm_seq.hip)
+struct SlstmSeqArgs {
+  const float* gates = nullptr;  // [B*T, 4, H] input pre-activations (Wx)
+  const float* rt2 = nullptr;    // [NH, SDH (k), SDH (channel), 4 (gate)] recurrent weights re-packed by launch_slstm_pack_rt
+  const float* bias = nullptr;   // [4, H]
+  float* state = nullptr;        // [4, state_B, H] in/out (h, c, n, m planes)
+  float* yout = nullptr;         // [B*T, H]
+  int B = 0, T = 0, H = 0, NH = 0, state_B = 0;
+};
+bool slstm_seq_supported(int H, int NH, int T);
+void launch_slstm_seq(const SlstmSeqArgs& a, hipStream_t stream);
+void launch_slstm_pack_rt(const float* rt, float* rt2, int NH, int SDH, hipStream_t stream);  // rt: [NH, 4, out, in]
+
 // a[r, f] = gelu(p[r, f]) * p[r, F + f]      p: [rows, 2F]
 void launch_gelu_gate(const float* p, float* a, int rows, int F, hipStream_t stream);
 

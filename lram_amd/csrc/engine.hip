@@ -103,7 +103,14 @@ struct lram_engine {
     size_t rows, k;
   };
   std::map<const float*, Split16> split16;
+  bool gemm_presplit = true;   // LRAM_GEMM_PRESPLIT=0: the norms ahead of proj_up / in_proj write fp32 + row maxima (round 3) instead of
+                               // the f16x2 GEMM's operand planes (gemm_f16x2p.hip)
   double gemm_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // launches / fp32-equivalent FLOPs per dispatcher family (lram_gemm_counts)
+  std::vector<DevBuf> slstm_gw;   // sLSTM: the four gate projections' weights packed [4][NH][SDH][SDH] (two launches instead of four)
+  bool slstm_gates_pair = false;  // LRAM_SLSTM_GATES_PAIR=1: the gate projections as two batched launches (a pair per operand) instead of four;
+                                  // measured neutral to -0.5 % at 4096 slots (profiles/r04_ab_slstm_seq.txt): off
+  std::vector<DevBuf> slstm_rt2;  // sLSTM: recurrent weights re-packed [head][k][channel][gate] per block (slstm_seq.hip), head dim 128
+  bool slstm_seq = true;          // LRAM_SLSTM_SEQ=0: per-token recurrent GEMM + pointwise launches for slices beyond the token kernel's
   std::vector<DevBuf> gate_coef;  // mLSTM: folded i / f gate coefficients per block (mlstm_front.hip), geometries it covers
   bool front_multi = true;     // LRAM_FRONT_MULTI=0: keep the one-workgroup-per-env front end for large launches too
   int front_min_envs = 256;    // LRAM_FRONT_MIN_ENVS: slices of at least this many env slots take the multi-env front end
@@ -182,6 +189,8 @@ struct lram_engine {
   int B = 0;
   std::vector<BlockState> st;
   DevBuf X, XN, TOK, HID, U, Q, K, V, XA, H, G, SCAL, RY, LOGITS, RES, DTP;
+  DevBuf XN2;   // the norm output as f16x2 operand planes [2][B*T, D] f16 (pre-split projections): its own buffer -- a slice inside an
+                // sLSTM block uses XN as fp32 while another slice's mLSTM block holds planes
   // bf16x3 operand planes written by the producers of the big projections' A operands (row norm -> proj_up / in_proj,
   // output gate -> proj_down, selective state update -> out_proj): three planes each, `*_plane` elements apart
   uint16_t *XN3 = nullptr, *G3 = nullptr;
@@ -264,6 +273,10 @@ struct lram_engine {
     dt_wt.clear();
     for (DevBuf& b : gate_coef) b.release();
     gate_coef.clear();
+    for (DevBuf& b : slstm_rt2) b.release();
+    slstm_rt2.clear();
+    for (DevBuf& b : slstm_gw) b.release();
+    slstm_gw.clear();
   }
   void drop_graph() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -288,7 +301,7 @@ struct lram_engine {
     lazy_ready = false;
     st.clear();
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
-                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &YPART, &X0, &U0})
+                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &YPART, &X0, &U0})
       b->release();
     ascale_rows = 0;
     if (XN3) (void)hipFree(XN3);
@@ -362,6 +375,7 @@ void validate_config(const lram_config& c) {
 void make_split(lram_engine* e, const float* w, size_t n);
 void persist_prepare(lram_engine* e);
 bool a3_for(const lram_engine* e, const float* w, int rows, int k, int64_t lda);
+bool presplit_for(const lram_engine* e, const float* w, int rows, int n, int k);
 
 void finalize(lram_engine* e) {
   const lram_config& c = e->cfg;
@@ -463,6 +477,18 @@ void finalize(lram_engine* e) {
   }
   // bf16 split planes of every GEMM weight (LRAM_GEMM=f32 keeps the exact fp32-MFMA kernels instead)
   e->drop_splits();
+  // sLSTM gate projections (i, f on the conv branch, z, o on the norm): the four [NH, SDH, SDH] weights side by side, so that
+  // a pair that shares its operand is ONE batched launch (nb1 = 2 gates x nb2 = NH heads) instead of two
+  e->slstm_gw.assign(c.n_blocks, DevBuf());
+  if (c.backbone == LRAM_BACKBONE_XLSTM && e->slstm_gates_pair) {
+    const size_t per = (size_t)c.d_model * (c.d_model / c.n_heads);
+    for (int i = 0; i < c.n_blocks; ++i) {
+      if (!c.block_is_slstm[i]) continue;
+      e->slstm_gw[i].alloc(4 * per);
+      for (int g = 0; g < 4; ++g)
+        LRAM_HIP_CHECK(hipMemcpy(e->slstm_gw[i].p + g * per, e->bw[i].gate_w[g], per * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+  }
   if (const char* v = std::getenv("LRAM_GEMM")) {
     e->use_bf16x3 = std::string(v) != "f32";
     e->use_f16x2 = std::string(v) != "f32" && std::string(v) != "bf16x3";
@@ -507,6 +533,8 @@ void finalize(lram_engine* e) {
         ws.push_back(p);
     for (const float* p : ws)
       if (p != nullptr) make_split(e, p, numel(p));
+    for (DevBuf& b : e->slstm_gw)
+      if (b.p != nullptr) make_split(e, b.p, b.n);
     LRAM_HIP_CHECK(hipDeviceSynchronize());
   }
   e->gate_coef.assign(e->bw.size(), DevBuf());
@@ -516,6 +544,16 @@ void finalize(lram_engine* e) {
       const BlockWeights& w = e->bw[i];
       e->gate_coef[i].alloc((size_t)c.inner * 4 * c.n_heads);
       launch_gate_coef(w.wq, w.wk, w.wv, w.wi, w.wf, c.inner, c.n_heads, e->gate_coef[i].p, nullptr);
+    }
+    LRAM_HIP_CHECK(hipDeviceSynchronize());
+  }
+  e->slstm_rt2.assign(e->bw.size(), DevBuf());
+  if (c.backbone == LRAM_BACKBONE_XLSTM && slstm_seq_supported(c.d_model, c.n_heads, c.tokens_per_step)) {
+    for (size_t i = 0; i < e->bw.size(); ++i) {
+      if (!c.block_is_slstm[i]) continue;
+      const size_t sdh = (size_t)c.d_model / c.n_heads;
+      e->slstm_rt2[i].alloc((size_t)c.n_heads * 4 * sdh * sdh);
+      launch_slstm_pack_rt(e->bw[i].rt, e->slstm_rt2[i].p, c.n_heads, (int)sdh, nullptr);
     }
     LRAM_HIP_CHECK(hipDeviceSynchronize());
   }
@@ -552,6 +590,7 @@ void alloc_workspace(lram_engine* e, int tokens) {
   if (c.backbone == LRAM_BACKBONE_XLSTM) e->AMX_H.alloc(BT * (size_t)c.n_heads);  // read pass -> proj_down (gate_in_pass)
   e->X.alloc(BT * D);
   e->XN.alloc(BT * D);
+  if (e->gemm_presplit && e->use_f16x2) e->XN2.alloc(BT * D);
   e->TOK.alloc(BT * D);
   e->HID.alloc(BT * D);
   e->LOGITS.alloc(B * c.act_dim * c.n_vocab);
@@ -790,6 +829,18 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
   // extra row-maximum launches -- and the three-workgroups-per-CU advantage needs a grid that fills the chip)
   // (wide weights -- the 206M stack's 5120 x 1280 / 1280 x 2560 -- pay from 512 rows: 206M at 512 slots runs 768-row slices,
   // 28.1k env-steps/s on bf16x3 vs 29.5k on f16x2)
+  if (g.a2 != nullptr) {  // A handed over as f16x2 operand planes by its producer (presplit_for() said this GEMM takes them)
+    auto it = e->split16.upper_bound(g.w);
+    LRAM_REQUIRE(it != e->split16.begin() && (--it, g.w < it->first + it->second.rows * it->second.k) && (int)it->second.k == g.ldw,
+                 "gemm: pre-split A operand for a weight without f16x2 planes");
+    const size_t row0 = (size_t)(g.w - it->first) / it->second.k;
+    g.w2 = it->second.planes + (g.w - it->first);
+    g.w2_plane = (int64_t)(it->second.rows * it->second.k);
+    g.w_inv = it->second.inv + row0;
+    launch_gemm_f16x2p(g, s);
+    count_gemm(e, 0, g);
+    return;
+  }
   const bool f16_rows = g.m >= e->f16x2_min_rows || (g.m >= 512 && (int64_t)g.n * g.k >= 2500000);
   if (e->use_f16x2 && f16_rows && g.nb1 * g.nb2 == 1 && g.a3 == nullptr && e->ASCALE.p != nullptr &&
       (size_t)g.m <= e->ascale_rows) {
@@ -844,6 +895,15 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
   LRAM_REQUIRE(g.gate == nullptr && g.act_silu_from < 0, "gemm: gated operand / output activation need the bf16x3 kernel");
   launch_gemm_f32(g, s);
   count_gemm(e, 2, g);
+}
+
+// Does the projection `rows x k` against weight w take the f16x2 kernel with BOTH operands pre-split (gemm_f16x2p.hip)?
+// Same row threshold as the on-the-fly f16x2 kernel; K a multiple of its 32-deep tile; the weight has f16 planes.
+bool presplit_for(const lram_engine* e, const float* w, int rows, int n, int k) {
+  if (!e->gemm_presplit || !e->use_f16x2 || e->use_a3 || (k & 31) != 0 || e->XN2.p == nullptr) return false;
+  if (!(rows >= e->f16x2_min_rows || (rows >= 512 && (int64_t)n * k >= 2500000))) return false;
+  auto it = e->split16.upper_bound(w);
+  return it != e->split16.begin() && (--it, w < it->first + it->second.rows * it->second.k) && (int)it->second.k == k;
 }
 
 // Does the projection `rows x k` against weight w take the bf16x3 kernel with a pre-split A operand?  (Same conditions
@@ -1011,9 +1071,15 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     launch_gemm_skinny(up, sl.s);
     count_gemm(e, 3, up);
   } else {
-    launch_row_norm(e->X.p + r0 * D, D, a3 ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
-                    c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, amx);
+    // f16x2 with both operands pre-split: the norm writes the two operand planes (into XN's memory: 2 x 2 bytes per
+    // element) and the rows' inverse scales (into AMX_XN) instead of fp32 + row maxima; both halves of proj_up read them
+    const bool ps = !a3 && presplit_for(e, w.proj_up, rows, inner, D);
+    uint16_t* xn2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * D;
+    launch_row_norm(e->X.p + r0 * D, D, (a3 || ps) ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
+                    c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, ps ? nullptr : amx,
+                    nullptr, ps ? xn2 : nullptr, (int64_t)e->XN2.n, ps ? amx : nullptr);
     up.a_amax = amx;
+    if (ps) up.a = nullptr, up.a_amax = nullptr, up.a2 = xn2, up.a2_plane = (int64_t)e->XN2.n, up.a2_inv = amx;
     if (a3) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
     gemm(e, up, sl.s);
   }
@@ -1057,7 +1123,12 @@ void mlstm_up_z(lram_engine* e, int i, int T, const Slice& sl) {
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = e->bw[i].proj_up + (size_t)inner * D, up.ldw = D;
   up.c = e->U.p + r0 * e->ucols + inner, up.ldc = 2 * inner, up.m = rows, up.n = inner, up.k = D;
   if (e->use_f16x2) up.a_amax = e->AMX_XN.p + r0;  // written by this block's norm launch (mlstm_front)
-  if (a3_for(e, e->bw[i].proj_up, rows, D, D)) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
+  if (a3_for(e, e->bw[i].proj_up, rows, D, D)) {
+    up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
+  } else if (presplit_for(e, e->bw[i].proj_up, rows, inner, D)) {  // (same decision as mlstm_front: XN holds operand planes)
+    up.a = nullptr, up.a_amax = nullptr;
+    up.a2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * D, up.a2_plane = (int64_t)e->XN2.n, up.a2_inv = e->AMX_XN.p + r0;
+  }
   if (gn_fused(e, T)) up.act_silu_from = 0;
   gemm(e, up, sl.s);
 }
@@ -1154,6 +1225,16 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
       g4.a_tab[g] = (g < 2) ? XC : XN, g4.w_tab[g] = w.gate_w[g], g4.c_tab[g] = gates + (int64_t)g * Hs;
     launch_gemm_skinny(g4, s);
     count_gemm(e, 3, g4);
+  } else if (e->slstm_gw[i].p != nullptr && e->use_bf16x3) {
+    for (int pr = 0; pr < 2; ++pr) {  // pair 0: i, f from the conv branch; pair 1: z, o from the norm
+      GemmArgs ga;
+      ga.a = pr == 0 ? XC : XN, ga.lda = D, ga.sA1 = 0, ga.sA2 = SDH;
+      ga.w = e->slstm_gw[i].p + (size_t)pr * 2 * NH * SDH * SDH, ga.ldw = SDH;
+      ga.sW1 = (int64_t)NH * SDH * SDH, ga.sW2 = (int64_t)SDH * SDH;
+      ga.c = gates + (int64_t)pr * 2 * Hs, ga.ldc = 4 * Hs, ga.sC1 = Hs, ga.sC2 = SDH;
+      ga.m = rows, ga.n = SDH, ga.k = SDH, ga.nb1 = 2, ga.nb2 = NH;
+      gemm(e, ga, s);
+    }
   } else {
     for (int g = 0; g < 4; ++g) {
       GemmArgs ga;
@@ -1179,7 +1260,15 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   }
   if (tok_fused && T == 1)  // the single launch read the state's h plane: it is refreshed from the output rows afterwards
     LRAM_HIP_CHECK(hipMemcpyAsync(state, Y, (size_t)sl.nb * Hs * sizeof(float), hipMemcpyDeviceToDevice, s));
-  for (int t = 0; !tok_fused && t < T; ++t) {
+  // slices beyond the token kernel's: the whole step's recurrence as ONE launch (head dim 128; slstm_seq.hip)
+  const bool seq = !tok_fused && e->slstm_seq && e->slstm_rt2[i].p != nullptr && slstm_seq_supported(Hs, NH, T);
+  if (seq) {
+    SlstmSeqArgs qa;
+    qa.gates = gates, qa.rt2 = e->slstm_rt2[i].p, qa.bias = w.rbias, qa.state = state, qa.yout = Y;
+    qa.B = sl.nb, qa.T = T, qa.H = Hs, qa.NH = NH, qa.state_B = e->B;
+    launch_slstm_seq(qa, s);
+  }
+  for (int t = 0; !tok_fused && !seq && t < T; ++t) {
     GemmArgs ra;
     ra.a = state, ra.lda = Hs, ra.sA1 = SDH, ra.sA2 = 0;
     ra.w = w.rt, ra.ldw = SDH, ra.sW1 = 4 * (int64_t)SDH * SDH, ra.sW2 = (int64_t)SDH * SDH;
@@ -1427,9 +1516,13 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   float* amx_xn = amx ? e->AMX_XN.p + r0 : nullptr;
   float* amx_xa = amx ? e->AMX_XA.p + r0 * parts : nullptr;
   float* amx_h = amx ? e->AMX_H.p + r0 * parts : nullptr;
+  // in_proj with both operands pre-split: the norm writes XN as two f16 planes + inverse row scales (see mlstm_front)
+  const bool ps_in = !a3_in && amx && presplit_for(e, w.in_proj, rows, 2 * di, D);
+  uint16_t* xn2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * D;
   if (stage == 0) {
-    launch_add_rms_norm(X, RES_in, RES_out, a3_in ? nullptr : XN, w.norm_g, rows, D, c.norm_eps, sl.s,
-                        a3_in ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, amx_xn);
+    launch_add_rms_norm(X, RES_in, RES_out, (a3_in || ps_in) ? nullptr : XN, w.norm_g, rows, D, c.norm_eps, sl.s,
+                        a3_in ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, ps_in ? nullptr : amx_xn,
+                        ps_in ? xn2 : nullptr, (int64_t)e->XN2.n, ps_in ? amx_xn : nullptr);
   } else if (stage == 1) {
     MambaConvArgs ca;
     ca.xz = U, ca.conv_state = st.conv.p + b0 * di * c.d_conv, ca.conv_w = w.conv_w, ca.conv_b = w.conv_b, ca.xc = XA;
@@ -1450,6 +1543,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     GemmArgs in;
     in.a = XN, in.lda = D, in.w = w.in_proj, in.ldw = D, in.c = U, in.ldc = 2 * di, in.bias = w.in_proj_b;
     in.m = rows, in.n = 2 * di, in.k = D, in.a_amax = amx_xn;
+    if (ps_in) in.a = nullptr, in.a_amax = nullptr, in.a2 = xn2, in.a2_plane = (int64_t)e->XN2.n, in.a2_inv = amx_xn;
     if (a3_in) in.a3 = e->XN3 + r0 * D, in.a3_plane = (int64_t)e->xn3_plane;
     gemm(e, in, gs);
   } else if (stage == 1) {
@@ -1847,6 +1941,9 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_FOLD_GAPS")) e->fold_gaps = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_FRONT_STAGGER")) e->front_stagger = std::atoi(v);
     if (const char* v = std::getenv("LRAM_FRONT_MULTI")) e->front_multi = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_SLSTM_GATES_PAIR")) e->slstm_gates_pair = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_GEMM_PRESPLIT")) e->gemm_presplit = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FRONT_MIN_ENVS")) e->front_min_envs = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
     *out = e.release();

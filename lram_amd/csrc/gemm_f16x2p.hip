@@ -250,9 +250,11 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
   }();
   // LRAM_F16P_STAGES (measurement knob): 1 = one LDS stage, two barriers per K tile, up to four workgroups per CU;
   // 2 = two stages, the next tile's DMA under the current tile's MFMAs, one barrier per K tile, two workgroups per CU
-  static const int stages = [] {
+  // default 0 = by grid size (same box, standalone: 16M proj_up 768 tiles 55 us with one stage / 65 with two; Mamba in_proj 576
+  // tiles 67 / 80; 16M proj_down 192 tiles 50 / 40; Mamba out_proj 144 tiles 65 / 51 -- profiles/r04_gemm_f16x2p_durations.txt)
+  static const int stages_env = [] {
     const char* v = std::getenv("LRAM_F16P_STAGES");
-    return v ? std::atoi(v) : 2;
+    return v ? std::atoi(v) : 0;
   }();
   g.mfma_prio = prio;
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
@@ -265,6 +267,7 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
   const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
   dim3 grid(tiles, 1, S);
   gemm_choose_xcd_split(g, BM, BN, 4);
+  const int stages = stages_env > 0 ? stages_env : ((long)tiles * S >= 384 ? 1 : 2);
   if (stages == 1) launch_stage<1>(g, grid, stream); else launch_stage<2>(g, grid, stream);
   LRAM_HIP_CHECK(hipGetLastError());
   if (S > 1) launch_splitk_reduce(g, stream);
