@@ -204,33 +204,6 @@ int32_t lram_set_micro_batches(lram_engine* e, int32_t n);
 int32_t lram_set_compat_mode(lram_engine* e, int32_t mamba_repeat, int32_t stale_state);
 int32_t lram_get_compat_mode(const lram_engine* e, int32_t* mamba_repeat, int32_t* stale_state);
 
-/* Alternative small-batch paths (xLSTM, 3 tokens per timestep, at most 8 env slots, materialised state, no graph
- * mode).  The reference's own operating point is a single env (src/callbacks/evaluation.py:80); there the generic path is
- * bound by its ~70 dependent kernel launches per env-step, and these two modes restructure the step around that:
- *   mode 3  fused phase kernels: norms, gates and activations fused into the GEMV that consumes them, the four sLSTM
- *           gate projections in one launch, each token's recurrent GEMV with its pointwise cell -- 40 launches per
- *           env-step of the 16M stack;
- *   mode 1  whole-step kernel: the same phases as ONE cooperative launch whose workgroups meet at device-wide barriers
- *           (agent-scope release / acquire).  A barrier that cannot complete times out (bounded spin, wall-clock: a
- *           co-tenant kernel that delays co-residency of the grid can trip it): that call -- and any call already
- *           enqueued behind it -- writes NaN actions and token -1 instead of results, the NEXT lram_step returns the
- *           error and leaves the mode, so an asynchronous caller of mode 1 must check the following call's return code
- *           (or the actions for NaN).  lram_set_persistent_mode(e, 1) drains the device and clears the barrier counter
- *           and error words, so the mode can be entered again.
- * Both are parity-tested against the oracle, and both measure SLOWER than the generic path on MI355X (16M stack, one
- * env: 0.374 ms generic, 0.410 ms fused, 0.76 ms whole-step): the step is a chain of ~70 dependent
- * memory round trips, fusing them into fewer launches does not shorten the chain, and a device-wide barrier costs an
- * L2 write-back + invalidate on each of the eight XCDs.  So mode 2 (auto, the default) = mode 0, the generic
- * launch-per-kernel path; the two modes stay selectable.  LRAM_PERSISTENT=0..3 and LRAM_PERSIST_WGS (workgroups of mode
- * 1, default 128) in the environment at lram_create set the initial values.  State lives in the same buffers on every
- * path.  lram_get_persistent_mode: the path the next lram_step takes (0, 1 or 3). */
-int32_t lram_set_persistent_mode(lram_engine* e, int32_t mode);
-int32_t lram_get_persistent_mode(const lram_engine* e);
-/* Debug: with LRAM_PERSIST_TRACE=1 in the environment at lram_create, workgroup 0 of the whole-step kernel records the
- * device wall clock (100 MHz) at the kernel start and before / after every barrier; copies the first n of the last
- * launch's 2 * barriers + 1 stamps to host memory (synchronises the device). */
-int32_t lram_persistent_trace(lram_engine* e, uint64_t* host_out, int32_t n);
-
 /* Per-kernel timing of the recurrent step, measured with HIP events on the stream the kernels are
  * launched on.  lram_profile_begin arms it; every later lram_step records one (start, stop) event pair
  * around the mLSTM cell-update launches (xLSTM) or the selective-state-update launches (Mamba).

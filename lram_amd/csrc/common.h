@@ -321,47 +321,6 @@ bool mlstm_lazy_supported(int DH, int T);
 // count[b] = 0, g[b, :] = 1 for masked envs (mask == nullptr: all), both parities handled by the caller
 void launch_mlstm_lazy_clear(int32_t* count, float* g, const uint8_t* mask, int B, int NH, hipStream_t stream);
 
-// ---------------------------------------------------------------------------------------------
-// Whole env-step of the xLSTM stack as one cooperative launch (persistent_step.inl), small batches
-// ---------------------------------------------------------------------------------------------
-constexpr int kPersistMaxBatch = 8;
-struct PersistBlock {  // one per block, array in device memory
-  int is_slstm;
-  const float *norm_g, *norm_b;
-  // mLSTM
-  const float *proj_up, *conv_w, *conv_b, *wq, *wk, *wv, *wi, *bi, *wf, *bf, *on_g, *on_b, *skip, *proj_down;
-  // sLSTM
-  const float* gate_w[4];
-  const float *rt, *rbias, *gn_g, *gn_b, *ffn_norm_g, *ffn_norm_b, *ffn_up, *ffn_down;
-  // recurrent state (reference layouts): mLSTM C / n / m / conv, sLSTM state [4, B, D] / conv
-  float *s0, *n, *m, *conv;
-};
-struct PersistArgs {
-  const PersistBlock* blocks;
-  int n_blocks;
-  int B, state_B, D, inner, NH, DH, SDH, F, state_dim, act_dim, n_vocab, n_discrete, action_channels, pred_token;
-  float tok_min, tok_max, ln_eps;
-  int norm_is_rms;
-  const float *w_state, *b_state, *w_rtg, *b_rtg, *w_rew, *b_rew, *eln_g, *eln_b, *w_head, *b_head, *post_g, *post_b;
-  const float* obs;
-  int emb;
-  const float *rtg, *rew;
-  const uint8_t* reset;
-  int discrete;
-  float* actions;
-  int32_t* tokens;
-  float *X, *XN, *TOK, *HID, *U, *Q, *K, *V, *XA, *H, *SCAL, *LOGITS;
-  unsigned long long* counter;  // device: grid-barrier arrivals, monotonically increasing across launches
-  unsigned long long base;      // its value when this launch starts
-  int* abort_dev;               // device word: a barrier timed out
-  int* err_host;                // host-mapped word: the same, for the engine
-  unsigned long long* trace = nullptr;  // optional device buffer [2 * barriers + 1]: phase timestamps of workgroup 0
-};
-int xlstm_persistent_barriers(int n_mlstm, int n_slstm);     // grid barriers one launch passes
-size_t xlstm_persistent_lds_bytes(const PersistArgs& a, int T);
-void launch_xlstm_persistent_step(const PersistArgs& a, int T, int n_wgs, hipStream_t stream);
-// the same phases as one launch each (fused norms / gates, 40 launches per step of the 16M stack instead of ~70)
-void launch_xlstm_small_batch_step(const PersistArgs& a, int T, const int32_t* block_is_slstm, hipStream_t stream);
 
 // mode 0 (mLSTM): out[r, hd] = (GN(h)[r,hd] * gamma + skip*xa) * silu(z)      z = u[r, inner + hd]
 // mode 1 (sLSTM): x[r, hd] += GN(h)[r,hd] * gamma

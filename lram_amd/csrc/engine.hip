@@ -204,16 +204,6 @@ struct lram_engine {
   static constexpr size_t kSplitKSlotElems = 6u << 20;  // 6 Mi floats (24 MiB) >= S*M*N for any GEMM the chooser splits
   static constexpr int kSplitKSlots = 9;                 // caller's stream + up to 8 micro-batch streams
   size_t ucols = 0, icols = 0;  // allocated row pitch of U and of Q/K/V/XA/H/G (slice offsets use these)
-  // whole-step cooperative kernel for small batches (persistent_step.inl)
-  int persist_mode = 2;                      // small-batch path: 0 generic launches, 1 whole-step cooperative kernel,
-                                             // 2 auto (= 0: the generic launches measured fastest), 3 fused phase kernels
-                                             // (LRAM_PERSISTENT)
-  int persist_wgs = 128;                     // workgroups of the cooperative launch (LRAM_PERSIST_WGS)
-  PersistBlock* persist_blocks = nullptr;    // device array, one entry per block
-  unsigned long long* persist_counter = nullptr;  // device: [0] barrier arrivals, [1] abort word
-  unsigned long long persist_base = 0;
-  int* persist_err = nullptr;                // host-mapped: a grid barrier timed out
-  unsigned long long* persist_trace = nullptr;  // LRAM_PERSIST_TRACE=1: device buffer of phase timestamps (debug)
   // graph replay
   bool graph_mode = false;
   bool graph_valid = false;
@@ -259,10 +249,6 @@ struct lram_engine {
     for (auto& kv : weights) kv.second.release();
     drop_splits();
     release_state();
-    if (persist_blocks) (void)hipFree(persist_blocks);
-    if (persist_counter) (void)hipFree(persist_counter);
-    if (persist_trace) (void)hipFree(persist_trace);
-    if (persist_err) (void)hipHostFree(persist_err);
   }
   void drop_splits() {
     for (auto& kv : split) (void)hipFree(kv.second.p);
@@ -373,7 +359,6 @@ void validate_config(const lram_config& c) {
 }
 
 void make_split(lram_engine* e, const float* w, size_t n);
-void persist_prepare(lram_engine* e);
 bool a3_for(const lram_engine* e, const float* w, int rows, int k, int64_t lda);
 bool presplit_for(const lram_engine* e, const float* w, int rows, int n, int k);
 
@@ -792,7 +777,6 @@ void state_alloc(lram_engine* e, int B) {
   alloc_workspace(e, kMaxTokens);
   e->lazy = lazy_choice(e);
   if (e->lazy) lazy_alloc(e);
-  persist_prepare(e);
   LRAM_HIP_CHECK(hipDeviceSynchronize());
 }
 
@@ -1642,102 +1626,6 @@ void embed_images(lram_engine* e, const uint8_t* images, int C, int H, int W, fl
   launch_relu(out, (int64_t)B * D, s);
 }
 
-// ---- whole-step cooperative kernel (small batches) ---------------------------------------------------------
-// mode: 1 whole-step cooperative kernel, 3 fused phase kernels.  The sLSTM head dim only matters for stacks that have
-// sLSTM blocks: the whole-step kernel walks it in 4-element lane groups, the fused per-token recurrent phase in
-// 16-element chunks (launch_xlstm_small_batch_step) -- a geometry accepted here must not throw in lram_step.
-bool persist_supported(const lram_engine* e, int mode) {
-  const lram_config& c = e->cfg;
-  if (c.backbone != LRAM_BACKBONE_XLSTM || c.tokens_per_step != 3 || e->B < 1 || e->B > kPersistMaxBatch) return false;
-  if ((c.inner / c.n_heads) % 64 != 0 || c.d_model % 4 != 0 || c.ffn_dim % 4 != 0) return false;
-  bool has_slstm = false;
-  for (int i = 0; i < c.n_blocks; ++i) has_slstm = has_slstm || c.block_is_slstm[i] != 0;
-  const int sdh = c.d_model / c.n_heads;
-  if (has_slstm && sdh % (mode == 3 ? 16 : 4) != 0) return false;
-  PersistArgs a{};
-  a.B = e->B, a.D = c.d_model, a.inner = c.inner, a.DH = c.inner / c.n_heads, a.SDH = c.d_model / c.n_heads, a.F = c.ffn_dim;
-  return xlstm_persistent_lds_bytes(a, 3) <= 120 * 1024;
-}
-
-// 0: generic launch-per-kernel path, 1: whole-step cooperative kernel, 3: fused phase kernels
-int persist_path(const lram_engine* e) {
-  if (e->persist_mode == 0 || e->graph_mode || (e->lazy && e->lazy_ready) || e->prof_on) return 0;
-  if (e->persist_mode != 1 && e->persist_mode != 3) return 0;
-  if (e->persist_blocks == nullptr || !persist_supported(e, e->persist_mode)) return 0;
-  if (e->persist_mode == 1) return (e->persist_err != nullptr && *e->persist_err != 0) ? 0 : 1;
-  // auto keeps the generic launches: measured on MI355X at one env of the 16M stack 0.374 ms per env-step against
-  // 0.410 ms for the fused phase kernels and 0.76 ms for the whole-step kernel (8 envs: 0.54 / 1.17 / 1.74 ms)
-  return e->persist_mode == 3 ? 3 : 0;
-}
-
-// Block descriptors (weights + state pointers) for the cooperative kernel; rebuilt with every state allocation.
-void persist_prepare(lram_engine* e) {
-  if (e->persist_blocks) (void)hipFree(e->persist_blocks);
-  e->persist_blocks = nullptr;
-  if (!persist_supported(e, 1) && !persist_supported(e, 3)) return;
-  const lram_config& c = e->cfg;
-  std::vector<PersistBlock> host(c.n_blocks);
-  for (int i = 0; i < c.n_blocks; ++i) {
-    const BlockWeights& w = e->bw[i];
-    const BlockState& st = e->st[i];
-    PersistBlock& pb = host[i];
-    std::memset(&pb, 0, sizeof(pb));
-    pb.is_slstm = c.block_is_slstm[i] != 0;
-    pb.norm_g = w.norm_g, pb.norm_b = w.norm_b;
-    pb.proj_up = w.proj_up, pb.conv_w = w.conv_w, pb.conv_b = w.conv_b, pb.wq = w.wq, pb.wk = w.wk, pb.wv = w.wv;
-    pb.wi = w.wi, pb.bi = w.bi, pb.wf = w.wf, pb.bf = w.bf, pb.on_g = w.on_g, pb.on_b = w.on_b, pb.skip = w.skip;
-    pb.proj_down = w.proj_down;
-    for (int g = 0; g < 4; ++g) pb.gate_w[g] = w.gate_w[g];
-    pb.rt = w.rt, pb.rbias = w.rbias, pb.gn_g = w.gn_g, pb.gn_b = w.gn_b, pb.ffn_norm_g = w.ffn_norm_g;
-    pb.ffn_norm_b = w.ffn_norm_b, pb.ffn_up = w.ffn_up, pb.ffn_down = w.ffn_down;
-    pb.s0 = st.s0.p, pb.n = st.n.p, pb.m = st.m.p, pb.conv = st.conv.p;
-  }
-  LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->persist_blocks), sizeof(PersistBlock) * host.size()));
-  LRAM_HIP_CHECK(hipMemcpy(e->persist_blocks, host.data(), sizeof(PersistBlock) * host.size(), hipMemcpyHostToDevice));
-  if (!e->persist_counter) {
-    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->persist_counter), 2 * sizeof(unsigned long long)));
-    LRAM_HIP_CHECK(hipMemset(e->persist_counter, 0, 2 * sizeof(unsigned long long)));
-    e->persist_base = 0;
-  }
-  if (!e->persist_trace && std::getenv("LRAM_PERSIST_TRACE") != nullptr) {
-    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->persist_trace), 1024 * sizeof(unsigned long long)));
-    LRAM_HIP_CHECK(hipMemset(e->persist_trace, 0, 1024 * sizeof(unsigned long long)));
-  }
-  if (!e->persist_err) {
-    LRAM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->persist_err), sizeof(int), hipHostMallocMapped));
-    *e->persist_err = 0;
-  }
-}
-
-void persist_step(lram_engine* e, int path, const float* obs, int emb, const float* rtg, const float* rew,
-                  const uint8_t* reset, int discrete, float* actions, int32_t* tokens, hipStream_t s) {
-  const lram_config& c = e->cfg;
-  PersistArgs a{};
-  a.blocks = e->persist_blocks, a.n_blocks = c.n_blocks;
-  a.B = e->B, a.state_B = e->B, a.D = c.d_model, a.inner = c.inner, a.NH = c.n_heads, a.DH = c.inner / c.n_heads;
-  a.SDH = c.d_model / c.n_heads, a.F = c.ffn_dim, a.state_dim = c.state_dim, a.act_dim = c.act_dim, a.n_vocab = c.n_vocab;
-  a.n_discrete = c.n_discrete, a.action_channels = c.action_channels, a.pred_token = c.pred_token;
-  a.tok_min = c.tok_min, a.tok_max = c.tok_max, a.ln_eps = c.ln_eps, a.norm_is_rms = c.norm_is_rms;
-  a.w_state = e->w_state, a.b_state = e->b_state, a.w_rtg = e->w_rtg, a.b_rtg = e->b_rtg, a.w_rew = e->w_rew;
-  a.b_rew = e->b_rew, a.eln_g = e->eln_g, a.eln_b = e->eln_b, a.w_head = e->w_head, a.b_head = e->b_head;
-  a.post_g = e->post_g, a.post_b = e->post_b;
-  a.obs = obs, a.emb = emb, a.rtg = rtg, a.rew = rew, a.reset = reset, a.discrete = discrete, a.actions = actions;
-  a.tokens = tokens;
-  a.X = e->X.p, a.XN = e->XN.p, a.TOK = e->TOK.p, a.HID = e->HID.p, a.U = e->U.p, a.Q = e->Q.p, a.K = e->K.p, a.V = e->V.p;
-  a.XA = e->XA.p, a.H = e->H.p, a.SCAL = e->SCAL.p, a.LOGITS = e->LOGITS.p;
-  a.counter = e->persist_counter, a.base = e->persist_base;
-  a.abort_dev = reinterpret_cast<int*>(e->persist_counter + 1), a.err_host = e->persist_err;
-  a.trace = e->persist_trace;
-  int n_s = 0;
-  for (int i = 0; i < c.n_blocks; ++i) n_s += c.block_is_slstm[i] != 0;
-  if (path == 1) {
-    launch_xlstm_persistent_step(a, c.tokens_per_step, e->persist_wgs, s);
-    e->persist_base += (unsigned long long)xlstm_persistent_barriers(c.n_blocks - n_s, n_s) * e->persist_wgs;
-  } else {
-    launch_xlstm_small_batch_step(a, c.tokens_per_step, c.block_is_slstm, s);
-  }
-}
-
 // L consecutive timesteps for every env slot (L = 1: one env-step).  Inputs are [B, L, .] / [B, L] row-major; the
 // reset mask applies before the first timestep; the action head runs on the last timestep only (and only if an
 // output buffer is given).  One fork / join of the slice streams brackets the whole call.
@@ -1913,8 +1801,6 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
       const std::string m(v);
       e->lazy_mode = m == "lazy" ? 1 : (m == "eager" || m == "materialised" || m == "materialized") ? 0 : 2;
     }
-    if (const char* v = std::getenv("LRAM_PERSISTENT")) e->persist_mode = std::max(0, std::min(3, std::atoi(v)));
-    if (const char* v = std::getenv("LRAM_PERSIST_WGS")) e->persist_wgs = std::max(8, std::min(256, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_F16_MIN_ROWS")) e->f16x2_min_rows = std::max(9, std::atoi(v));
     if (const char* v = std::getenv("LRAM_COMPAT_SHARE")) e->compat_share = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_MAMBA_DT_FUSE")) e->mamba_dt_fuse = std::atoi(v) != 0;
@@ -2036,16 +1922,6 @@ int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding
     LRAM_REQUIRE(e->cfg.tokens_per_step == 3, "lram_step: the (state, rtg, reward) front end needs tokens_per_step == 3");
     LRAM_HIP_CHECK(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (e->persist_err != nullptr && *e->persist_err != 0 && e->persist_mode == 1) {
-      e->persist_mode = 2;  // back to the default path from here on
-      throw Error("lram_step: a device-wide barrier of the whole-step kernel timed out in an earlier call (results of "
-                  "that call are invalid); the whole-step kernel is now disabled for this engine");
-    }
-    if (const int path = persist_path(e)) {
-      lazy_materialize(e, s);
-      persist_step(e, path, dev_obs, obs_is_embedding, dev_rtg, dev_reward, dev_reset_mask, discrete, dev_actions, dev_tokens, s);
-      return;
-    }
     compat_prepare(e, discrete);  // (workspace of the shared repeated forwards: outside any capture)
     if (e->graph_mode && !e->prof_on) {
       GraphKey key{};
@@ -2234,38 +2110,6 @@ int32_t lram_get_compat_mode(const lram_engine* e, int32_t* mamba_repeat, int32_
   if (stale_state) *stale_state = e->compat_stale ? 1 : 0;
   return 0;
 }
-
-int32_t lram_set_persistent_mode(lram_engine* e, int32_t mode) {
-  return guarded([&] {
-    LRAM_REQUIRE(e != nullptr && mode >= 0 && mode <= 3,
-                 "lram_set_persistent_mode: mode must be 0 (generic launches), 1 (whole-step kernel), 2 (auto) or 3 (fused "
-                 "phase kernels)");
-    LRAM_REQUIRE((mode != 1 && mode != 3) || e->B == 0 || persist_supported(e, mode),
-                 "lram_set_persistent_mode: the small-batch paths cover xLSTM stacks with 3 tokens per timestep and at most "
-                 "8 env slots (sLSTM head dim a multiple of 4 for mode 1, of 16 for mode 3)");
-    if (mode == 1 && e->persist_counter != nullptr) {
-      // (re-)enabling the whole-step kernel starts from a clean barrier: counter, abort word and the host-mapped error
-      // word are cleared once everything enqueued so far has drained (a timed-out call leaves all three set)
-      LRAM_HIP_CHECK(hipSetDevice(e->device));
-      LRAM_HIP_CHECK(hipDeviceSynchronize());
-      LRAM_HIP_CHECK(hipMemset(e->persist_counter, 0, 2 * sizeof(unsigned long long)));
-      e->persist_base = 0;
-      if (e->persist_err) *e->persist_err = 0;
-    }
-    e->persist_mode = mode;
-  });
-}
-
-int32_t lram_persistent_trace(lram_engine* e, uint64_t* host_out, int32_t n) {
-  return guarded([&] {
-    LRAM_REQUIRE(e && host_out && n > 0 && n <= 1024, "lram_persistent_trace: bad argument");
-    LRAM_REQUIRE(e->persist_trace != nullptr, "lram_persistent_trace: set LRAM_PERSIST_TRACE=1 before lram_create");
-    LRAM_HIP_CHECK(hipDeviceSynchronize());
-    LRAM_HIP_CHECK(hipMemcpy(host_out, e->persist_trace, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
-  });
-}
-
-int32_t lram_get_persistent_mode(const lram_engine* e) { return (e != nullptr && e->B > 0) ? persist_path(e) : 0; }
 
 int32_t lram_profile_begin(lram_engine* e) {
   return guarded([&] {

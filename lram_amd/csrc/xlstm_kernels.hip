@@ -26,8 +26,7 @@ namespace {
 constexpr int kPreThreads = 256;
 constexpr int kMaxGroups = 4;  // channel groups (of 4) per thread: inner <= 4096
 
-// (body as a device function of the env index: the launch-per-kernel path calls it with blockIdx.x, the whole-step
-// kernel of persistent_step.inl with the env slots it loops over)
+// (body as a device function of the env index: the kernel calls it with blockIdx.x)
 template <int T, int NH, bool SINGLE = false>
 __device__ __forceinline__ void mlstm_pre_body(const MlstmPreArgs& a, const int b) {
   constexpr int NRED = 2 * T * NH;
@@ -814,8 +813,6 @@ __global__ __launch_bounds__(256) void gelu_gate_kernel(const float* p, float* o
   *reinterpret_cast<float4*>(out + r * F + c) = o;
 }
 
-#include "persistent_step.inl"
-
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -928,74 +925,6 @@ void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream) {
     case 12: launch_cell_t<12>(a, stream); break;
     default: throw Error("lram: tokens per launch must be 1..4, 6, 9 or 12");
   }
-  LRAM_HIP_CHECK(hipGetLastError());
-}
-
-int xlstm_persistent_barriers(int n_mlstm, int n_slstm) { return 2 + 4 * n_mlstm + 6 * n_slstm; }
-
-size_t xlstm_persistent_lds_bytes(const PersistArgs& a, int T) {
-  const size_t rows = kPsRowGroup;
-  size_t fl = std::max<size_t>(rows * a.D, std::max<size_t>(rows * a.inner, rows * (size_t)a.F));
-  fl = std::max<size_t>(fl, (size_t)2 * T * a.DH + 16 * T * 64);  // cell body, 64-column slices
-  fl = std::max<size_t>(fl, (size_t)a.B * a.D);
-  fl = std::max<size_t>(fl, (size_t)5 * a.SDH);
-  return fl * sizeof(float);
-}
-
-void launch_xlstm_persistent_step(const PersistArgs& a_in, int T, int n_wgs, hipStream_t stream) {
-  LRAM_REQUIRE(T == 3, "persistent step: tokens_per_step must be 3");
-  LRAM_REQUIRE(a_in.B >= 1 && a_in.B <= kPersistMaxBatch, "persistent step: batch out of range");
-  LRAM_REQUIRE(a_in.DH % 64 == 0 && a_in.SDH % 4 == 0 && a_in.D % 4 == 0 && a_in.F % 4 == 0, "persistent step: geometry");
-  PersistArgs a = a_in;
-  const size_t lds = xlstm_persistent_lds_bytes(a, T);
-  LRAM_REQUIRE(lds <= 120 * 1024, "persistent step: model too wide for the LDS row buffers");
-  static uint64_t raised = 0;
-  if (first_use_on_device(raised))
-    LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xlstm_persistent_step_kernel<3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-  void* params[] = {&a};
-  LRAM_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&xlstm_persistent_step_kernel<3>), dim3(n_wgs),
-                                            dim3(256), params, lds, stream));
-}
-
-// The same step as one launch per phase (small-batch path): `is_slstm` per block comes from the host's config.
-template <int PH>
-static void launch_phase(const PersistArgs& a, int blk, int tok, int nwg, size_t lds, hipStream_t s) {
-  if (lds > 48 * 1024) {
-    static uint64_t raised = 0;
-    if (first_use_on_device(raised))
-      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&xlstm_phase_kernel<3, PH>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-  }
-  hipLaunchKernelGGL((xlstm_phase_kernel<3, PH>), dim3(std::max(1, nwg)), dim3(256), lds, s, a, blk, tok);
-}
-
-void launch_xlstm_small_batch_step(const PersistArgs& a, int T, const int32_t* block_is_slstm, hipStream_t s) {
-  LRAM_REQUIRE(T == 3, "small-batch step: tokens_per_step must be 3");
-  LRAM_REQUIRE(a.B >= 1 && a.B <= kPersistMaxBatch, "small-batch step: batch out of range");
-  LRAM_REQUIRE(a.DH % 64 == 0 && a.SDH % 16 == 0 && a.D % 4 == 0 && a.F % 4 == 0, "small-batch step: geometry");
-  const int B = a.B, R = B * T, D = a.D, inner = a.inner, NH = a.NH, F = a.F;
-  const size_t f4 = sizeof(float), rows = kPsRowGroup;
-  auto col_wgs = [](int n) { return (n + 4 * kPsCols - 1) / (4 * kPsCols); };  // one pass of every wave
-  launch_phase<kPhFrontEmbed>(a, 0, 0, R * ((D + 63) / 64), 0, s);
-  launch_phase<kPhFrontNorm>(a, 0, 0, (R + 3) / 4, 0, s);
-  for (int i = 0; i < a.n_blocks; ++i) {
-    if (!block_is_slstm[i]) {
-      launch_phase<kPhMA>(a, i, 0, col_wgs(2 * inner), rows * D * f4, s);
-      launch_phase<kPhMB>(a, i, 0, B, 0, s);
-      launch_phase<kPhMC>(a, i, 0, B * NH * (a.DH / 64), (2 * T * a.DH + 16 * T * 64) * f4, s);
-      launch_phase<kPhMD>(a, i, 0, col_wgs(D), rows * inner * f4, s);
-    } else {
-      launch_phase<kPhS1>(a, i, 0, B, 0, s);
-      launch_phase<kPhS2>(a, i, 0, col_wgs(4 * D), 0, s);
-      for (int t = 0; t < T; ++t) launch_phase<kPhS3Tok>(a, i, t, B * NH * (a.SDH / 16), 0, s);
-      launch_phase<kPhS4>(a, i, 0, R, D * f4, s);
-      launch_phase<kPhS5>(a, i, 0, col_wgs(2 * F), 0, s);
-      launch_phase<kPhS6>(a, i, 0, col_wgs(D), rows * F * f4, s);
-    }
-  }
-  launch_phase<kPhHead>(a, 0, 0, col_wgs(a.act_dim * a.n_vocab), (size_t)B * D * f4, s);
-  launch_phase<kPhArgmax>(a, 0, 0, (B * a.act_dim + 3) / 4, 0, s);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

@@ -58,9 +58,6 @@ _SYMBOLS = {
     "lram_state_import": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
     "lram_set_graph_mode": (ctypes.c_int32, [_VP, ctypes.c_int32]),
     "lram_set_micro_batches": (ctypes.c_int32, [_VP, ctypes.c_int32]),
-    "lram_set_persistent_mode": (ctypes.c_int32, [_VP, ctypes.c_int32]),
-    "lram_get_persistent_mode": (ctypes.c_int32, [_VP]),
-    "lram_persistent_trace": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int32]),
     "lram_set_compat_mode": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32]),
     "lram_get_compat_mode": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "lram_profile_begin": (ctypes.c_int32, [_VP]),
@@ -385,23 +382,6 @@ class Engine:
     def set_micro_batches(self, n: int):
         """Env slices pipelined on separate HIP streams (0 = auto, 1 = off); results are independent of n."""
         _check(self.lib, self.lib.lram_set_micro_batches(self._h, int(n)))
-
-    def set_persistent_mode(self, mode):
-        """Small-batch path (lram_set_persistent_mode): 0 / "generic" launch-per-kernel, 1 / "whole_step" cooperative
-        kernel, 2 / "auto", 3 / "fused" phase kernels."""
-        names = {"generic": 0, "off": 0, "whole_step": 1, "auto": 2, "fused": 3}
-        _check(self.lib, self.lib.lram_set_persistent_mode(self._h, names[mode] if isinstance(mode, str) else int(mode)))
-
-    @property
-    def persistent_mode(self) -> str:
-        """The path the next step() takes: "generic", "whole_step" or "fused"."""
-        return {0: "generic", 1: "whole_step", 3: "fused"}[int(self.lib.lram_get_persistent_mode(self._h))]
-
-    def persistent_trace(self, n: int):
-        """Phase timestamps (100 MHz ticks) of the last whole-step launch (needs LRAM_PERSIST_TRACE=1 at creation)."""
-        buf = (ctypes.c_uint64 * n)()
-        _check(self.lib, self.lib.lram_persistent_trace(self._h, buf, n))
-        return list(buf)
 
     def set_compat_mode(self, mamba_repeat: int = 1, stale_state: bool = False):
         """Reference-trajectory modes of the Mamba agent (lram_set_compat_mode):

@@ -4,7 +4,7 @@
 # over the 8 XCDs).  Counters only, no trace domains beside --kernel-trace.
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/pmc_mfma; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && export PYTHONPATH=$R
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -- python3 $R/scripts/bench_gemm.py f16x2 bf16x3 f32 > $OUT/order.json 2> $OUT/err.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -- python3 $R/scripts/bench_gemm.py f16x2 f16x2p bf16x3 f32 > $OUT/order.json 2> $OUT/err.log
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections, json
 order = json.loads(open(sys.argv[1] + "/order.json").readline())
@@ -12,7 +12,7 @@ rows = collections.defaultdict(dict)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if ("gemm_bf16x3_kernel" in n or "gemm_f32_kernel" in n or "gemm_f16x2_kernel" in n):
+        if ("gemm_bf16x3_kernel" in n or "gemm_f32_kernel" in n or "gemm_f16x2_kernel" in n or "gemm_f16x2p_kernel" in n):
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(rows)
 i = 0
