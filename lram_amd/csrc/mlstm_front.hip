@@ -225,7 +225,9 @@ void launch_mlstm_front(const MlstmFrontArgs& a_in, hipStream_t stream) {
   }();
   // (same box, 4096 env slots: 2 envs per workgroup 426.2k env-steps/s, 4: 429.4k, 8: 431.1k / 429.7k, 16: 430.8k / 431.9k;
   // the one-workgroup-per-env kernel 420.3k / 419.0k -- profiles/r04_ab_front_kernel.txt)
-  a.epw = epw_env > 0 ? epw_env : (a.epw > 0 ? a.epw : 8);
+  // fewer envs per workgroup for smaller slices, so that the launch still covers the chip: one workgroup per CU from 256 envs
+  // (512-env slices at 8 envs per workgroup are 64 workgroups: 58.7 us per launch in the 1024-slot timeline)
+  a.epw = epw_env > 0 ? epw_env : (a.epw > 0 ? a.epw : std::max(1, std::min(8, a.B / 256)));
   const int nwg = (a.B + a.epw - 1) / a.epw;
   hipLaunchKernelGGL(mlstm_front_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, stream, a);
   LRAM_HIP_CHECK(hipGetLastError());

@@ -512,3 +512,33 @@ def test_errors_are_loud(hip_lib):
     with pytest.raises(ValueError):
         eng.step(torch.zeros(3, spec.state_dim).cuda(), torch.zeros(2).cuda(), torch.zeros(2).cuda())
     eng.close()
+
+
+@pytest.mark.parametrize("name,B", [("xlstm_16m", 400), ("mamba_48m", 352)])
+def test_presplit_projection_operands_change_nothing(hip_lib, name, B, monkeypatch):
+    """LRAM_GEMM_PRESPLIT (default on): the norms ahead of proj_up / in_proj write the f16x2 GEMM's operand planes instead of
+    fp32 rows + row maxima and the projection runs on gemm_f16x2p.hip.  Same pieces, same products, same order: the engine's
+    actions, hidden states and recurrent state are BIT-identical with the knob off (>= 1024 operand rows per launch)."""
+    from lram_amd.engine import Engine
+    spec = preset(name)
+    sd = init_state_dict(spec, seed=91)
+    seq = make_inputs(spec, B, 3, seed=92, reset_prob=0.1)
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("LRAM_GEMM_PRESPLIT", knob)
+        eng = Engine(spec, sd, B, device="cuda:0")
+        eng.set_micro_batches(1)
+        eng.gemm_counts(reset=True)
+        acts = []
+        for obs, rtg, rew, mask in seq:
+            a, _ = eng.step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+            acts.append(a.clone())
+        torch.cuda.synchronize()
+        ran = eng.gemm_counts()
+        assert ran["f16x2"]["launches"] > 0                      # the big projections did take the f16x2 family
+        _, hidden, _ = eng.taps()
+        outs[knob] = (torch.stack(acts), hidden.clone(), eng.export_state_tensor(spec.n_blocks - 1, 0).clone())
+        eng.close()
+    monkeypatch.delenv("LRAM_GEMM_PRESPLIT")
+    for x, y in zip(outs["1"], outs["0"]):
+        assert torch.equal(x, y)
