@@ -75,6 +75,13 @@ struct GemmArgs {
   const float* w_inv = nullptr;
   const float* a_amax = nullptr;
   int amax_parts = 1;  // row r's maximum = max of a_amax[r * amax_parts + 0 .. amax_parts - 1]
+  // ... times a_amax_mul[r] (optional) times a_amax_scale: an UPPER BOUND of the row's largest magnitude assembled from what
+  // the producers know (e.g. max |h| per head x a Cauchy-Schwarz bound of the gate) serves as well as the maximum itself --
+  // the split is floating point, a scale that is 2^k too small costs precision only for elements below 2^(k-18) of the row's
+  // largest (tests/test_gpu_parity.py::test_gemm_f16x2_tolerates_a_loose_row_bound)
+  const float* a_amax_mul = nullptr;
+  float a_amax_scale = 1.f;
+  float a_amax_c0 = 0.f, a_amax_c1 = 1.f;  // bound = (c0 + c1 * max of the parts) * mul[r] * scale
   // optional (f16x2 kernel with pre-split operands, gemm_f16x2p.hip): A pre-split by its producer into two f16 planes (hi, lo)
   // of the row-scaled value, laid out like a (row stride lda), `a2_plane` elements apart, with a2_inv[r] = the exact inverse
   // of row r's power-of-two scale (`a` may then be null; K a multiple of 32)
@@ -163,8 +170,11 @@ void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2 = nullptr,
                      uint16_t* planes = nullptr, int64_t plane_stride = 0,   // planes: bf16x3 GEMM operand (row stride
                      float* amax = nullptr, const ScalarTokens* st = nullptr,                                  // out_stride); out may then be null
-                     uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr);  // f16x2 operand planes (hi, lo) of the
-                                                                                             // row-scaled result + inverse row scales
+                     uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr,  // f16x2 operand planes (hi, lo) of the
+                     float* l2 = nullptr);                                                   // row-scaled result + inverse row scales;
+                                                                                             // l2: optional [rows] Euclidean norm of each output row
+void launch_max_row_l2(const float* w, int rows, int k, float* out, hipStream_t stream);  // out[0] = max_r |w[r, :]|_2
+void launch_max_abs(const float* v, int n, float* out, hipStream_t stream);                // out[0] = max_i |v[i]|
 // Mamba block entry: res_out = hidden (+ res_in);  normed = RMSNorm(res_out) * gamma.
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
                          const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes = nullptr,
@@ -232,6 +242,7 @@ struct MlstmFrontArgs {
   const float *bi = nullptr, *bf = nullptr;
   float* xa = nullptr;          // [B*T, inner] out  silu(conv)
   float* scal = nullptr;        // [B*T, NH, 4] out  (f_t, i_t, denom_t, m_t)
+  float* xa_amax = nullptr;     // optional [B*T, NH] out: max |xa| per (row, head) (an ingredient of proj_down's row-scale bound)
   const uint8_t* reset = nullptr;
   int B = 0, T = 0, inner = 0, NH = 0, K = 0;
   int epw = 0;                  // env slots per workgroup (0 = default)

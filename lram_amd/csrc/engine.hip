@@ -103,6 +103,7 @@ struct lram_engine {
     size_t rows, k;
   };
   std::map<const float*, Split16> split16;
+  bool down_presplit = false;  // LRAM_DOWN_PRESPLIT=1: proj_down's gated operand split once by a row kernel (in place of the row-maximum launch)
   bool gemm_presplit = true;   // LRAM_GEMM_PRESPLIT=0: the norms ahead of proj_up / in_proj write fp32 + row maxima (round 3) instead of
                                // the f16x2 GEMM's operand planes (gemm_f16x2p.hip)
   double gemm_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // launches / fp32-equivalent FLOPs per dispatcher family (lram_gemm_counts)
@@ -189,6 +190,14 @@ struct lram_engine {
   int B = 0;
   std::vector<BlockState> st;
   DevBuf X, XN, TOK, HID, U, Q, K, V, XA, H, G, SCAL, RY, LOGITS, RES, DTP;
+  DevBuf XN_L2; // [B*T] Euclidean norm of the mLSTM block's normed input rows (bound of the output gate: LRAM_AMAX_BOUND)
+  std::vector<float> z_norm_max;  // per mLSTM block: max_j |proj_up.weight[inner + j, :]|_2 (z half)
+  std::vector<float> h_bound_c0, h_bound_c1;  // per mLSTM block: |GN(h) g + b + skip xa| <= c0 + c1 max|xa| (c0 = sqrt(DH) max|g| + max|b|, c1 = max|skip|)
+  bool amax_bound = false;  // LRAM_AMAX_BOUND=1: proj_down's row scales from an upper bound assembled by the GEMM's prologue (max |xa| per
+                            // head from the front end, |xn| from the norm, constants from finalize) instead of a row-maximum launch over
+                            // h * silu(z): -14 launches, -0.75 GB per step, accuracy unchanged (a 1024 x loose bound still passes the fp64
+                            // bar) and the step 1.5 % SLOWER (426.5k / 422.7k -> 418.6k / 417.2k, profiles/r04_ab_amax_bound.txt): off
+  DevBuf G2;    // the gated mLSTM output as f16x2 operand planes [2][B*T, inner] f16 (proj_down pre-split: LRAM_DOWN_PRESPLIT)
   DevBuf XN2;   // the norm output as f16x2 operand planes [2][B*T, D] f16 (pre-split projections): its own buffer -- a slice inside an
                 // sLSTM block uses XN as fp32 while another slice's mLSTM block holds planes
   // bf16x3 operand planes written by the producers of the big projections' A operands (row norm -> proj_up / in_proj,
@@ -287,7 +296,7 @@ struct lram_engine {
     lazy_ready = false;
     st.clear();
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
-                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &YPART, &X0, &U0})
+                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &G2, &XN_L2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &YPART, &X0, &U0})
       b->release();
     ascale_rows = 0;
     if (XN3) (void)hipFree(XN3);
@@ -532,6 +541,29 @@ void finalize(lram_engine* e) {
     }
     LRAM_HIP_CHECK(hipDeviceSynchronize());
   }
+  e->z_norm_max.assign(e->bw.size(), 0.f);
+  e->h_bound_c0.assign(e->bw.size(), 0.f), e->h_bound_c1.assign(e->bw.size(), 1.f);
+  if (c.backbone == LRAM_BACKBONE_XLSTM) {
+    DevBuf tmp;
+    tmp.alloc(1);
+    for (size_t i = 0; i < e->bw.size(); ++i) {
+      if (c.block_is_slstm[i]) continue;
+      launch_max_row_l2(e->bw[i].proj_up + (size_t)c.inner * c.d_model, c.inner, c.d_model, tmp.p, nullptr);
+      LRAM_HIP_CHECK(hipMemcpy(&e->z_norm_max[i], tmp.p, sizeof(float), hipMemcpyDeviceToHost));
+      float mg = 0.f, mb = 0.f, ms = 0.f;
+      launch_max_abs(e->bw[i].on_g, c.inner, tmp.p, nullptr);
+      LRAM_HIP_CHECK(hipMemcpy(&mg, tmp.p, sizeof(float), hipMemcpyDeviceToHost));
+      if (e->bw[i].on_b != nullptr) {
+        launch_max_abs(e->bw[i].on_b, c.inner, tmp.p, nullptr);
+        LRAM_HIP_CHECK(hipMemcpy(&mb, tmp.p, sizeof(float), hipMemcpyDeviceToHost));
+      }
+      launch_max_abs(e->bw[i].skip, c.inner, tmp.p, nullptr);
+      LRAM_HIP_CHECK(hipMemcpy(&ms, tmp.p, sizeof(float), hipMemcpyDeviceToHost));
+      // a group-normalised vector of DH elements has no element beyond sqrt(DH - 1) in magnitude
+      e->h_bound_c0[i] = std::sqrt((float)(c.inner / c.n_heads)) * mg + mb, e->h_bound_c1[i] = ms;
+    }
+    tmp.release();
+  }
   e->slstm_rt2.assign(e->bw.size(), DevBuf());
   if (c.backbone == LRAM_BACKBONE_XLSTM && slstm_seq_supported(c.d_model, c.n_heads, c.tokens_per_step)) {
     for (size_t i = 0; i < e->bw.size(); ++i) {
@@ -576,6 +608,8 @@ void alloc_workspace(lram_engine* e, int tokens) {
   e->X.alloc(BT * D);
   e->XN.alloc(BT * D);
   if (e->gemm_presplit && e->use_f16x2) e->XN2.alloc(BT * D);
+  if (e->amax_bound && e->use_f16x2 && c.backbone == LRAM_BACKBONE_XLSTM) e->XN_L2.alloc(BT);
+  if (e->down_presplit && e->gemm_presplit && e->use_f16x2 && c.backbone == LRAM_BACKBONE_XLSTM) e->G2.alloc(BT * (size_t)c.inner);
   e->TOK.alloc(BT * D);
   e->HID.alloc(BT * D);
   e->LOGITS.alloc(B * c.act_dim * c.n_vocab);
@@ -1035,6 +1069,14 @@ bool gn_fused(const lram_engine* e, int T) {
          e->cfg.inner % 8 == 0 && e->cfg.d_model % 8 == 0 && e->B >= 64;  // (fewer rows take the GEMV path)
 }
 
+// proj_down's f16x2 row scales without a row-maximum launch: max |GN(h) + skip xa| per (row, head) from the read pass's epilogue
+// (values it holds in registers) times a bound of the output gate, |silu(z_j)| <= |z_j| <= |xn| |W_z[j]| (Cauchy-Schwarz: the row
+// norm of the block's normed input from the norm kernel, the largest row norm of proj_up's z half from finalize).
+bool amax_bound_now(const lram_engine* e, int T, int slice_envs) {
+  return e->amax_bound && e->use_f16x2 && e->XN_L2.p != nullptr && gn_fused(e, T) && !gate_in_pass(e, T) && e->front_multi &&
+         slice_envs >= e->front_min_envs && mlstm_front_supported(e->cfg.inner, e->cfg.n_heads, e->cfg.conv_k, T);  // (max |xa| comes from the multi-env front end)
+}
+
 void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl) {
   const lram_config& c = e->cfg;
   const int D = c.d_model, inner = c.inner, NH = c.n_heads, rows = sl.nb * T;
@@ -1049,7 +1091,7 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p + r0 * e->ucols, up.ldc = 2 * inner;
   up.m = rows, up.n = split_up_now(e) ? inner : 2 * inner, up.k = D;
   if (gn_fused(e, T) && !split_up_now(e)) up.act_silu_from = inner;  // the z half is stored as silu(z)
-  if (!a3 && !split_up_now(e) && takes_skinny_with_norm(e, up)) {
+  if (!a3 && !split_up_now(e) && !amax_bound_now(e, T, sl.nb) && takes_skinny_with_norm(e, up)) {  // (the bound needs the norm kernel's row norms)
     // few rows: the norm runs in the projection's prologue (each workgroup normalises its 32 rows in registers)
     up.a = e->X.p + r0 * D, up.norm_g = w.norm_g, up.norm_b = w.norm_b, up.norm_eps = c.ln_eps, up.norm_rms = c.norm_is_rms;
     launch_gemm_skinny(up, sl.s);
@@ -1061,7 +1103,8 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     uint16_t* xn2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * D;
     launch_row_norm(e->X.p + r0 * D, D, (a3 || ps) ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
                     c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, ps ? nullptr : amx,
-                    nullptr, ps ? xn2 : nullptr, (int64_t)e->XN2.n, ps ? amx : nullptr);
+                    nullptr, ps ? xn2 : nullptr, (int64_t)e->XN2.n, ps ? amx : nullptr,
+                    amax_bound_now(e, T, sl.nb) ? e->XN_L2.p + r0 : nullptr);
     up.a_amax = amx;
     if (ps) up.a = nullptr, up.a_amax = nullptr, up.a2 = xn2, up.a2_plane = (int64_t)e->XN2.n, up.a2_inv = amx;
     if (a3) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
@@ -1075,6 +1118,7 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     fa.n_state = st.n.p + b0 * inner, fa.m_state = st.m.p + b0 * NH;
     fa.conv_w = w.conv_w, fa.conv_b = w.conv_b, fa.wq = w.wq, fa.wk = w.wk, fa.gc = e->gate_coef[i].p, fa.bi = w.bi, fa.bf = w.bf;
     fa.xa = e->XA.p + r0 * e->icols, fa.scal = e->SCAL.p + r0 * NH * 4, fa.reset = reset ? reset + b0 : nullptr;
+    if (amax_bound_now(e, T, sl.nb)) fa.xa_amax = e->AMX_H.p + r0 * NH;
     fa.B = sl.nb, fa.T = T, fa.inner = inner, fa.NH = NH, fa.K = c.conv_k;
     launch_mlstm_front(fa, sl.s);
     return;
@@ -1149,12 +1193,25 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
   if (gn_fused(e, T)) {  // H holds GN(h) + skip * xa, U's z half silu(z)
     GemmArgs dn;
     dn.a = e->H.p + r0 * e->icols, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
+    dn.m = rows, dn.n = D, dn.k = inner;
     if (gate_in_pass(e, T)) {  // H is gated already; its row maxima came with it, one per head
       if (e->use_f16x2) dn.a_amax = e->AMX_H.p + r0 * NH, dn.amax_parts = NH;
+    } else if (e->G2.p != nullptr && presplit_for(e, w.proj_down, rows, D, inner)) {
+      // the gated operand split ONCE per row (H * silu(z) -> two f16 planes + inverse row scales: one row kernel in place of
+      // the row-maximum launch) instead of in every workgroup of every N tile while it is staged
+      uint16_t* g2 = reinterpret_cast<uint16_t*>(e->G2.p) + r0 * inner;
+      float* inv = e->AMX_H.p + r0;
+      launch_row_split_f16x2(e->H.p + r0 * e->icols, inner, e->U.p + r0 * e->ucols + inner, 2 * inner, rows, inner, g2, inner,
+                             (int64_t)e->G2.n, inv, sl.s);
+      dn.a = nullptr, dn.a2 = g2, dn.a2_plane = (int64_t)e->G2.n, dn.a2_inv = inv;
     } else {
       dn.gate = e->U.p + r0 * e->ucols + inner, dn.ldg = 2 * inner;
+      if (amax_bound_now(e, T, sl.nb)) {  // an upper bound of the gated rows' maxima, assembled by the GEMM's prologue
+        dn.a_amax = e->AMX_H.p + r0 * NH, dn.amax_parts = NH;
+        dn.a_amax_mul = e->XN_L2.p + r0, dn.a_amax_scale = 1.02f * e->z_norm_max[i];
+        dn.a_amax_c0 = e->h_bound_c0[i], dn.a_amax_c1 = e->h_bound_c1[i];
+      }
     }
-    dn.m = rows, dn.n = D, dn.k = inner;
     gemm(e, dn, sl.s);
     return;
   }
@@ -1830,6 +1887,8 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SLSTM_GATES_PAIR")) e->slstm_gates_pair = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_PRESPLIT")) e->gemm_presplit = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_DOWN_PRESPLIT")) e->down_presplit = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_AMAX_BOUND")) e->amax_bound = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FRONT_MIN_ENVS")) e->front_min_envs = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
     *out = e.release();
@@ -2232,6 +2291,9 @@ int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int
       g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
       g.residual = accumulate ? dev_c : nullptr;
       g.m = m, g.n = n, g.k = k, g.w2 = planes, g.w2_plane = (int64_t)numel, g.w_inv = scales, g.a_amax = scales + n;
+      // test hook: the row maxima handed over as an upper bound that is `slack` times too large (the engine's producers may
+      // hand over bounds instead of maxima: GemmArgs::a_amax_mul / a_amax_scale)
+      if (const char* v = std::getenv("LRAM_TEST_AMAX_SLACK")) g.a_amax_scale = std::max(1.f, (float)std::atof(v));
       launch_gemm_f16x2(g, s);
       LRAM_HIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
     if (gm < g.m) {
       const float* ap = g.a_amax + (int64_t)gm * g.amax_parts;
       for (int q = 0; q < g.amax_parts; ++q) mx = fmaxf(mx, ap[q]);
+      mx = (g.a_amax_c0 + g.a_amax_c1 * mx) * (g.a_amax_mul != nullptr ? g.a_amax_mul[gm] : 1.f) * g.a_amax_scale;
     }
     srow[tid] = gm < g.m ? pow2_scale(mx) : 0.f;
   }
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
       if (gm < g.m) {
         const float* ap = g.a_amax + (int64_t)gm * g.amax_parts;
         for (int q = 0; q < g.amax_parts; ++q) mx = fmaxf(mx, ap[q]);
+        mx = (g.a_amax_c0 + g.a_amax_c1 * mx) * (g.a_amax_mul != nullptr ? g.a_amax_mul[gm] : 1.f) * g.a_amax_scale;
       }
       srow[tid] = gm < g.m ? pow2_scale(mx) : 0.f;
     }
