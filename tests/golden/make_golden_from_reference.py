@@ -8,6 +8,11 @@ Importable pieces of the hot path: the action tokenizer package
 and `src/algos/models/rms_norm.py` (LlamaRMSNorm, used at decision_xlstm.py:190-191).  Everything else on
 the path needs gym / stable_baselines3 / xlstm / mamba_ssm, which are not installable here.
 Only inputs and outputs are stored -- no reference source text.
+
+SECURITY NOTE: this generator `exec`s code taken from /root/reference (named classes, functions and top-level assignments of
+its files), i.e. it runs untrusted third-party code with the privileges of whoever regenerates the fixtures.  Run it only
+in a throw-away build container on a read-only checkout of the reference (as here), never on a developer machine with
+credentials and never on the GPU box; nothing in tests/, bench.py or the product package imports or executes it.
 """
 import importlib.util
 import json
