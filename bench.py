@@ -491,7 +491,8 @@ def main(argv=None, engine_factory=None, device=None):
         per_env = cell_bytes_lazy(spec, T) if lazy else cell_bytes_materialised(spec, T)
         per_env_8d = cell_bytes_materialised(spec, T)
     else:
-        kname, per_env = "mamba_ssm_kernel", ssm_bytes(spec, T)
+        # (lane = channel form for env-steps of the d_state-16 / dt_rank-48 geometry from 64 envs, else the 4-lanes-per-channel kernel)
+        kname, per_env = "mamba_ssm_lane_kernel | mamba_ssm_kernel (selective state update)", ssm_bytes(spec, T)
         per_env_8d = per_env
     roofline = {"bound": "hbm", "kernel": kname, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": None, "traffic": None, "traffic_source": None,

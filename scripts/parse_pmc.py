@@ -21,7 +21,7 @@ import json
 import os
 import sys
 
-CELL = ("mlstm_cell_kernel", "mlstm_lazy_cell_kernel", "mamba_ssm_kernel")
+CELL = ("mlstm_cell_kernel", "mlstm_lazy_cell_kernel", "mamba_ssm_kernel", "mamba_ssm_lane_kernel")
 FOLD = ("mlstm_lazy_fold_kernel",)
 COPY = ("stream_copy",)
 N_STEADY = int(os.environ.get("PMC_STEADY_STEPS", "26"))   # two fold periods

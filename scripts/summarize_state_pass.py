@@ -22,7 +22,7 @@ def main(prof_dir: str) -> None:
     for r in csv.DictReader(open(trace)):
         d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         k = r["Kernel_Name"]
-        if "mlstm_lazy_cell_kernel" in k or "mlstm_cell_kernel" in k or "mamba_ssm_kernel" in k:
+        if "mlstm_lazy_cell_kernel" in k or "mlstm_cell_kernel" in k or "mamba_ssm_kernel" in k or "mamba_ssm_lane_kernel" in k:
             cells[int(r["Grid_Size_Z"])].append(d)
             name = k.split("(")[0].replace("void ", "").replace("lram::(anonymous namespace)::", "")
         elif "mlstm_lazy_fold_kernel" in k:
