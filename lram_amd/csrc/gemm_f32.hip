@@ -427,7 +427,10 @@ int gemm_choose_split_k(GemmArgs& g) {
   // LRAM_SPLITK_TILES (measurement knob): outputs with fewer 128 x 128 tiles than this are split along K
   static const int min_tiles = [] {
     const char* v = std::getenv("LRAM_SPLITK_TILES");
-    return v ? std::atoi(v) : 128;
+    // (round 4: 128 -> 48.  With the faster front end the 1024-slot step is bound by its chain, whose proj_down -- 48 tiles of
+    // 128 x 128 per 512-env slice -- ran as 5 K splits + a reduce launch: 313k -> 320k env-steps/s unsplit; 512 / 2048 / 4096 slots,
+    // Mamba-48M and the 206M stack within +- 0.5 %: profiles/r04_ab_splitk_threshold.txt)
+    return v ? std::atoi(v) : 48;
   }();
   if (tiles >= min_tiles || nk < 4) return 1;
   int S = std::min(std::min(nk / 2, 16), (256 + tiles - 1) / tiles);
