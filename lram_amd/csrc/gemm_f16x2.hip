@@ -451,12 +451,18 @@ void launch_gemm_f16x2(const GemmArgs& g_in, hipStream_t stream) {
     S = gemm_choose_split_k(g);
   const int tiles_n = (g.n + BN - 1) / BN;
   const int tiles128 = ((g.m + 127) / 128) * tiles_n;
-  // 64-row tiles where 128-row tiles leave workgroup slots empty (three workgroups per CU: 768 slots)
+  // 64-row tiles where 128-row tiles leave workgroup slots empty (three workgroups per CU: 768 slots) and the launch is narrow, or
+  // where they would leave CUs without any workgroup and K is short (1536 x 1024 x 512: 31.6 us with 96 tiles of 128 rows, 20.5
+  // with 192 of 64; long-K launches: see launch_gemm_f16x2p)
   static const int force_bm = [] {
     const char* v = std::getenv("LRAM_GEMM_BM");
     return v ? std::atoi(v) : 0;
   }();
-  const bool small = force_bm == 64 || (force_bm == 0 && S == 1 && tiles128 < 768 && tiles_n <= 6 && g.m > 64);
+  static const int bm64_below = [] {
+    const char* v = std::getenv("LRAM_GEMM_BM64_BELOW");
+    return v ? std::atoi(v) : 256;
+  }();
+  const bool small = force_bm == 64 || (force_bm == 0 && g.m > 64 && ((S == 1 && tiles128 < 768 && tiles_n <= 6) || ((long)tiles128 * S < bm64_below && g.k <= 768)));
   const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;
   dim3 grid(tiles, 1, S);
   gemm_choose_xcd_split(g, small ? 64 : 128, BN, 4);

@@ -33,21 +33,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int PLANE = 128 * BK;      // f16 elements of one 128-row plane tile (8 KiB)
-constexpr int STAGE = 4 * PLANE;     // A hi, A lo, W hi, W lo (32 KiB)
+constexpr int BN = 128, BK = 32;
+constexpr int PLANE = 128 * BK;      // f16 elements of one 128-row plane tile of W (8 KiB)
 
-template <bool HAS_BIAS, bool HAS_RES, int NSTAGE>
+// BMT: tile height, 128 (64 x 64 per wave) or 64 (32 x 64 per wave: launches that would leave CUs without a workgroup)
+template <bool HAS_BIAS, bool HAS_RES, int NSTAGE, int BMT = 128>
 __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(1024))) _Float16 lds[NSTAGE * STAGE];
+  constexpr int TI = BMT / 64;                      // MFMA row tiles per wave
+  constexpr int APL = BMT * BK;                     // f16 elements of one A plane tile
+  constexpr int STG = 2 * APL + 2 * PLANE;          // one LDS stage: A hi, A lo, W hi, W lo
+  constexpr int NPA = 2 * (BMT / 16);               // 1 KiB DMA pieces of the A planes
+  constexpr int NPIECE = NPA + 16, PPW = NPIECE / 4;  // ... of a stage, per wave
+  __shared__ __attribute__((aligned(1024))) _Float16 lds[NSTAGE * STG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
   const int tiles_n = (g.n + BN - 1) / BN;
-  const int tiles_m = (g.m + BM - 1) / BM;
+  const int tiles_m = (g.m + BMT - 1) / BMT;
   int tm_idx, tn_idx;
   gemm_tile_of(g, blockIdx.x, tiles_m, tiles_n, tm_idx, tn_idx);  // XCD-aware tile order (common.h)
-  const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+  const int m0 = tm_idx * BMT, n0 = tn_idx * BN;
 
   // ---- DMA sources: 32 pieces of 1 KiB per stage (4 planes x 8 row blocks of 16 rows), 8 per wave.  Wave w takes
   // pieces w, w + 4, ...: piece p = plane (p >> 3), row block (p & 7).  Lane l fills linear position (row = 16 rb + l / 4,
@@ -55,34 +60,38 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
   // (their products land in rows / columns the epilogue drops).
   const _Float16* A2 = reinterpret_cast<const _Float16*>(g.a2);
   const _Float16* W2 = reinterpret_cast<const _Float16*>(g.w2);
-  const _Float16* src[8];
+  const _Float16* src[PPW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < PPW; ++i) {
     const int p = wave + 4 * i;
-    const int plane = p >> 3, rb = p & 7;
+    const bool is_a = p < NPA;
+    const int q = is_a ? p : p - NPA;                 // piece within its operand
+    const int rbs = is_a ? BMT / 16 : 8;              // row blocks per plane
+    const int plane = q / rbs, rb = q % rbs;
     const int row = 16 * rb + (lane >> 2);
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    if (plane < 2) {
+    if (is_a) {
       const int gm = min(m0 + row, g.m - 1);
       src[i] = A2 + (int64_t)plane * g.a2_plane + (int64_t)gm * g.lda + 8 * chunk;
     } else {
       const int gn = min(n0 + row, g.n - 1);
-      src[i] = W2 + (int64_t)(plane - 2) * g.w2_plane + (int64_t)gn * g.ldw + 8 * chunk;
+      src[i] = W2 + (int64_t)plane * g.w2_plane + (int64_t)gn * g.ldw + 8 * chunk;
     }
   }
   auto dma_tile = [&](int stage, int k0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < PPW; ++i) {
       const int p = wave + 4 * i;
-      // (LDS destination: wave-uniform base of the piece; the hardware adds lane * 16)
+      // (LDS destination: wave-uniform base of the piece -- pieces lie in the stage in piece order: A hi, A lo, W hi, W lo;
+      // the hardware adds lane * 16)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(lds + stage * STAGE + p * 512), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds + stage * STG + p * 512), 16, 0, 0);
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -90,8 +99,8 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
 
   const int li = lane & 31, lh = lane >> 5;
   const int sw = (li >> 2) & 3;  // chunk swizzle of this lane's rows (tile row offsets are multiples of 32)
-  const _Float16* a_base = lds + (64 * wm + li) * BK;
-  const _Float16* b_base = lds + 2 * PLANE + (64 * wn + li) * BK;
+  const _Float16* a_base = lds + ((BMT / 2) * wm + li) * BK;
+  const _Float16* b_base = lds + 2 * APL + (64 * wn + li) * BK;
 
   const int nk_all = g.k / BK;
   const int kt0 = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
@@ -102,16 +111,16 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int ko = ((2 * ks + lh) ^ sw) << 3;
-      f16x8 af[2][2], bf[2][2];
+      f16x8 af[TI][2], bf[2][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          af[t][p] = *reinterpret_cast<const f16x8*>(a_base + stage * STAGE + p * PLANE + 32 * t * BK + ko);
-          bf[t][p] = *reinterpret_cast<const f16x8*>(b_base + stage * STAGE + p * PLANE + 32 * t * BK + ko);
+          if (t < TI) af[t][p] = *reinterpret_cast<const f16x8*>(a_base + stage * STG + p * APL + 32 * t * BK + ko);
+          bf[t][p] = *reinterpret_cast<const f16x8*>(b_base + stage * STG + p * PLANE + 32 * t * BK + ko);
         }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           // smallest terms first
@@ -148,11 +157,11 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
   float* C = g.c;
   float* S = g.split_k > 1 ? g.splitk_ws + (int64_t)blockIdx.z * g.m * g.n : nullptr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TI; ++i) {
     float ainv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int row = m0 + (BMT / 2) * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
       ainv[r] = g.a2_inv[min(row, g.m - 1)];
     }
 #pragma unroll
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
       const float bv = HAS_BIAS ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = m0 + (BMT / 2) * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < g.m) {
           float v = acc[i][j][r] * (wi * ainv[r]);
           if (S != nullptr) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
@@ -228,18 +237,18 @@ void launch_row_split_f16x2(const float* a, int64_t lda, const float* gate, int6
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
-template <int NSTAGE>
+template <int NSTAGE, int BMT>
 static void launch_stage(const GemmArgs& g, dim3 grid, hipStream_t stream) {
   const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
   dim3 block(256);
   if (hb && hr)
-    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, true, NSTAGE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, true, NSTAGE, BMT>), grid, block, 0, stream, g);
   else if (hb)
-    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, false, NSTAGE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, false, NSTAGE, BMT>), grid, block, 0, stream, g);
   else if (hr)
-    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, true, NSTAGE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, true, NSTAGE, BMT>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, false, NSTAGE>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, false, NSTAGE, BMT>), grid, block, 0, stream, g);
 }
 
 void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
@@ -264,11 +273,31 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
     g.split_k = 1, g.k_tiles_per_split = 0;  // output activation: K unsplit
   else
     S = gemm_choose_split_k(g);
-  const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
+  // 64-row tiles where 128-row tiles would leave CUs without a workgroup AND K is short (16M at 1024 slots: proj_up's
+  // 1536 x 1024 x 512 halves are 96 tiles of 128 x 128 -- 26.0 us -- or 192 of 64 x 128 -- 17.8 us; 1024 / 2048 slots +1.0 / +1.9 %).
+  // Standalone the 64-row tiles win on every launch below ~400 tiles (Mamba's out_proj 3072 x 768 x 1536: 43 vs 51 us, the 206M
+  // proj_down 768 x 1280 x 2560: 56 vs 82 us), but inside the two-slice pipeline -- where the other slice's kernels fill the idle
+  // CUs anyway -- their 1.5 x operand traffic per flop costs Mamba-48M 2.3 % and the 206M stack 1.5 %: long-K launches keep 128 rows
+  // (profiles/r04_ab_tile_height.txt; LRAM_GEMM_BM = 64 / 128 forces either, LRAM_GEMM_BM64_BELOW moves the tile-count limit)
+  static const int force_bm = [] {
+    const char* v = std::getenv("LRAM_GEMM_BM");
+    return v ? std::atoi(v) : 0;
+  }();
+  static const int bm64_below = [] {
+    const char* v = std::getenv("LRAM_GEMM_BM64_BELOW");
+    return v ? std::atoi(v) : 256;
+  }();
+  const int tiles128 = ((g.m + 127) / 128) * ((g.n + BN - 1) / BN);
+  const bool bm64 = force_bm == 64 || (force_bm == 0 && (long)tiles128 * S < bm64_below && g.k <= 768 && g.m > 64);
+  const int tiles = bm64 ? ((g.m + 63) / 64) * ((g.n + BN - 1) / BN) : tiles128;
   dim3 grid(tiles, 1, S);
-  gemm_choose_xcd_split(g, BM, BN, 4);
+  gemm_choose_xcd_split(g, bm64 ? 64 : 128, BN, 4);
   const int stages = stages_env > 0 ? stages_env : ((long)tiles * S >= 384 ? 1 : 2);
-  if (stages == 1) launch_stage<1>(g, grid, stream); else launch_stage<2>(g, grid, stream);
+  if (bm64) {
+    if (stages == 1) launch_stage<1, 64>(g, grid, stream); else launch_stage<2, 64>(g, grid, stream);
+  } else {
+    if (stages == 1) launch_stage<1, 128>(g, grid, stream); else launch_stage<2, 128>(g, grid, stream);
+  }
   LRAM_HIP_CHECK(hipGetLastError());
   if (S > 1) launch_splitk_reduce(g, stream);
 }

@@ -20,6 +20,10 @@ SHAPES = [  # (tag, M, N, K)
     # Mamba-48M at 2048 envs runs two slices of 1024 envs: 3072 rows per projection launch
     ("mamba_in_s", 3072, 3072, 768), ("mamba_out_s", 3072, 768, 1536), ("mamba_x_s", 3072, 80, 1536),
     ("mamba_dt_s", 3072, 1536, 48),
+    # 16M at 1024 env slots: two slices of 512 envs, 1536 rows per projection launch
+    ("c2_down", 1536, 512, 1024), ("c2_up_x", 1536, 1024, 512), ("c2_up", 1536, 2048, 512),
+    # 206M at 512 env slots: two slices of 256 envs, 768 rows per projection launch (weights beyond one XCD's L2)
+    ("206m_up_s", 768, 5120, 1280), ("206m_down_s", 768, 1280, 2560),
 ]
 REPS = 5
 
