@@ -22,6 +22,21 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + expf(-x)); 
 // torch softplus (beta 1, threshold 20)
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
+// The same two on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each; results within ~3 ulp of the libm
+// forms above), for kernels that evaluate them per (channel, token): the libm softplus is a 145-instruction double-float log1p and
+// was 39 % of the Mamba state-update kernel's instruction stream.
+__device__ __forceinline__ float silu_hw(float x) {
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+// softplus(x) = max(x, 0) + log1p(e), e = exp(-|x|); log1p(e) = log(u) * e / (u - 1) with u = fl(1 + e) cancels the rounding of
+// 1 + e (for u == 1 the result is e itself); above the reference's threshold 20 the second term is below half an ulp of x
+__device__ __forceinline__ float softplus_hw(float x) {
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(x));
+  const float u = 1.f + e, d = u - 1.f;
+  const float t = (__builtin_amdgcn_logf(u) * 0.69314718055994531f) * (e * __builtin_amdgcn_rcpf(d));
+  return fmaxf(x, 0.f) + (d == 0.f ? e : t);
+}
+
 // exact (erf) GELU, torch.nn.functional.gelu default
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
@@ -84,6 +99,23 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
+}
+
+// The wave's maximum of NON-NEGATIVE values, in lane 63 only, on the DPP cross-lane paths (two quad permutes, two row mirrors, two
+// row broadcasts) instead of six ds_bpermute round trips through the LDS crossbar: for kernels that take a maximum per (row,
+// channel block) inside their inner loop.  Non-negative floats order like their bit patterns, so the maximum is taken on unsigned
+// integers with 0 for lanes a step has no source for -- the form hipcc folds into one v_max_u32_dpp per step.
+__device__ __forceinline__ float wave_max_nonneg_lane63(float x) {
+  unsigned v = __builtin_bit_cast(unsigned, x);
+#define LRAM_DPP_MAX(ctrl) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false))
+  LRAM_DPP_MAX(0xB1);   // quad_perm [1, 0, 3, 2]
+  LRAM_DPP_MAX(0x4E);   // quad_perm [2, 3, 0, 1]
+  LRAM_DPP_MAX(0x141);  // row_half_mirror
+  LRAM_DPP_MAX(0x140);  // row_mirror: every lane of a 16-lane row holds the row's maximum
+  LRAM_DPP_MAX(0x142);  // row_bcast15: row r takes row r - 1's
+  LRAM_DPP_MAX(0x143);  // row_bcast31: rows 2, 3 take row 1's (= rows 0, 1)
+#undef LRAM_DPP_MAX
+  return __builtin_bit_cast(float, v);
 }
 
 }  // namespace lram

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
 #pragma unroll
     for (int i = 0; i < kRows; ++i) {
       const int et = g + 4 * i;
-      if (et < nrow) sc[et / T][et % T][1][c] = softplus_f(acc[i] + bias);
+      if (et < nrow) sc[et / T][et % T][1][c] = softplus_hw(acc[i] + bias);
     }
   }
   for (int i = tid; i < ne * T * 2 * N; i += 256) {
@@ -165,9 +165,9 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
     if (w == 0)
       v = a.xc[row * di + d];
     else if (w == 1)
-      v = softplus_f(a.dtp[row * di + d] + a.dt_bias[d]);
+      v = softplus_hw(a.dtp[row * di + d] + a.dt_bias[d]);
     else
-      v = silu_f(a.xz[row * 2 * di + di + d]);
+      v = silu_hw(a.xz[row * 2 * di + di + d]);
     sc[et / T][et % T][w][c] = v;
   }
   __syncthreads();
@@ -231,7 +231,12 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
 // 16-term in-lane dot).  Same arithmetic as the 4-lane form (dt bit for bit: same k-ordered fma chain); y sums its 16
 // terms in lane order instead of 4 + shuffle tree.  Reference: selective_state_update as called from Mamba.step
 // (src/algos/models/decision_mamba.py:136-138, [3P] mamba_ssm 2.1.0).
-template <int T, int R, bool ILP, int OCC>
+// TR: the state block of a wave and an env -- 64 channels x 16 states, one contiguous 4 KB run -- moves between HBM and the
+// registers COALESCED (instruction q of a lane: 16 bytes at 1 KB * q + 16 * lane) and is transposed to / from the lane = channel
+// form through the wave's own 4 KB of LDS (in-order LDS pipeline of one wave: no barrier).  Without it each lane reads and writes
+// its 64 contiguous bytes as four 16-byte pieces at a 64-byte lane stride: that shape alone (no arithmetic, same grid) runs at
+// 2.5 TB/s, the coalesced one at 4.9 (scripts/rmw_pattern.cpp, profiles/r04_mamba_state_access_shape.txt).
+template <int T, int R, bool ILP, int OCC, bool TR>
 __global__ __launch_bounds__(256, OCC) void mamba_ssm_lane_kernel(float* __restrict__ ssm_state, const float* __restrict__ xc,
                                                              const float* __restrict__ xz, const float* __restrict__ xdb,
                                                              const float* __restrict__ dt_wt, const float* __restrict__ dt_bias,
@@ -246,24 +251,28 @@ __global__ __launch_bounds__(256, OCC) void mamba_ssm_lane_kernel(float* __restr
   const int e_begin = eg * epw, e_end = min(B, e_begin + epw);
   if (e_begin >= e_end) return;
   const int d = cb * 64 + lane;
+  __shared__ v4f_t tb_all[TR ? 4 * 256 : 1];
+  v4f_t* tb = tb_all + (TR ? (threadIdx.x >> 6) * 256 : 0);
   // per-channel constants, once per wave
   float wt[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) wt[r] = dt_wt[(int64_t)r * di + d];
-  float A[N];
+  float A2[N];  // A * log2(e), A = -exp(A_log): the decay exp(dt * A) is one multiply and one v_exp_f32
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float4 al = *reinterpret_cast<const float4*>(A_log + (int64_t)d * N + 4 * q);
-    A[4 * q] = -expf(al.x), A[4 * q + 1] = -expf(al.y), A[4 * q + 2] = -expf(al.z), A[4 * q + 3] = -expf(al.w);
+    constexpr float kLog2e = 1.4426950408889634f;
+    A2[4 * q] = -kLog2e * expf(al.x), A2[4 * q + 1] = -kLog2e * expf(al.y), A2[4 * q + 2] = -kLog2e * expf(al.z),
+            A2[4 * q + 3] = -kLog2e * expf(al.w);
   }
   const float Dd = Dp[d], bias = dt_bias[d];
   // operands of one env: its 16 states, x and z of the T tokens (requested one env ahead)
   v4f_t sn[4];
   float xn[T], zn[T];
   auto request = [&](int b) {
-    const float* sp = ssm_state + ((int64_t)b * di + d) * N;
+    const float* sp = TR ? ssm_state + ((int64_t)b * di + cb * 64) * N + 4 * lane : ssm_state + ((int64_t)b * di + d) * N;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sn[q] = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(sp + 4 * q));
+    for (int q = 0; q < 4; ++q) sn[q] = __builtin_nontemporal_load(reinterpret_cast<const v4f_t*>(sp + (TR ? 256 * q : 4 * q)));
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const int64_t row = (int64_t)b * T + t;
@@ -274,10 +283,18 @@ __global__ __launch_bounds__(256, OCC) void mamba_ssm_lane_kernel(float* __restr
   request(e_begin);
   for (int b = e_begin; b < e_end; ++b) {
     float s[N], x[T], z[T];
-    const bool rs = reset != nullptr && reset[b] != 0;  // (wave-uniform)
+    const bool rs = reset != nullptr && __builtin_amdgcn_readfirstlane((int)reset[b]) != 0;  // wave-uniform: a scalar branch
+    if (TR) {  // piece q of lane l is float4 64 q + l of the block; channel c owns float4s 4 c .. 4 c + 3
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      s[4 * q] = rs ? 0.f : sn[q].x, s[4 * q + 1] = rs ? 0.f : sn[q].y, s[4 * q + 2] = rs ? 0.f : sn[q].z, s[4 * q + 3] = rs ? 0.f : sn[q].w;
+      for (int q = 0; q < 4; ++q) tb[64 * q + lane] = sn[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sn[q] = tb[4 * lane + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[4 * q] = sn[q].x, s[4 * q + 1] = sn[q].y, s[4 * q + 2] = sn[q].z, s[4 * q + 3] = sn[q].w;
+    if (rs) {
+#pragma unroll
+      for (int n = 0; n < N; ++n) s[n] = 0.f;
     }
 #pragma unroll
     for (int t = 0; t < T; ++t) x[t] = xn[t], z[t] = zn[t];
@@ -297,13 +314,13 @@ __global__ __launch_bounds__(256, OCC) void mamba_ssm_lane_kernel(float* __restr
 #pragma unroll
         for (int r = 0; r < R; ++r) acc += wt[r] * xr[r];
       }
-      const float dt = softplus_f(acc + bias);
+      const float dt = softplus_hw(acc + bias);
       const float xv = x[t], dx = dt * xv;
       float yv = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
 #pragma unroll
       for (int n = 0; n < N; ++n) {
         // decay via the hardware exp2 (v_exp_f32): |dt * A| is O(1), relative error ~1e-7
-        s[n] = s[n] * __expf(dt * A[n]) + dx * xr[R + n];
+        s[n] = s[n] * __builtin_amdgcn_exp2f(dt * A2[n]) + dx * xr[R + n];
         const float term = s[n] * xr[R + N + n];
         if (!ILP || (n & 3) == 0) yv += term;
         else if ((n & 3) == 1) y1 += term;
@@ -311,19 +328,34 @@ __global__ __launch_bounds__(256, OCC) void mamba_ssm_lane_kernel(float* __restr
         else y3 += term;
       }
       if (ILP) yv = (yv + y1) + (y2 + y3);
-      yv = (yv + Dd * xv) * silu_f(z[t]);
+      yv = (yv + Dd * xv) * silu_hw(z[t]);
       y[row * di + d] = yv;
       if (amax != nullptr) {
-        const float m = wave_max(fabsf(yv));
-        if (lane == 0) amax[row * ncb + cb] = m;
+        const float m = wave_max_nonneg_lane63(fabsf(yv));
+        if (lane == 63) amax[row * ncb + cb] = m;
       }
     }
-    float* sp = ssm_state + ((int64_t)b * di + d) * N;
+    if (TR) {
+      v4f_t o[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v4f_t v;
-      v.x = s[4 * q], v.y = s[4 * q + 1], v.z = s[4 * q + 2], v.w = s[4 * q + 3];
-      __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(sp + 4 * q));
+      for (int q = 0; q < 4; ++q) {
+        v4f_t v;
+        v.x = s[4 * q], v.y = s[4 * q + 1], v.z = s[4 * q + 2], v.w = s[4 * q + 3];
+        tb[4 * lane + q] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = tb[64 * q + lane];
+      float* sp = ssm_state + ((int64_t)b * di + cb * 64) * N + 4 * lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) __builtin_nontemporal_store(o[q], reinterpret_cast<v4f_t*>(sp + 256 * q));
+    } else {
+      float* sp = ssm_state + ((int64_t)b * di + d) * N;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v4f_t v;
+        v.x = s[4 * q], v.y = s[4 * q + 1], v.z = s[4 * q + 2], v.w = s[4 * q + 3];
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f_t*>(sp + 4 * q));
+      }
     }
   }
 }
@@ -382,13 +414,19 @@ void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream) {
       const char* v = std::getenv("LRAM_MAMBA_SSM_OCC");
       return v ? std::atoi(v) : 3;
     }();
-#define LRAM_SSM_LANE(ILPV, OCCV)                                                                                              \
-  hipLaunchKernelGGL((mamba_ssm_lane_kernel<3, 48, ILPV, OCCV>), grid, block, 0, stream, a.ssm_state, a.xc, a.xz, a.xdb, a.dt_wt, \
+    static const int tr = [] {   // LRAM_MAMBA_SSM_TR (measurement knob): 0 = each lane moves its own 64 contiguous state bytes
+      const char* v = std::getenv("LRAM_MAMBA_SSM_TR");
+      return v ? std::atoi(v) : 1;
+    }();
+#define LRAM_SSM_LANE(ILPV, OCCV, XV)                                                                                          \
+  hipLaunchKernelGGL((mamba_ssm_lane_kernel<3, 48, ILPV, OCCV, XV>), grid, block, 0, stream, a.ssm_state, a.xc, a.xz, a.xdb, a.dt_wt, \
                      a.dt_bias, a.A_log, a.Dp, a.reset, a.y, a.amax, a.B, a.d_inner, epw)
-    if (ilp && occ == 4) LRAM_SSM_LANE(true, 4);
-    else if (ilp) LRAM_SSM_LANE(true, 3);
-    else if (occ == 4) LRAM_SSM_LANE(false, 4);
-    else LRAM_SSM_LANE(false, 3);
+    if (tr) {
+      if (occ == 4) LRAM_SSM_LANE(true, 4, true); else LRAM_SSM_LANE(true, 3, true);
+    } else if (ilp && occ == 4) LRAM_SSM_LANE(true, 4, false);
+    else if (ilp) LRAM_SSM_LANE(true, 3, false);
+    else if (occ == 4) LRAM_SSM_LANE(false, 4, false);
+    else LRAM_SSM_LANE(false, 3, false);
 #undef LRAM_SSM_LANE
     LRAM_HIP_CHECK(hipGetLastError());
     return;
