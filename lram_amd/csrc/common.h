@@ -68,10 +68,13 @@ struct GemmArgs {
   // optional (bf16x3 kernel, no split-K): output columns >= act_silu_from are stored as silu(value); -1 = none
   int act_silu_from = -1;
   // optional (f16x2 kernel): W pre-split into two f16 planes (hi, lo) of the row-scaled weight, `w2_plane` elements apart,
+  // K-TILE-MAJOR: element (n, k) of a plane lives at (k / 32) * w2_kt + n * 32 + k % 32, w2_kt = 32 x the rows of the whole
+  // weight (K padded to a multiple of 32) -- the 128 rows x 32 columns a workgroup stages per K tile are ONE contiguous 8 KB run
+  // instead of 128 pieces of 64 bytes at the row pitch (half cache lines: 1.4 x slower to deliver, scripts/tile_delivery.cpp);
   // with the exact inverse of each weight row's power-of-two scale; a_amax[r] = largest magnitude of A's row r (of the
   // gated row with `gate`), or an upper bound of it, from which the kernel derives the row's power-of-two scale
   const uint16_t* w2 = nullptr;
-  int64_t w2_plane = 0;
+  int64_t w2_plane = 0, w2_kt = 0;
   const float* w_inv = nullptr;
   const float* a_amax = nullptr;
   int amax_parts = 1;  // row r's maximum = max of a_amax[r * amax_parts + 0 .. amax_parts - 1]
@@ -83,10 +86,10 @@ struct GemmArgs {
   float a_amax_scale = 1.f;
   float a_amax_c0 = 0.f, a_amax_c1 = 1.f;  // bound = (c0 + c1 * max of the parts) * mul[r] * scale
   // optional (f16x2 kernel with pre-split operands, gemm_f16x2p.hip): A pre-split by its producer into two f16 planes (hi, lo)
-  // of the row-scaled value, laid out like a (row stride lda), `a2_plane` elements apart, with a2_inv[r] = the exact inverse
-  // of row r's power-of-two scale (`a` may then be null; K a multiple of 32)
+  // of the row-scaled value, K-tile-major like w2 (element (r, k) at (k / 32) * a2_kt + r * 32 + k % 32), `a2_plane` elements
+  // apart, with a2_inv[r] = the exact inverse of row r's power-of-two scale (`a` may then be null; K a multiple of 32)
   const uint16_t* a2 = nullptr;
-  int64_t a2_plane = 0;
+  int64_t a2_plane = 0, a2_kt = 0;
   const float* a2_inv = nullptr;
   // optional split-K workspace (un-batched GEMMs with few output tiles: skinny N or small M): partial [S][M][N]
   // slabs are written by S x tiles workgroups and summed, in fixed order, by a second tiny kernel (deterministic)
@@ -145,13 +148,16 @@ bool gemm_f16x2_supported(const GemmArgs& g);
 void launch_gemm_f16x2(const GemmArgs& g, hipStream_t stream);    // fp32-accurate, 2 x f16 split operands, row-scaled
 bool gemm_f16x2p_supported(const GemmArgs& g);
 void launch_gemm_f16x2p(const GemmArgs& g, hipStream_t stream);   // the same with A pre-split too: DMA staging, MFMA-only loop
-// planes[0 / 1][r][k] (row pitch ldp, `plane` elements apart) = hi / lo of scale_r * a[r][k] (* gate[r][k]), inv[r] = 1 / scale_r
+// planes[0 / 1] (K-tile-major: (r, k) at (k / 32) * kt + r * 32 + k % 32; `plane` elements apart) = hi / lo of
+// scale_r * a[r][k] (* gate[r][k]), inv[r] = 1 / scale_r
 void launch_row_split_f16x2(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, uint16_t* planes,
-                            int64_t ldp, int64_t plane, float* inv, hipStream_t stream);
+                            int64_t kt, int64_t plane, float* inv, hipStream_t stream);
 // amax[r] = max_k |a[r][k] (* gate[r][k])|
 void launch_row_amax(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* amax,
                      hipStream_t stream);
-// planes [2][rows][k] f16 (hi, lo of the row-scaled weight), inv[rows] = 1 / scale
+// planes [2][K tiles][rows][32] f16 (hi, lo of the row-scaled weight, K-tile-major, split_f16x2_plane_elems(rows, k) each),
+// inv[rows] = 1 / scale
+inline size_t split_f16x2_plane_elems(size_t rows, size_t k) { return rows * ((k + 31) / 32 * 32); }
 void launch_split_f16x2(const float* w, int rows, int k, uint16_t* planes, float* inv, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
@@ -171,7 +177,7 @@ void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out
                      uint16_t* planes = nullptr, int64_t plane_stride = 0,   // planes: bf16x3 GEMM operand (row stride
                      float* amax = nullptr, const ScalarTokens* st = nullptr,                                  // out_stride); out may then be null
                      uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr,  // f16x2 operand planes (hi, lo) of the
-                     float* l2 = nullptr);                                                   // row-scaled result + inverse row scales;
+                     float* l2 = nullptr, int64_t h2_kt = 0);                                // row-scaled result (K-tile-major, h2_kt elements per K tile) + inverse row scales;
                                                                                              // l2: optional [rows] Euclidean norm of each output row
 void launch_max_row_l2(const float* w, int rows, int k, float* out, hipStream_t stream);  // out[0] = max_r |w[r, :]|_2
 void launch_max_abs(const float* v, int n, float* out, hipStream_t stream);                // out[0] = max_i |v[i]|
@@ -180,7 +186,8 @@ void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_ou
                          const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes = nullptr,
                          int64_t plane_stride = 0,  // planes: `normed` as a bf16x3 GEMM operand (normed may be null)
                          float* amax = nullptr,     // [rows] largest |normed| per row (f16x2 GEMM's a_amax)
-                         uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr);  // f16x2 operand planes of `normed`
+                         uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr,   // f16x2 operand planes of `normed`
+                         int64_t h2_kt = 0);                                                      // (K-tile-major, h2_kt elements per K tile)
 
 // ---------------------------------------------------------------------------------------------
 // front end / head

@@ -501,7 +501,7 @@ void finalize(lram_engine* e) {
       const size_t rows = rows_of(p, k);
       if (rows == 0) return;
       lram_engine::Split16 sp{nullptr, nullptr, rows, k};
-      LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp.planes), 2 * rows * k * sizeof(uint16_t)));
+      LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp.planes), 2 * split_f16x2_plane_elems(rows, k) * sizeof(uint16_t)));
       LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&sp.inv), rows * sizeof(float)));
       launch_split_f16x2(p, (int)rows, (int)k, sp.planes, sp.inv, nullptr);
       e->split16[p] = sp;
@@ -852,8 +852,9 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
     LRAM_REQUIRE(it != e->split16.begin() && (--it, g.w < it->first + it->second.rows * it->second.k) && (int)it->second.k == g.ldw,
                  "gemm: pre-split A operand for a weight without f16x2 planes");
     const size_t row0 = (size_t)(g.w - it->first) / it->second.k;
-    g.w2 = it->second.planes + (g.w - it->first);
-    g.w2_plane = (int64_t)(it->second.rows * it->second.k);
+    LRAM_REQUIRE(row0 * it->second.k == (size_t)(g.w - it->first), "gemm: a weight's f16x2 planes are addressed by whole rows");
+    g.w2 = it->second.planes + row0 * 32;  // K-tile-major planes
+    g.w2_plane = (int64_t)split_f16x2_plane_elems(it->second.rows, it->second.k), g.w2_kt = (int64_t)it->second.rows * 32;
     g.w_inv = it->second.inv + row0;
     launch_gemm_f16x2p(g, s);
     count_gemm(e, 0, g);
@@ -865,10 +866,10 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
     auto it = e->split16.upper_bound(g.w);
     if (it != e->split16.begin() && (--it, g.w < it->first + it->second.rows * it->second.k) && (int)it->second.k == g.ldw) {
       const size_t row0 = (size_t)(g.w - it->first) / it->second.k;  // a GEMM may address a row range of a weight
-      g.w2 = it->second.planes + (g.w - it->first);
-      g.w2_plane = (int64_t)(it->second.rows * it->second.k);
+      g.w2 = it->second.planes + row0 * 32;                          // (K-tile-major planes)
+      g.w2_plane = (int64_t)split_f16x2_plane_elems(it->second.rows, it->second.k), g.w2_kt = (int64_t)it->second.rows * 32;
       g.w_inv = it->second.inv + row0;
-      if (gemm_f16x2_supported(g)) {
+      if (row0 * it->second.k == (size_t)(g.w - it->first) && gemm_f16x2_supported(g)) {
         if (g.a_amax == nullptr) {  // no producer handed the row maxima over: one small launch ahead of the GEMM
           int slot = 0;
           for (size_t i = 0; i < e->micro_streams.size() && i + 1 < (size_t)lram_engine::kSplitKSlots; ++i)
@@ -881,7 +882,7 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
         count_gemm(e, 0, g);
         return;
       }
-      g.w2 = nullptr, g.w_inv = nullptr;
+      g.w2 = nullptr, g.w_inv = nullptr, g.w2_kt = 0;
     }
   }
   // few operand rows (more than the GEMV's 8, at most gemm_skinny_rows): one 32 x 32 fp32 matrix-core tile per workgroup, operands
@@ -1100,13 +1101,14 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     // f16x2 with both operands pre-split: the norm writes the two operand planes (into XN's memory: 2 x 2 bytes per
     // element) and the rows' inverse scales (into AMX_XN) instead of fp32 + row maxima; both halves of proj_up read them
     const bool ps = !a3 && presplit_for(e, w.proj_up, rows, inner, D);
-    uint16_t* xn2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * D;
+    uint16_t* xn2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * 32;  // K-tile-major planes: [D / 32][B * T][32]
+    const int64_t xn2_kt = ps ? (int64_t)(e->XN2.n / D) * 32 : 0;
     launch_row_norm(e->X.p + r0 * D, D, (a3 || ps) ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
                     c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, ps ? nullptr : amx,
                     nullptr, ps ? xn2 : nullptr, (int64_t)e->XN2.n, ps ? amx : nullptr,
-                    amax_bound_now(e, T, sl.nb) ? e->XN_L2.p + r0 : nullptr);
+                    amax_bound_now(e, T, sl.nb) ? e->XN_L2.p + r0 : nullptr, xn2_kt);
     up.a_amax = amx;
-    if (ps) up.a = nullptr, up.a_amax = nullptr, up.a2 = xn2, up.a2_plane = (int64_t)e->XN2.n, up.a2_inv = amx;
+    if (ps) up.a = nullptr, up.a_amax = nullptr, up.a2 = xn2, up.a2_plane = (int64_t)e->XN2.n, up.a2_kt = xn2_kt, up.a2_inv = amx;
     if (a3) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
     gemm(e, up, sl.s);
   }
@@ -1155,7 +1157,8 @@ void mlstm_up_z(lram_engine* e, int i, int T, const Slice& sl) {
     up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
   } else if (presplit_for(e, e->bw[i].proj_up, rows, inner, D)) {  // (same decision as mlstm_front: XN holds operand planes)
     up.a = nullptr, up.a_amax = nullptr;
-    up.a2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * D, up.a2_plane = (int64_t)e->XN2.n, up.a2_inv = e->AMX_XN.p + r0;
+    up.a2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * 32, up.a2_plane = (int64_t)e->XN2.n, up.a2_kt = (int64_t)(e->XN2.n / D) * 32;
+    up.a2_inv = e->AMX_XN.p + r0;
   }
   if (gn_fused(e, T)) up.act_silu_from = 0;
   gemm(e, up, sl.s);
@@ -1199,11 +1202,12 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
     } else if (e->G2.p != nullptr && presplit_for(e, w.proj_down, rows, D, inner)) {
       // the gated operand split ONCE per row (H * silu(z) -> two f16 planes + inverse row scales: one row kernel in place of
       // the row-maximum launch) instead of in every workgroup of every N tile while it is staged
-      uint16_t* g2 = reinterpret_cast<uint16_t*>(e->G2.p) + r0 * inner;
+      uint16_t* g2 = reinterpret_cast<uint16_t*>(e->G2.p) + r0 * 32;  // K-tile-major planes
+      const int64_t g2_kt = (int64_t)(e->G2.n / inner) * 32;
       float* inv = e->AMX_H.p + r0;
-      launch_row_split_f16x2(e->H.p + r0 * e->icols, inner, e->U.p + r0 * e->ucols + inner, 2 * inner, rows, inner, g2, inner,
+      launch_row_split_f16x2(e->H.p + r0 * e->icols, inner, e->U.p + r0 * e->ucols + inner, 2 * inner, rows, inner, g2, g2_kt,
                              (int64_t)e->G2.n, inv, sl.s);
-      dn.a = nullptr, dn.a2 = g2, dn.a2_plane = (int64_t)e->G2.n, dn.a2_inv = inv;
+      dn.a = nullptr, dn.a2 = g2, dn.a2_plane = (int64_t)e->G2.n, dn.a2_kt = g2_kt, dn.a2_inv = inv;
     } else {
       dn.gate = e->U.p + r0 * e->ucols + inner, dn.ldg = 2 * inner;
       if (amax_bound_now(e, T, sl.nb)) {  // an upper bound of the gated rows' maxima, assembled by the GEMM's prologue
@@ -1559,11 +1563,12 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   float* amx_h = amx ? e->AMX_H.p + r0 * parts : nullptr;
   // in_proj with both operands pre-split: the norm writes XN as two f16 planes + inverse row scales (see mlstm_front)
   const bool ps_in = !a3_in && amx && presplit_for(e, w.in_proj, rows, 2 * di, D);
-  uint16_t* xn2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * D;
+  uint16_t* xn2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * 32;  // K-tile-major planes: [D / 32][B * T][32]
+  const int64_t xn2_kt = ps_in ? (int64_t)(e->XN2.n / D) * 32 : 0;
   if (stage == 0) {
     launch_add_rms_norm(X, RES_in, RES_out, (a3_in || ps_in) ? nullptr : XN, w.norm_g, rows, D, c.norm_eps, sl.s,
                         a3_in ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, ps_in ? nullptr : amx_xn,
-                        ps_in ? xn2 : nullptr, (int64_t)e->XN2.n, ps_in ? amx_xn : nullptr);
+                        ps_in ? xn2 : nullptr, (int64_t)e->XN2.n, ps_in ? amx_xn : nullptr, xn2_kt);
   } else if (stage == 1) {
     MambaConvArgs ca;
     ca.xz = U, ca.conv_state = st.conv.p + b0 * di * c.d_conv, ca.conv_w = w.conv_w, ca.conv_b = w.conv_b, ca.xc = XA;
@@ -1584,7 +1589,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     GemmArgs in;
     in.a = XN, in.lda = D, in.w = w.in_proj, in.ldw = D, in.c = U, in.ldc = 2 * di, in.bias = w.in_proj_b;
     in.m = rows, in.n = 2 * di, in.k = D, in.a_amax = amx_xn;
-    if (ps_in) in.a = nullptr, in.a_amax = nullptr, in.a2 = xn2, in.a2_plane = (int64_t)e->XN2.n, in.a2_inv = amx_xn;
+    if (ps_in) in.a = nullptr, in.a_amax = nullptr, in.a2 = xn2, in.a2_plane = (int64_t)e->XN2.n, in.a2_kt = xn2_kt, in.a2_inv = amx_xn;
     if (a3_in) in.a3 = e->XN3 + r0 * D, in.a3_plane = (int64_t)e->xn3_plane;
     gemm(e, in, gs);
   } else if (stage == 1) {
@@ -2279,7 +2284,7 @@ int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int
   return guarded([&] {
     LRAM_REQUIRE(ldw == k, "lram_gemm_f16x2: W must be contiguous [n, k]");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t numel = (size_t)n * k;
+    const size_t numel = split_f16x2_plane_elems((size_t)n, (size_t)k);  // (K-tile-major planes)
     uint16_t* planes = nullptr;
     float* scales = nullptr;  // [n] inverse weight scales, then [m] activation scales
     LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&planes), 2 * numel * sizeof(uint16_t)));
@@ -2290,7 +2295,7 @@ int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int
       GemmArgs g;
       g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
       g.residual = accumulate ? dev_c : nullptr;
-      g.m = m, g.n = n, g.k = k, g.w2 = planes, g.w2_plane = (int64_t)numel, g.w_inv = scales, g.a_amax = scales + n;
+      g.m = m, g.n = n, g.k = k, g.w2 = planes, g.w2_plane = (int64_t)numel, g.w2_kt = 32 * (int64_t)n, g.w_inv = scales, g.a_amax = scales + n;
       // test hook: the row maxima handed over as an upper bound that is `slack` times too large (the engine's producers may
       // hand over bounds instead of maxima: GemmArgs::a_amax_mul / a_amax_scale)
       if (const char* v = std::getenv("LRAM_TEST_AMAX_SLACK")) g.a_amax_scale = std::max(1.f, (float)std::atof(v));
@@ -2320,12 +2325,12 @@ int32_t lram_gemm_f16x2_presplit(const float* dev_a, int64_t lda, const float* d
     LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scales), ((size_t)n + m) * sizeof(float)));
     try {
       launch_split_f16x2(dev_w, n, k, wp, scales, s);
-      launch_row_split_f16x2(dev_a, lda, nullptr, 0, m, k, ap, k, (int64_t)an, scales + n, s);
+      launch_row_split_f16x2(dev_a, lda, nullptr, 0, m, k, ap, 32 * (int64_t)m, (int64_t)an, scales + n, s);
       GemmArgs g;
       g.lda = k, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
       g.residual = accumulate ? dev_c : nullptr;
-      g.m = m, g.n = n, g.k = k, g.w2 = wp, g.w2_plane = (int64_t)wn, g.w_inv = scales;
-      g.a2 = ap, g.a2_plane = (int64_t)an, g.a2_inv = scales + n;
+      g.m = m, g.n = n, g.k = k, g.w2 = wp, g.w2_plane = (int64_t)wn, g.w2_kt = 32 * (int64_t)n, g.w_inv = scales;
+      g.a2 = ap, g.a2_plane = (int64_t)an, g.a2_kt = 32 * (int64_t)m, g.a2_inv = scales + n;
       launch_gemm_f16x2p(g, s);
       LRAM_HIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {

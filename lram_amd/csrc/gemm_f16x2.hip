@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
     wkc[j] = (rem & 3) << 3;
     const int gn = n0 + r;
     wok[j] = gn < g.n;
-    wrow[j] = W2 + (int64_t)plane * g.w2_plane + (int64_t)(wok[j] ? gn : g.n - 1) * g.ldw + wkc[j];
+    wrow[j] = W2 + (int64_t)plane * g.w2_plane + (int64_t)(wok[j] ? gn : g.n - 1) * 32 + wkc[j];  // (K-tile-major planes)
   }
   // Loads are unconditional (clamped addresses, never a branch around a load: hipcc would otherwise wait for ALL
   // outstanding loads at the next use and the second register set would buy nothing); what lies outside the problem is
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool kin = !k_tail || k0 + wkc[j] < g.k;
-      rw[set][j] = *reinterpret_cast<const uint4*>(wrow[j] + (kin ? k0 : 0));
+      rw[set][j] = *reinterpret_cast<const uint4*>(wrow[j] + (kin ? (int64_t)(k0 >> 5) * g.w2_kt : 0));
     }
   };
   auto store_tile = [&](int set, int k0, int buf = 0) {
@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void row_amax_kernel(const float* a, int64_t l
   if (lane == 0) amax[row] = mx;
 }
 
-// One wave per weight row: planes[0][n][k] = hi, planes[1][n][k] = lo of scale * w[n][k]; inv[n] = 1 / scale.
+// One wave per weight row: planes[0] = hi, planes[1] = lo of scale * w[n][k], K-tile-major ((n, k) at ((k / 32) * rows + n) * 32
+// + k % 32; the columns of a last partial K tile beyond K are never used: the GEMM masks them); inv[n] = 1 / scale.
 __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* w, int rows, int k, _Float16* planes, int64_t plane,
                                                           float* inv) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -359,16 +360,17 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* w, int ro
   for (int c = lane; c < k; c += 64) {
     const float v = wr[c] * s;
     const _Float16 h = (_Float16)v;
-    planes[(int64_t)row * k + c] = h;
-    planes[plane + (int64_t)row * k + c] = (_Float16)(v - (float)h);
+    const int64_t at = ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31);
+    planes[at] = h;
+    planes[plane + at] = (_Float16)(v - (float)h);
   }
   if (lane == 0) inv[row] = 1.f / s;
 }
 }  // namespace
 
 bool gemm_f16x2_supported(const GemmArgs& g) {
-  return g.w2 != nullptr && g.w_inv != nullptr && g.nb1 * g.nb2 == 1 && (g.k & 7) == 0 && (g.ldw & 7) == 0 &&
-         (g.lda & 3) == 0 && (g.w2_plane & 7) == 0 && g.a3 == nullptr && (g.gate == nullptr || (g.ldg & 3) == 0);
+  return g.w2 != nullptr && g.w_inv != nullptr && g.nb1 * g.nb2 == 1 && (g.k & 7) == 0 && g.w2_kt >= 32 * (int64_t)g.n &&
+         (g.w2_kt & 7) == 0 && (g.lda & 3) == 0 && (g.w2_plane & 7) == 0 && g.a3 == nullptr && (g.gate == nullptr || (g.ldg & 3) == 0);
 }
 
 void launch_row_amax(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* amax,
@@ -380,7 +382,7 @@ void launch_row_amax(const float* a, int64_t lda, const float* gate, int64_t ldg
 
 void launch_split_f16x2(const float* w, int rows, int k, uint16_t* planes, float* inv, hipStream_t stream) {
   hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, w, rows, k,
-                     reinterpret_cast<_Float16*>(planes), (int64_t)rows * k, inv);
+                     reinterpret_cast<_Float16*>(planes), (int64_t)split_f16x2_plane_elems(rows, k), inv);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

@@ -72,16 +72,17 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
     if (is_a) {
       const int gm = min(m0 + row, g.m - 1);
-      src[i] = A2 + (int64_t)plane * g.a2_plane + (int64_t)gm * g.lda + 8 * chunk;
+      src[i] = A2 + (int64_t)plane * g.a2_plane + (int64_t)gm * 32 + 8 * chunk;
     } else {
       const int gn = min(n0 + row, g.n - 1);
-      src[i] = W2 + (int64_t)plane * g.w2_plane + (int64_t)gn * g.ldw + 8 * chunk;
+      src[i] = W2 + (int64_t)plane * g.w2_plane + (int64_t)gn * 32 + 8 * chunk;
     }
   }
-  auto dma_tile = [&](int stage, int k0) {
+  auto dma_tile = [&](int stage, int kt) {  // (K-tile-major planes: the tile's rows of a plane are one contiguous run)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int p = wave + 4 * i;
+      const int64_t k0 = (int64_t)kt * (4 * i < NPA ? g.a2_kt : g.w2_kt);  // (pieces 4 i .. 4 i + 3 belong to one operand)
       // (LDS destination: wave-uniform base of the piece -- pieces lie in the stage in piece order: A hi, A lo, W hi, W lo;
       // the hardware adds lane * 16)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
@@ -136,16 +137,16 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
     // tile kt sits in stage kt & 1 once the barrier at the top of its iteration is passed (__syncthreads drains the issuing
     // waves' DMAs: an LDS-DMA is a pending LDS write on the VM counter); the DMA of tile kt + 1 is issued right behind that
     // barrier -- every wave has then finished reading that stage (tile kt - 1) -- and is in flight under tile kt's MFMAs
-    dma_tile(0, kt0 * BK);
+    dma_tile(0, kt0);
     for (int kt = kt0; kt < nk; ++kt) {
       const int cur = (kt - kt0) & 1;
       __syncthreads();
-      if (kt + 1 < nk) dma_tile(cur ^ 1, (kt + 1) * BK);
+      if (kt + 1 < nk) dma_tile(cur ^ 1, kt + 1);
       mfma_tile(cur);
     }
   } else {
     for (int kt = kt0; kt < nk; ++kt) {
-      dma_tile(0, kt * BK);
+      dma_tile(0, kt);
       __syncthreads();
       mfma_tile(0);
       __syncthreads();
@@ -189,11 +190,12 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
   }
 }
 
-// One wave per row (K <= 3072): planes[0][r][k] = hi, planes[1][r][k] = lo of scale * a[r][k] (* gate[r][k]);
-// inv[r] = 1 / scale (exact power of two).  The stand-alone form of what the norm kernels do in their epilogue.
+// One wave per row (K <= 3072): planes[0] = hi, planes[1] = lo of scale * a[r][k] (* gate[r][k]), K-tile-major ((r, k) at
+// (k / 32) * kt + r * 32 + k % 32); inv[r] = 1 / scale (exact power of two).  The stand-alone form of what the norm kernels
+// do in their epilogue.
 constexpr int kSplitMaxV = 12;
 __global__ __launch_bounds__(256) void row_split_f16x2_kernel(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows,
-                                                              int k, _Float16* planes, int64_t ldp, int64_t plane, float* inv) {
+                                                              int k, _Float16* planes, int64_t kt, int64_t plane, float* inv) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const int nv = k >> 2;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void row_split_f16x2_kernel(const float* a, in
 #pragma unroll
   for (int j = 0; j < kSplitMaxV; ++j) {
     const int i = lane + 64 * j;
-    if (i < nv) split2_store4(v[j], s, planes + (int64_t)row * ldp + 4 * i, plane);
+    if (i < nv) split2_store4(v[j], s, planes + (int64_t)(i >> 3) * kt + (int64_t)row * 32 + 4 * (i & 7), plane);
   }
   if (lane == 0) inv[row] = 1.f / s;
 }
@@ -223,17 +225,18 @@ __global__ __launch_bounds__(256) void row_split_f16x2_kernel(const float* a, in
 
 bool gemm_f16x2p_supported(const GemmArgs& g) {
   return g.a2 != nullptr && g.a2_inv != nullptr && g.w2 != nullptr && g.w_inv != nullptr && g.nb1 * g.nb2 == 1 &&
-         (g.k % BK) == 0 && (g.ldw & 7) == 0 && (g.lda & 7) == 0 && (g.w2_plane & 7) == 0 && (g.a2_plane & 7) == 0 &&
+         (g.k % BK) == 0 && g.w2_kt >= 32 * (int64_t)g.n && g.a2_kt >= 32 * (int64_t)g.m && (g.w2_plane & 7) == 0 && (g.a2_plane & 7) == 0 &&
+         (g.w2_kt & 7) == 0 && (g.a2_kt & 7) == 0 &&
          g.gate == nullptr && g.a3 == nullptr && (reinterpret_cast<uintptr_t>(g.a2) & 15) == 0 &&
          (reinterpret_cast<uintptr_t>(g.w2) & 15) == 0;
 }
 
 void launch_row_split_f16x2(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, uint16_t* planes,
-                            int64_t ldp, int64_t plane, float* inv, hipStream_t stream) {
-  LRAM_REQUIRE((k & 3) == 0 && k <= 4 * 64 * kSplitMaxV && (lda & 3) == 0 && (ldp & 3) == 0 && (gate == nullptr || (ldg & 3) == 0),
-               "row split: K must be a multiple of 4, <= 3072; row pitches multiples of 4");
+                            int64_t kt, int64_t plane, float* inv, hipStream_t stream) {
+  LRAM_REQUIRE((k & 3) == 0 && k <= 4 * 64 * kSplitMaxV && (lda & 3) == 0 && kt >= 32 * (int64_t)rows && (gate == nullptr || (ldg & 3) == 0),
+               "row split: K must be a multiple of 4, <= 3072; row pitches multiples of 4; K-tile pitch >= 32 x rows");
   hipLaunchKernelGGL(row_split_f16x2_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a, lda, gate, ldg, rows, k,
-                     reinterpret_cast<_Float16*>(planes), ldp, plane, inv);
+                     reinterpret_cast<_Float16*>(planes), kt, plane, inv);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

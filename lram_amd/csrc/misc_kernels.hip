@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
                                                        int64_t out_stride, const float* gamma, const float* beta,
                                                        int rows, int d, float eps, int rms, float* out2,
                                                        uint16_t* planes, int64_t plane_stride, float* amax,
-                                                       ScalarTokens st, _Float16* h2, int64_t h2_plane, float* h2_inv, float* l2) {
+                                                       ScalarTokens st, _Float16* h2, int64_t h2_plane, float* h2_inv, float* l2, int64_t h2_kt) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
 #pragma unroll
     for (int j = 0; j < kNormMaxV; ++j) {
       const int i = lane + 64 * j;
-      if (i < nv) split2_store4(v[j], sc, h2 + (int64_t)row * out_stride + 4 * i, h2_plane);
+      if (i < nv) split2_store4(v[j], sc, h2 + (int64_t)(i >> 3) * h2_kt + (int64_t)row * 32 + 4 * (i & 7), h2_plane);
     }
     if (lane == 0) h2_inv[row] = 1.f / sc;
   }
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
 __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, const float* res_in, float* res_out,
                                                            float* normed, const float* gamma, int rows, int d,
                                                            float eps, uint16_t* planes, int64_t plane_stride,
-                                                           float* amax, _Float16* h2, int64_t h2_plane, float* h2_inv) {
+                                                           float* amax, _Float16* h2, int64_t h2_plane, float* h2_inv, int64_t h2_kt) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, 
 #pragma unroll
     for (int j = 0; j < kNormMaxV; ++j) {
       const int i = lane + 64 * j;
-      if (i < nv) split2_store4(v[j], sc, h2 + base + 4 * i, h2_plane);
+      if (i < nv) split2_store4(v[j], sc, h2 + (int64_t)(i >> 3) * h2_kt + (int64_t)row * 32 + 4 * (i & 7), h2_plane);
     }
     if (lane == 0) h2_inv[row] = 1.f / sc;
   }
@@ -369,22 +369,22 @@ void launch_max_row_l2(const float* w, int rows, int k, float* out, hipStream_t 
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2,
                      uint16_t* planes, int64_t plane_stride, float* amax, const ScalarTokens* st, uint16_t* h2, int64_t h2_plane,
-                     float* h2_inv, float* l2) {
+                     float* h2_inv, float* l2, int64_t h2_kt) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "row norm: d must be a multiple of 4 and <= 2048");
-  LRAM_REQUIRE(h2 == nullptr || h2_inv != nullptr, "row norm: f16x2 operand planes need the inverse-scale output");
+  LRAM_REQUIRE(h2 == nullptr || (h2_inv != nullptr && h2_kt >= 32 * (int64_t)rows), "row norm: f16x2 operand planes need the inverse-scale output and the K-tile pitch");
   hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, in_stride, out, out_stride,
                      gamma, beta, rows, d, eps, rms, out2, planes, plane_stride, amax, st ? *st : ScalarTokens(),
-                     reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv, l2);
+                     reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv, l2, h2_kt);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
                          const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes,
-                         int64_t plane_stride, float* amax, uint16_t* h2, int64_t h2_plane, float* h2_inv) {
+                         int64_t plane_stride, float* amax, uint16_t* h2, int64_t h2_plane, float* h2_inv, int64_t h2_kt) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "rms norm: d must be a multiple of 4 and <= 2048");
-  LRAM_REQUIRE(h2 == nullptr || h2_inv != nullptr, "rms norm: f16x2 operand planes need the inverse-scale output");
+  LRAM_REQUIRE(h2 == nullptr || (h2_inv != nullptr && h2_kt >= 32 * (int64_t)rows), "rms norm: f16x2 operand planes need the inverse-scale output and the K-tile pitch");
   hipLaunchKernelGGL(add_rms_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, hidden, res_in, res_out,
-                     normed, gamma, rows, d, eps, planes, plane_stride, amax, reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv);
+                     normed, gamma, rows, d, eps, planes, plane_stride, amax, reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv, h2_kt);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
