@@ -358,6 +358,18 @@ def test_mamba_48m_shapes(hip_lib):
     assert _run_parity("mamba_48m", B=6, steps=4) == 0
 
 
+@pytest.mark.parametrize("B", [77, 130])
+def test_mamba_lane_state_update_at_ragged_env_counts(hip_lib, B):
+    """From 64 env slots Mamba-48M's selective state update runs lane = channel (mamba_ssm_lane_kernel: 8 env slots per wave,
+    the 4 KB state block of a wave moved coalesced and transposed through LDS, softplus / SiLU / decay on the hardware
+    transcendentals).  Env counts that are not multiples of 8 leave a short last wave, make_inputs' resets take the wave-uniform
+    zero-state branch; hidden states, actions and every layer's conv / ssm state against the oracle at the usual bars."""
+    from lram_amd.config import ModelSpec
+    spec = ModelSpec(backbone="mamba", kind="MDDMamba", d_model=768, n_blocks=3)  # Mamba-48M's widths (d_inner 1536, dt_rank 48)
+    assert spec.d_inner == 1536 and spec.dt_rank in (0, 48)
+    assert _run_parity(f"mamba_768_b{B}", B=B, steps=5, spec=spec) == 0
+
+
 @pytest.mark.parametrize("name,B", [("mamba_48m", 6), ("mamba_tiny", 7)])
 def test_mamba_dt_proj_as_its_own_gemm_stays_correct(hip_lib, monkeypatch, name, B):
     """Default: dt_proj (K = dt_rank) is evaluated inside the selective-state-update kernel (d_state 16, dt_rank <= 64; every
