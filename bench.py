@@ -547,7 +547,8 @@ def main(argv=None, engine_factory=None, device=None):
     # HBM bytes per launch come from a separate rocprofv3 --pmc pass (scripts/pmc_pass.sh -> profiles/): a constant
     # read from a committed file, labelled as such
     for rnd in ("r04", "r03", "r02", "r01"):
-        pmc_file = os.path.join(ROOT, "profiles", "%s_cell_kernel_hbm_traffic%s.json" % (rnd, "_lazy" if lazy else ""))
+        tag = "" if args.config == "xlstm_16m" else "_" + args.config   # (scripts/parse_pmc.py names the other configs' files)
+        pmc_file = os.path.join(ROOT, "profiles", "%s_cell_kernel_hbm_traffic%s%s.json" % (rnd, tag, "_lazy" if lazy else ""))
         if not os.path.exists(pmc_file):
             continue
         try:
