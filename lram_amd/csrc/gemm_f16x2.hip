@@ -464,7 +464,11 @@ void launch_gemm_f16x2(const GemmArgs& g_in, hipStream_t stream) {
     const char* v = std::getenv("LRAM_GEMM_BM64_BELOW");
     return v ? std::atoi(v) : 256;
   }();
-  const bool small = force_bm == 64 || (force_bm == 0 && g.m > 64 && ((S == 1 && tiles128 < 768 && tiles_n <= 6) || ((long)tiles128 * S < bm64_below && g.k <= 768)));
+  static const int bm64_anyk = [] {   // LRAM_GEMM_BM64_ANYK: below this many tiles 64-row tiles whatever K (under half a workgroup per CU)
+    const char* v = std::getenv("LRAM_GEMM_BM64_ANYK");
+    return v ? std::atoi(v) : 128;
+  }();
+  const bool small = force_bm == 64 || (force_bm == 0 && g.m > 64 && ((S == 1 && tiles128 < 768 && tiles_n <= 6) || ((long)tiles128 * S < bm64_below && g.k <= 768) || (long)tiles128 * S < bm64_anyk));
   const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;
   dim3 grid(tiles, 1, S);
   gemm_choose_xcd_split(g, small ? 64 : 128, BN, 4);

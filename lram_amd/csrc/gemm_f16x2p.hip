@@ -290,8 +290,12 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
     const char* v = std::getenv("LRAM_GEMM_BM64_BELOW");
     return v ? std::atoi(v) : 256;
   }();
+  static const int bm64_anyk = [] {   // LRAM_GEMM_BM64_ANYK: below this many tiles 64-row tiles whatever K (under half a workgroup per CU)
+    const char* v = std::getenv("LRAM_GEMM_BM64_ANYK");
+    return v ? std::atoi(v) : 128;
+  }();
   const int tiles128 = ((g.m + 127) / 128) * ((g.n + BN - 1) / BN);
-  const bool bm64 = force_bm == 64 || (force_bm == 0 && (long)tiles128 * S < bm64_below && g.k <= 768 && g.m > 64);
+  const bool bm64 = force_bm == 64 || (force_bm == 0 && g.m > 64 && (((long)tiles128 * S < bm64_below && g.k <= 768) || (long)tiles128 * S < bm64_anyk));
   const int tiles = bm64 ? ((g.m + 63) / 64) * ((g.n + BN - 1) / BN) : tiles128;
   dim3 grid(tiles, 1, S);
   gemm_choose_xcd_split(g, bm64 ? 64 : 128, BN, 4);
