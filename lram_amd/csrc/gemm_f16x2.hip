@@ -61,6 +61,10 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
   // power-of-two scale of each of the tile's A rows (0 beyond M): lives in the first stage's memory before the first
   // tile is written and again after the last one is read (two stages of the 128-row tile are exactly half the CU's LDS)
   float* srow = reinterpret_cast<float*>(lds);
+  // single-stage instances keep the tile's inverse row scales and inverse column scales in their own 1 KB from the start, so
+  // the epilogue neither asks the memory for them after the last MFMA nor divides (the two-stage instances fill the CU's LDS
+  // with two workgroups exactly and refill `srow` instead)
+  __shared__ float sinv[DB ? 1 : BM + BN];
   _Float16* As = lds;               // [2][BM][PITCH]   hi, lo
   _Float16* Bs = lds + 2 * APLANE;  // [2][128][PITCH]
 
@@ -87,6 +91,9 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
       mx = (g.a_amax_c0 + g.a_amax_c1 * mx) * (g.a_amax_mul != nullptr ? g.a_amax_mul[gm] : 1.f) * g.a_amax_scale;
     }
     srow[tid] = gm < g.m ? pow2_scale(mx) : 0.f;
+    if (!DB) sinv[tid] = gm < g.m ? 1.f / pow2_scale(mx) : 0.f;  // (exact: a power of two)
+  } else if (!DB && tid < BM + BN) {
+    sinv[tid] = g.w_inv[min(n0 + tid - BM, g.n - 1)];
   }
   __syncthreads();
   auto refill_srow = [&]() {  // (after the K loop, behind its last barrier)
@@ -293,7 +300,6 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
     for (int u = 0; u < PF; ++u) half(u, kt + u);
   }
   if (PF > 1 && kt < nk) half(0, kt);  // odd tile count: one half left
-  refill_srow();
   }
 
   // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5));
@@ -305,13 +311,13 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + 64 * wn + 32 * j + li;
       if (col >= g.n) continue;
-      const float wi = g.w_inv[col];
+      const float wi = DB ? g.w_inv[col] : sinv[BM + col - n0];
       const float bv = HAS_BIAS ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + WM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < g.m) {
-          float v = acc[i][j][r] * (wi / srow[row - m0]);
+          float v = DB ? acc[i][j][r] * (wi / srow[row - m0]) : acc[i][j][r] * (wi * sinv[row - m0]);
           if (S != nullptr) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
             S[(int64_t)row * g.n + col] = v;
             continue;

@@ -53,6 +53,19 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
   int tm_idx, tn_idx;
   gemm_tile_of(g, blockIdx.x, tiles_m, tiles_n, tm_idx, tn_idx);  // XCD-aware tile order (common.h)
   const int m0 = tm_idx * BMT, n0 = tn_idx * BN;
+  // the tile's inverse row / column scales, requested before the first K tile and in LDS from its barrier on: the epilogue
+  // used to request them only after the last MFMA -- a memory round trip at the end of every workgroup, and on grids of at
+  // most one round of workgroups nothing overlaps an epilogue (skeleton of this kernel, 6144 x 2048 x 512: K loop 32 us,
+  // + C stores 5, + the scale loads at the end 5; scripts/gemm_skeleton.cpp)
+  // (one-stage instances, 128 VGPRs: through 1 KB of LDS; two-stage instances have 256 VGPRs and take them into registers --
+  // a second LDS object with ordinary stores makes hipcc wait for the in-flight tile DMA before every fragment read, which
+  // serialises the two stages: +16 ... +34 % on the small grids they serve)
+  __shared__ float scl[NSTAGE == 1 ? BMT + BN : 1];
+  if (NSTAGE == 1) {
+    const int t = threadIdx.x;
+    if (t < BMT) scl[t] = g.a2_inv[min(m0 + t, g.m - 1)];
+    else if (t < BMT + BN) scl[t] = g.w_inv[min(n0 + t - BMT, g.n - 1)];
+  }
 
   // ---- DMA sources: 32 pieces of 1 KiB per stage (4 planes x 8 row blocks of 16 rows), 8 per wave.  Wave w takes
   // pieces w, w + 4, ...: piece p = plane (p >> 3), row block (p & 7).  Lane l fills linear position (row = 16 rb + l / 4,
@@ -100,6 +113,16 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
 
   const int li = lane & 31, lh = lane >> 5;
   const int sw = (li >> 2) & 3;  // chunk swizzle of this lane's rows (tile row offsets are multiples of 32)
+  float ainv_r[NSTAGE == 1 ? 1 : TI][NSTAGE == 1 ? 1 : 16], winv_r[2];
+  if (NSTAGE != 1) {
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ainv_r[i][r] = g.a2_inv[min(m0 + (BMT / 2) * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh, g.m - 1)];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) winv_r[j] = g.w_inv[min(n0 + 64 * wn + 32 * j + li, g.n - 1)];
+  }
   const _Float16* a_base = lds + ((BMT / 2) * wm + li) * BK;
   const _Float16* b_base = lds + 2 * APL + (64 * wn + li) * BK;
 
@@ -163,13 +186,13 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + (BMT / 2) * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      ainv[r] = g.a2_inv[min(row, g.m - 1)];
+      ainv[r] = NSTAGE == 1 ? scl[row - m0] : ainv_r[NSTAGE == 1 ? 0 : i][NSTAGE == 1 ? 0 : r];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + 64 * wn + 32 * j + li;
       if (col >= g.n) continue;
-      const float wi = g.w_inv[col];
+      const float wi = NSTAGE == 1 ? scl[BMT + col - n0] : winv_r[j];
       const float bv = HAS_BIAS ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
