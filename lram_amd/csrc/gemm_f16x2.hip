@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
   float* srow = reinterpret_cast<float*>(lds);
   // single-stage instances keep the tile's inverse row scales and inverse column scales in their own 1 KB from the start, so
   // the epilogue neither asks the memory for them after the last MFMA nor divides (the two-stage instances fill the CU's LDS
-  // with two workgroups exactly and refill `srow` instead)
+  // with two workgroups exactly and take them into registers instead)
   __shared__ float sinv[DB ? 1 : BM + BN];
   _Float16* As = lds;               // [2][BM][PITCH]   hi, lo
   _Float16* Bs = lds + 2 * APLANE;  // [2][128][PITCH]
@@ -96,19 +96,6 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
     sinv[tid] = g.w_inv[min(n0 + tid - BM, g.n - 1)];
   }
   __syncthreads();
-  auto refill_srow = [&]() {  // (after the K loop, behind its last barrier)
-    if (tid < BM) {
-      const int gm = m0 + tid;
-      float mx = 0.f;
-      if (gm < g.m) {
-        const float* ap = g.a_amax + (int64_t)gm * g.amax_parts;
-        for (int q = 0; q < g.amax_parts; ++q) mx = fmaxf(mx, ap[q]);
-        mx = (g.a_amax_c0 + g.a_amax_c1 * mx) * (g.a_amax_mul != nullptr ? g.a_amax_mul[gm] : 1.f) * g.a_amax_scale;
-      }
-      srow[tid] = gm < g.m ? pow2_scale(mx) : 0.f;
-    }
-    __syncthreads();
-  };
   const int lr = tid >> 3;        // A: row within a 32-row slab
   const int lc = (tid & 7) << 2;  // A: k offset 0,4,..,28
   constexpr int NA = BM / 32;     // float4 per thread and K tile
@@ -132,6 +119,21 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
     sa[i] = srow[lr + 32 * i];
     arow[i] = A + (int64_t)gmc * g.lda + lc;
     if (GATE) grow[i] = g.gate + (int64_t)gmc * g.ldg + lc;
+  }
+  // two-stage instances (256 VGPRs): the inverse scales of this lane's epilogue rows / columns into registers while `srow` is
+  // still valid -- the epilogue then neither refills it from memory nor divides
+  float sinv_r[DB ? TI : 1][DB ? 16 : 1], winv_r[2];
+  if (DB) {
+    const int li_ = lane & 31, lh_ = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float sr = srow[WM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh_];
+        sinv_r[DB ? i : 0][DB ? r : 0] = sr != 0.f ? 1.f / sr : 0.f;  // (exact: a power of two; 0 marks rows beyond M)
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) winv_r[j] = g.w_inv[min(n0 + 64 * wn + 32 * j + li_, g.n - 1)];
   }
   __syncthreads();  // every thread has its row scales: the tile stages may overwrite srow now
   const _Float16* wrow[4];
@@ -277,7 +279,6 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
       step(1, kt + 1);
     }
     if (kt < nk) step(0, kt);
-    refill_srow();
   } else {
   // The prefetch of a half is unconditional (past the last tile it re-reads the last one; nothing consumes it) and the
   // loop body always runs all PF halves: hipcc's wait counts are then exact -- a load behind a condition makes it
@@ -311,13 +312,13 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + 64 * wn + 32 * j + li;
       if (col >= g.n) continue;
-      const float wi = DB ? g.w_inv[col] : sinv[BM + col - n0];
+      const float wi = DB ? winv_r[j] : sinv[BM + col - n0];
       const float bv = HAS_BIAS ? g.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + WM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < g.m) {
-          float v = DB ? acc[i][j][r] * (wi / srow[row - m0]) : acc[i][j][r] * (wi * sinv[row - m0]);
+          float v = acc[i][j][r] * (wi * (DB ? sinv_r[DB ? i : 0][DB ? r : 0] : sinv[row - m0]));
           if (S != nullptr) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
             S[(int64_t)row * g.n + col] = v;
             continue;
