@@ -101,6 +101,21 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// The wave's sum as a wave-uniform value, on the DPP cross-lane paths (no LDS crossbar round trips): quad permutes and row
+// mirrors leave every lane of a 16-lane row with the row's sum, the two row broadcasts assemble the four rows in row 3, and
+// lane 63 is read back into a scalar register.  Fixed summation order (deterministic).
+__device__ __forceinline__ float wave_sum_bcast(float x) {
+#define LRAM_DPP_ADD(ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+  LRAM_DPP_ADD(0xB1);   // quad_perm [1, 0, 3, 2]
+  LRAM_DPP_ADD(0x4E);   // quad_perm [2, 3, 0, 1]
+  LRAM_DPP_ADD(0x141);  // row_half_mirror
+  LRAM_DPP_ADD(0x140);  // row_mirror
+  LRAM_DPP_ADD(0x142);  // row_bcast15: rows 1, 3 (and 2) take the sum of the row before
+  LRAM_DPP_ADD(0x143);  // row_bcast31: row 3 takes rows 0 + 1
+#undef LRAM_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 // The wave's maximum of NON-NEGATIVE values, in lane 63 only, on the DPP cross-lane paths (two quad permutes, two row mirrors, two
 // row broadcasts) instead of six ds_bpermute round trips through the LDS crossbar: for kernels that take a maximum per (row,
 // channel block) inside their inner loop.  Non-negative floats order like their bit patterns, so the maximum is taken on unsigned

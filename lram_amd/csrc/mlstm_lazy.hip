@@ -424,8 +424,16 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
 // saved keep the kernel at 144 VGPRs -- three of its waves then leave room for a projection GEMM's wave on the SIMD).
 // SF: the window scores are reduced BEFORE the pass over C_base (the khat registers are dead while it runs and hold
 // its rows in flight instead) rather than after it.
-template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false, bool EARLY = false>
+// W4 (KPL == 4, LPR == 64, scores first): the window's khat AND v rows are fetched as one float4 per lane and row -- wave w keeps
+// rows w, w + 4, ... of both, lane l their columns 4 l .. 4 l + 3 -- instead of one float per lane and (row, 64-column group) for
+// khat and one float per thread and row for v: 19 wide requests per lane in place of 76 narrow ones.  The memory pipeline
+// handles a wave's request in the same time whether its lanes ask for 4 or for 16 bytes, and the narrow form cost the pass as
+// much request time as the whole stream over C_base (64 wide requests per lane): with the stream switched off the pass took 0.32
+// of its 0.92 ms.  A wave reduces its rows' scores itself (DPP adds, broadcast by readlane), multiplies them onto its v rows
+// right away and hands the sums to the row-group reduction of the pass (red = G y_partial + window partial).
+template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false, bool EARLY = false, bool W4 = false>
 __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
+  static_assert(!W4 || (KPL == 4 && LPR == 64 && SF && !EARLY), "W4: 256-wide heads, scores first");
   constexpr int kRowsPerWave = (WP + T + 3) / 4;
   constexpr int CW = 4 * LPR;
   constexpr int RP = 256 / LPR;
@@ -517,14 +525,26 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   }
   // window V column of this thread (threads >= CW idle here): in flight during the pass over C_base
   const float* wvb = a.wv + (base * DH) + slice * CW + (tid < CW ? tid : 0);
-  float vw[WP];
+  float vw[W4 ? 1 : WP];
+  if (!W4) {
 #pragma unroll
-  for (int j = 0; j < WP; ++j) vw[j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
+    for (int j = 0; j < WP; ++j) vw[W4 ? 0 : j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
+  }
   // window khat rows of this wave (rows wave, wave + 4, ...), KPL values per lane and row
   const float* wkb = a.wk + base * DH;
-  float kreg[KPL > 0 ? kRowsPerWave : 1][KPL > 0 ? KPL : 1];
+  float kreg[(KPL > 0 && !W4) ? kRowsPerWave : 1][(KPL > 0 && !W4) ? KPL : 1];
   (void)kreg;
-  if (KPL > 0) {
+  v4f k4[W4 ? kRowsPerWave : 1], v4w[W4 ? kRowsPerWave : 1];
+  (void)k4, (void)v4w;
+  if (W4) {
+    const float* wvr = a.wv + base * DH;
+#pragma unroll
+    for (int i = 0; i < kRowsPerWave; ++i) {
+      const int j = wave + 4 * i;
+      k4[W4 ? i : 0] = j < n ? *reinterpret_cast<const v4f*>(wkb + (int64_t)j * DH + 4 * lane) : (v4f)(0.f);
+      v4w[W4 ? i : 0] = (j < n && j < WP) ? *reinterpret_cast<const v4f*>(wvr + (int64_t)j * DH + 4 * lane) : (v4f)(0.f);
+    }
+  } else if (KPL > 0) {
 #pragma unroll
     for (int i = 0; i < kRowsPerWave; ++i) {
       const int j = wave + 4 * i;
@@ -567,8 +587,43 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
     }
     return c;
   };
+  v4f accw[W4 ? T : 1];  // W4: this wave's rows of sum_j p[t][j] v_j, columns 4 lane .. 4 lane + 3
+#pragma unroll
+  for (int t = 0; t < (W4 ? T : 1); ++t) accw[t] = (v4f)(0.f);
   auto window_scores = [&]() {
   if (KPL < 0) {
+  } else if (W4) {
+#pragma unroll
+    for (int i = 0; i < kRowsPerWave; ++i) {
+      const int j = wave + 4 * i;
+      if (j < n + T) {  // (uniform over the wave)
+        const v4f kv = j < n ? k4[W4 ? i : 0] : *reinterpret_cast<const v4f*>(ks + (j - n) * DH + 4 * lane);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const v4f q4 = *reinterpret_cast<const v4f*>(qs + t * DH + 4 * lane);
+          const float sc = coefficient(j, t) * wave_sum_bcast(q4.x * kv.x + q4.y * kv.y + q4.z * kv.z + q4.w * kv.w);
+          if (lane == 0) pw[t * WT + j] = sc;
+          if (j < n && j < WP) accw[W4 ? t : 0] += sc * v4w[W4 ? i : 0];
+        }
+      }
+    }
+    if (WP < W) {  // rows beyond the register prefetch (only when more than WP tokens are pending)
+      for (int j = wave + 4 * kRowsPerWave; j < n + T; j += 4) {
+        float p[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) p[t] = 0.f;
+        for (int r = lane; r < DH; r += 64) {
+          const float kv = j < n ? wkb[(int64_t)j * DH + r] : ks[(j - n) * DH + r];
+#pragma unroll
+          for (int t = 0; t < T; ++t) p[t] += qs[t * DH + r] * kv;
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float sm = wave_sum(p[t]);
+          if (lane == 0) pw[t * WT + j] = coefficient(j, t) * sm;
+        }
+      }
+    }
   } else if (KPL > 0) {
 #pragma unroll
     for (int i = 0; i < kRowsPerWave; ++i) {
@@ -688,7 +743,8 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
     }
   }
 #pragma unroll
-  for (int t = 0; t < T; ++t) *reinterpret_cast<v4f*>(red + ((rg * T + t) * CW) + 4 * cl) = acc[t];
+  for (int t = 0; t < T; ++t)
+    *reinterpret_cast<v4f*>(red + ((rg * T + t) * CW) + 4 * cl) = W4 ? G[t] * acc[t] + accw[W4 ? t : 0] : acc[t];
 
   if (!SF) window_scores();
   __syncthreads();
@@ -704,17 +760,20 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       float y = 0.f;
 #pragma unroll
       for (int g = 0; g < RP; ++g) y += red[(g * T + t) * CW + c];
+      float yf = 0.f;
       if (from_fold) {
         const int nrs = DH / kFR;
         const float* yi = a.ypart + ((((int64_t)b * NH + h) * nrs) * T + t) * DH + slice * CW + c;
-        for (int g = 0; g < nrs; ++g) y += yi[(int64_t)g * T * DH];
+        for (int g = 0; g < nrs; ++g) yf += yi[(int64_t)g * T * DH];
       }
-      hn[t] = G[t] * y;
+      hn[t] = W4 ? y + G[t] * yf : G[t] * (y + yf);  // (W4: the row groups' sums hold G y + the window rows' part already)
     }
+    if (!W4) {
 #pragma unroll
-    for (int j = 0; j < WP; ++j) {
+      for (int j = 0; j < WP; ++j) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) hn[t] += pw[t * WT + j] * vw[j];  // vw == 0 beyond the window, pw zero-filled
+        for (int t = 0; t < T; ++t) hn[t] += pw[t * WT + j] * vw[W4 ? 0 : j];  // vw == 0 beyond the window, pw zero-filled
+      }
     }
     if (WP < W) {
       for (int j = WP; j < n; ++j) {
@@ -824,7 +883,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_clear_kernel(int32_t* count, f
   if (gid == b * NH) count[b] = 0;
 }
 
-template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false, bool EARLY = false>
+template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false, bool EARLY = false, bool W4 = false>
 void launch_cell_tluk(const MlstmLazyArgs& a, hipStream_t s) {
   constexpr int CW = 4 * LPR, RP = 256 / LPR;
   dim3 grid(a.DH / CW, a.NH, a.B), block(256);
@@ -837,11 +896,11 @@ void launch_cell_tluk(const MlstmLazyArgs& a, hipStream_t s) {
   if (shmem > 48 * 1024) {
     static uint64_t raised = 0;
     if (first_use_on_device(raised)) {
-      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF, EARLY>),
+      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF, EARLY, W4>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
   }
-  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF, EARLY>), grid, block, shmem, s, a);
+  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF, EARLY, W4>), grid, block, shmem, s, a);
 }
 
 template <int T>
@@ -876,6 +935,11 @@ void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
         return v ? std::atoi(v) : 0;
       }();
       if (unroll == 8 && early) return launch_cell_tluk<T, 64, 8, 4, 36, true, true>(a, s);
+      static const int w4 = [] {   // LRAM_LAZY_W4 (measurement knob): 0 = narrow per-lane requests for the window rows
+        const char* v = std::getenv("LRAM_LAZY_W4");
+        return v ? std::atoi(v) : 1;
+      }();
+      if (unroll == 8 && w4) return launch_cell_tluk<T, 64, 8, 4, 36, true, false, true>(a, s);
       if (unroll == 8) return launch_cell_tluk<T, 64, 8, 4, 36, true>(a, s);
       if (unroll == 4) return launch_cell_tluk<T, 64, 4, 4, 36, true>(a, s);
     }
