@@ -34,11 +34,11 @@ __global__ __launch_bounds__(256) void mamba_conv_kernel(MambaConvArgs a) {
     win.z = win.w;
     win.w = x;
     const float y = win.x * w.x + win.y * w.y + win.z * w.z + win.w * w.w + bias;
-    const float o = silu_f(y);
+    const float o = silu_hw(y);
     a.xc[row * di + d] = o;
     if (a.amax != nullptr) {  // (d_inner is a multiple of 64: the lanes of a wave share the env, hence the row)
-      const float m = wave_max(fabsf(o));
-      if ((threadIdx.x & 63) == 0) a.amax[row * (di >> 6) + (d >> 6)] = m;  // this wave's 64 channels of the row
+      const float m = wave_max_nonneg_lane63(fabsf(o));
+      if ((threadIdx.x & 63) == 63) a.amax[row * (di >> 6) + (d >> 6)] = m;  // this wave's 64 channels of the row
     }
   }
   *reinterpret_cast<float4*>(a.conv_state + gid * 4) = win;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void mamba_conv_rt_kernel(MambaConvArgs a) {
     win.y = win.z;
     win.z = win.w;
     win.w = x;
-    a.xc[row * di + d] = silu_f(win.x * w.x + win.y * w.y + win.z * w.z + win.w * w.w + bias);
+    a.xc[row * di + d] = silu_hw(win.x * w.x + win.y * w.y + win.z * w.z + win.w * w.w + bias);
   }
   *reinterpret_cast<float4*>(a.conv_state + gid * 4) = win;
 }
