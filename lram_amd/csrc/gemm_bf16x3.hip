@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
         if (row < g.m) {
           float v = acc[i][j][r] + bv;
           if (HAS_RES) v += R[(int64_t)row * g.ldc + col];
-          if (g.act_silu_from >= 0 && col >= g.act_silu_from) v = silu_f(v);
+          if (g.act_silu_from >= 0 && col >= g.act_silu_from) v = silu_hw(v);
           C[(int64_t)row * g.ldc + col] = v;
         }
       }

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
           }
           v += bv;
           if (HAS_RES) v += g.residual[(int64_t)row * g.ldc + col];
-          if (g.act_silu_from >= 0 && col >= g.act_silu_from) v = silu_f(v);
+          if (g.act_silu_from >= 0 && col >= g.act_silu_from) v = silu_hw(v);
           C[(int64_t)row * g.ldc + col] = v;
         }
       }

@@ -194,19 +194,31 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
       if (col >= g.n) continue;
       const float wi = NSTAGE == 1 ? scl[BMT + col - n0] : winv_r[j];
       const float bv = HAS_BIAS ? g.bias[col] : 0.f;
+      // (per (i, j) one base pointer; the 16 rows of the accumulator tile are compile-time multiples of the row pitch from it --
+      // the per-element 64-bit row * pitch products, bounds checks and libm SiLU of the first form were ~60 instructions per
+      // stored value, as many in the epilogue as in the whole K loop)
+      const int row0 = m0 + (BMT / 2) * wm + 32 * i + 4 * lh;
+      const bool act = g.act_silu_from >= 0 && col >= g.act_silu_from;
+      const bool rows_in = row0 + 27 < g.m;  // (uniform but for tiles on the lower edge)
+      if (S != nullptr) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
+        float* sp = S + (int64_t)row0 * g.n + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = (r & 3) + 8 * (r >> 2);
+          if (rows_in || row0 + ro < g.m) sp[(int64_t)ro * g.n] = acc[i][j][r] * (wi * ainv[r]);
+        }
+        continue;
+      }
+      float* cp = C + (int64_t)row0 * g.ldc + col;
+      const float* rp = HAS_RES ? g.residual + (int64_t)row0 * g.ldc + col : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (BMT / 2) * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < g.m) {
-          float v = acc[i][j][r] * (wi * ainv[r]);
-          if (S != nullptr) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
-            S[(int64_t)row * g.n + col] = v;
-            continue;
-          }
-          v += bv;
-          if (HAS_RES) v += g.residual[(int64_t)row * g.ldc + col];
-          if (g.act_silu_from >= 0 && col >= g.act_silu_from) v = silu_f(v);
-          C[(int64_t)row * g.ldc + col] = v;
+        const int ro = (r & 3) + 8 * (r >> 2);
+        if (rows_in || row0 + ro < g.m) {
+          float v = acc[i][j][r] * (wi * ainv[r]) + bv;
+          if (HAS_RES) v += rp[(int64_t)ro * g.ldc];
+          if (act) v = silu_hw(v);
+          cp[(int64_t)ro * g.ldc] = v;
         }
       }
     }
