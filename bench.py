@@ -625,6 +625,16 @@ def main(argv=None, engine_factory=None, device=None):
         sink = torch.zeros(1024, device=dev)
         out["hbm_read_measured_GBps"] = rate(lambda: stream_read(src, sink)) / 2
         del src, dst
+        # the same read over 4 GiB per launch: launches of 1 GiB (~0.15 ms) lose ~10 % to ramp-up, tail and the gaps between them
+        # (scripts/read_shape.cpp: 7.0-7.2 TB/s for 1.6-6.4 GB per launch on the boxes that report 6.1-6.4 above)
+        try:
+            big = torch.empty(4 * n_copy, device=dev)
+            n_keep, n_copy = n_copy, 2 * n_copy            # rate() prices 2 x n_copy floats per call
+            out["hbm_read_4GiB_launch_GBps"] = rate(lambda: stream_read(big, sink))
+            n_copy = n_keep
+            del big
+        except RuntimeError:
+            pass
     out["algorithmic_bytes_per_env_step"] = 2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim
     out["whole_step_8d_GBps"] = out["algorithmic_bytes_per_env_step"] * value / world / 1e9
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
