@@ -39,3 +39,14 @@ def test_state_pass_file_agrees_with_the_whole_step_reduction():
     launches = (spec.n_blocks - len(spec.slstm_at)) * pm["micro_batches"]
     per_launch = (fam["mlstm_lazy_cell_kernel"] + fam["mlstm_lazy_fold_kernel"]) * 1e9 / launches
     assert abs(pm["hbm_bytes_per_launch"] / per_launch - 1.0) < 0.03
+
+
+def test_mamba_state_update_counters_match_the_byte_model():
+    """Same check for the C3 line's dominant kernel (the selective state update): its `roofline.traffic` constant is replayed
+    from profiles/rNN_cell_kernel_hbm_traffic_mamba_48m.json (scripts/pmc_pass.sh with PMC_TAG=mamba_48m)."""
+    pm = json.load(open(_latest("r0[4-9]_cell_kernel_hbm_traffic_mamba_48m.json")))
+    spec = preset(pm["config"])
+    model = bench.ssm_bytes(spec, spec.tokens_per_step)
+    ratio = pm["hbm_bytes_per_env_per_launch"] / model
+    assert 0.95 <= ratio <= 1.10, (ratio, pm["hbm_bytes_per_env_per_launch"], model)
+    assert "steady-state" in pm["reduction"] and pm["envs_per_launch"] * pm["micro_batches"] == pm["batch"]
