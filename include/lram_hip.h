@@ -75,6 +75,9 @@ const char* lram_last_error(void);
 
 /* ABI version the library was built with. */
 int32_t lram_abi_version(void);
+/* 64 hex digits: sha256 over the library's sources, headers and compiler flags (lram_amd/build.py::source_hash).  The
+ * Python side rebuilds when it differs from the checked-out tree; tests/conftest.py and bench.py assert / report it. */
+const char* lram_build_id(void);
 
 /* Create an engine on HIP device `device`.  Replaces the construction of the policy's encoder,
  * xLSTMEncoder.__init__ / MambaEncoder.__init__ (decision_xlstm.py:119-136, decision_mamba.py:52-107). */
@@ -183,6 +186,14 @@ int32_t lram_set_graph_mode(lram_engine* e, int32_t enable);
 int32_t lram_set_state_mode(lram_engine* e, int32_t mode, int32_t fold_period);
 /* 1 when the lazy representation is in effect for the allocated batch, else 0. */
 int32_t lram_get_state_mode(const lram_engine* e);
+/* Lazy representation, looked at WITHOUT folding (an export would change the fold schedule of the run it observes): copies
+ * for mLSTM block `block`
+ *   which 0: the scale g of C_base accumulated since the env's last fold   float[B, NH]
+ *   which 1: the stabiliser state m                                         float[B, NH]
+ *   which 2: pending window tokens per env (as floats)                       float[B]
+ * into dev_dst, as of the last completed step.  Evidence hook of the long-horizon parity tests (the range g and m cover over
+ * a 1000-step episode: evaluation.py:130-177 never clears the cache inside an episode); fails in materialised mode. */
+int32_t lram_lazy_peek(lram_engine* e, int32_t block, int32_t which, float* dev_dst, void* stream);
 
 /* Micro-batch pipeline (xLSTM): the env slots are processed as `n` slices on engine-owned HIP streams; the
  * HBM-bound matrix-memory kernels of all slices run back to back on one stream while the other slices'
@@ -254,11 +265,6 @@ int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int
 int32_t lram_gemm_f16x2_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                                  int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                                  int32_t k, void* stream);
-/* The same with the activation operand pre-split into three bf16 planes first (the form in which the engine's norm /
- * gate / state-update kernels hand their results to the big projections): bit-identical to lram_gemm_bf16x3. */
-int32_t lram_gemm_bf16x3_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
-                         int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
-                         int32_t k, void* stream);
 /* Image observations: uint8 frames [batch, channels, height, width] -> state-token embeddings [batch, d_model]
  * through the IMPALA CNN (3 x [conv3x3 -> maxpool(3,2,1) -> 2 residual blocks], 16/32/32 channels, ReLU, flatten,
  * Linear, ReLU).  Replaces `self.embed_image(state.float() / 255)` (online_decision_transformer_model.py:523-526;

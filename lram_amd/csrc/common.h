@@ -57,10 +57,6 @@ struct GemmArgs {
   // optional: W pre-split into three bf16 planes (hi, mid, lo), each laid out like w, `w3_plane` elements apart
   const uint16_t* w3 = nullptr;
   int64_t w3_plane = 0;
-  // optional: A pre-split by its producer into three bf16 planes laid out like a (row stride lda), `a3_plane` elements
-  // apart (bf16x3 kernel only; `a` may then be null)
-  const uint16_t* a3 = nullptr;
-  int64_t a3_plane = 0;
   // optional (bf16x3 kernel, fp32 A, no batch, no split-K): A[r][k] is multiplied by gate[r * ldg + k] while it is staged
   // (the mLSTM output gate: gate holds silu(z), written by proj_up's epilogue via act_silu_from)
   const float* gate = nullptr;
@@ -72,19 +68,12 @@ struct GemmArgs {
   // weight (K padded to a multiple of 32) -- the 128 rows x 32 columns a workgroup stages per K tile are ONE contiguous 8 KB run
   // instead of 128 pieces of 64 bytes at the row pitch (half cache lines: 1.4 x slower to deliver, scripts/tile_delivery.cpp);
   // with the exact inverse of each weight row's power-of-two scale; a_amax[r] = largest magnitude of A's row r (of the
-  // gated row with `gate`), or an upper bound of it, from which the kernel derives the row's power-of-two scale
+  // gated row with `gate`), from which the kernel derives the row's power-of-two scale
   const uint16_t* w2 = nullptr;
   int64_t w2_plane = 0, w2_kt = 0;
   const float* w_inv = nullptr;
   const float* a_amax = nullptr;
   int amax_parts = 1;  // row r's maximum = max of a_amax[r * amax_parts + 0 .. amax_parts - 1]
-  // ... times a_amax_mul[r] (optional) times a_amax_scale: an UPPER BOUND of the row's largest magnitude assembled from what
-  // the producers know (e.g. max |h| per head x a Cauchy-Schwarz bound of the gate) serves as well as the maximum itself --
-  // the split is floating point, a scale that is 2^k too small costs precision only for elements below 2^(k-18) of the row's
-  // largest (tests/test_gpu_parity.py::test_gemm_f16x2_tolerates_a_loose_row_bound)
-  const float* a_amax_mul = nullptr;
-  float a_amax_scale = 1.f;
-  float a_amax_c0 = 0.f, a_amax_c1 = 1.f;  // bound = (c0 + c1 * max of the parts) * mul[r] * scale
   // optional (f16x2 kernel with pre-split operands, gemm_f16x2p.hip): A pre-split by its producer into two f16 planes (hi, lo)
   // of the row-scaled value, K-tile-major like w2 (element (r, k) at (k / 32) * a2_kt + r * 32 + k % 32), `a2_plane` elements
   // apart, with a2_inv[r] = the exact inverse of row r's power-of-two scale (`a` may then be null; K a multiple of 32)
@@ -110,7 +99,7 @@ struct GemmArgs {
   // set by the launcher (gemm_choose_xcd_split): the 8 XCDs (each with its own 4 MB L2) take an xcd_gm x xcd_gn grid of
   // output blocks, xcd_gm * xcd_gn == 8; 0 = the one-dimensional map (each XCD a contiguous run of tiles, M-major)
   int xcd_gm = 0, xcd_gn = 0;
-  int mfma_prio = 0;      // set by the launcher (LRAM_GEMM_PRIO): raise the wave's issue priority around the MFMA block
+  int mfma_prio = 0;      // set by the launcher: raise the wave's issue priority around the MFMA block
   int split_k = 1;        // set by the launcher
   int k_tiles_per_split = 0;
 };
@@ -172,22 +161,17 @@ struct ScalarTokens {
   int64_t in_stride = 1;
   int T = 3;
 };
+// (h2: optional f16x2 operand planes (hi, lo) of the row-scaled result, K-tile-major with h2_kt elements per K tile, h2_plane
+// elements apart, + h2_inv[rows] inverse row scales -- the pre-split projection kernel's A operand; out may then be null)
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2 = nullptr,
-                     uint16_t* planes = nullptr, int64_t plane_stride = 0,   // planes: bf16x3 GEMM operand (row stride
-                     float* amax = nullptr, const ScalarTokens* st = nullptr,                                  // out_stride); out may then be null
-                     uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr,  // f16x2 operand planes (hi, lo) of the
-                     float* l2 = nullptr, int64_t h2_kt = 0);                                // row-scaled result (K-tile-major, h2_kt elements per K tile) + inverse row scales;
-                                                                                             // l2: optional [rows] Euclidean norm of each output row
-void launch_max_row_l2(const float* w, int rows, int k, float* out, hipStream_t stream);  // out[0] = max_r |w[r, :]|_2
-void launch_max_abs(const float* v, int n, float* out, hipStream_t stream);                // out[0] = max_i |v[i]|
+                     float* amax = nullptr, const ScalarTokens* st = nullptr, uint16_t* h2 = nullptr, int64_t h2_plane = 0,
+                     float* h2_inv = nullptr, int64_t h2_kt = 0);
 // Mamba block entry: res_out = hidden (+ res_in);  normed = RMSNorm(res_out) * gamma.
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
-                         const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes = nullptr,
-                         int64_t plane_stride = 0,  // planes: `normed` as a bf16x3 GEMM operand (normed may be null)
+                         const float* gamma, int rows, int d, float eps, hipStream_t stream,
                          float* amax = nullptr,     // [rows] largest |normed| per row (f16x2 GEMM's a_amax)
-                         uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr,   // f16x2 operand planes of `normed`
-                         int64_t h2_kt = 0);                                                      // (K-tile-major, h2_kt elements per K tile)
+                         uint16_t* h2 = nullptr, int64_t h2_plane = 0, float* h2_inv = nullptr, int64_t h2_kt = 0);
 
 // ---------------------------------------------------------------------------------------------
 // front end / head
@@ -249,7 +233,6 @@ struct MlstmFrontArgs {
   const float *bi = nullptr, *bf = nullptr;
   float* xa = nullptr;          // [B*T, inner] out  silu(conv)
   float* scal = nullptr;        // [B*T, NH, 4] out  (f_t, i_t, denom_t, m_t)
-  float* xa_amax = nullptr;     // optional [B*T, NH] out: max |xa| per (row, head) (an ingredient of proj_down's row-scale bound)
   const uint8_t* reset = nullptr;
   int B = 0, T = 0, inner = 0, NH = 0, K = 0;
   int epw = 0;                  // env slots per workgroup (0 = default)
@@ -308,17 +291,6 @@ struct MlstmLazyArgs {
   // GN(h) * gn_g (+ gn_b) + gn_skip * xa, the output gate silu(z) is applied by proj_down while it stages its operand
   const float *gn_g = nullptr, *gn_b = nullptr, *gn_skip = nullptr;
   float gn_eps = 0.f;
-  // ... and the output gate as well (gn_gate != nullptr, with gn_g): gn_gate[row * gn_ldg + channel] holds silu(z), written
-  // by the un-split proj_up's epilogue BEFORE this pass; h is stored gated, and the largest magnitude of each (row, head)
-  // slice of it goes to gn_amax[row * NH + head] -- proj_down's f16x2 row scales (a_amax with amax_parts = NH): no
-  // row-maximum launch, no second read of h and z ahead of the GEMM
-  const float* gn_gate = nullptr;
-  int64_t gn_ldg = 0;
-  float* gn_amax = nullptr;
-  // fold + readout in one pass over the due envs' matrix memory: the fold kernel, run AFTER this step's front end, also
-  // leaves the partial readouts y_t[c] = sum_r q_t[r] C_new[r][c] of its 64 rows in ypart [B, NH, DH / 64, T, DH]; the
-  // read pass then sums them (fixed order) instead of streaming C_base again for the envs that just folded
-  float* ypart = nullptr;
   float* pw = nullptr;    // [B, NH, T, kLazyWT] window scores: only for geometries with several column slices per head
   const uint8_t* reset;   // [B] or null
   int B, T, NH, DH;
@@ -326,7 +298,6 @@ struct MlstmLazyArgs {
   int force;              // fold kernel: fold every env that has pending tokens (materialise)
   int compact = 0;        // fold kernel: launch only over the envs whose phase comes up (no window can overflow)
   int first = 0;          // set by the launcher
-  int fold_wmax = 0;      // fold kernel: host-side upper bound of the pending tokens of the envs that fold (0 = unknown)
   int min_lds_bytes = 0;
 };
 void launch_mlstm_lazy_fold(const MlstmLazyArgs& a, hipStream_t stream);
@@ -338,6 +309,7 @@ void launch_mlstm_lazy_book(const MlstmLazyArgs& a, hipStream_t stream);
 bool mlstm_lazy_supported(int DH, int T);
 // count[b] = 0, g[b, :] = 1 for masked envs (mask == nullptr: all), both parities handled by the caller
 void launch_mlstm_lazy_clear(int32_t* count, float* g, const uint8_t* mask, int B, int NH, hipStream_t stream);
+void launch_lazy_counts_as_float(const int32_t* count, float* out, int B, hipStream_t stream);
 
 
 // mode 0 (mLSTM): out[r, hd] = (GN(h)[r,hd] * gamma + skip*xa) * silu(z)      z = u[r, inner + hd]
@@ -350,8 +322,6 @@ struct GroupNormArgs {
   const float* xa;     // mode 0 [rows, NH*DH]
   const float* u;      // mode 0 [rows, 2*NH*DH]
   float* out;          // mode 0: g [rows, NH*DH] (may be null when planes are given); mode 1: x [rows, NH*DH] (+=)
-  uint16_t* planes = nullptr;  // mode 0: g as a bf16x3 GEMM operand (three planes, row stride NH*DH)
-  int64_t plane_stride = 0;
   int rows, NH, DH, mode;
   float eps;
 };
@@ -435,11 +405,9 @@ struct MambaSsmArgs {
   const float* A_log;   // [d_inner, N]
   const float* Dp;      // [d_inner]
   const float* xz;      // [B*T, 2*d_inner] (z at + d_inner)
-  float* y;             // [B*T, d_inner] out (may be null when y3 is given)
+  float* y;             // [B*T, d_inner] out
   const uint8_t* reset;
   int B, T, d_inner, N, R;
-  uint16_t* y3 = nullptr;   // y as a bf16x3 GEMM operand: three planes [B*T, d_inner], y3_plane elements apart
-  int64_t y3_plane = 0;
   float* amax = nullptr;    // optional [B*T][d_inner / 64]: per-64-channel partial row maxima of y (f16x2 GEMM's a_amax)
   const float* dt_wt = nullptr;  // optional dt_proj.weight TRANSPOSED [R, d_inner]: dt_proj evaluated inside the kernel, dtp unused
 };

@@ -103,13 +103,9 @@ struct lram_engine {
     size_t rows, k;
   };
   std::map<const float*, Split16> split16;
-  bool down_presplit = false;  // LRAM_DOWN_PRESPLIT=1: proj_down's gated operand split once by a row kernel (in place of the row-maximum launch)
   bool gemm_presplit = true;   // LRAM_GEMM_PRESPLIT=0: the norms ahead of proj_up / in_proj write fp32 + row maxima (round 3) instead of
                                // the f16x2 GEMM's operand planes (gemm_f16x2p.hip)
   double gemm_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // launches / fp32-equivalent FLOPs per dispatcher family (lram_gemm_counts)
-  std::vector<DevBuf> slstm_gw;   // sLSTM: the four gate projections' weights packed [4][NH][SDH][SDH] (two launches instead of four)
-  bool slstm_gates_pair = false;  // LRAM_SLSTM_GATES_PAIR=1: the gate projections as two batched launches (a pair per operand) instead of four;
-                                  // measured neutral to -0.5 % at 4096 slots (profiles/r04_ab_slstm_seq.txt): off
   std::vector<DevBuf> slstm_rt2;  // sLSTM: recurrent weights re-packed [head][k][channel][gate] per block (slstm_seq.hip), head dim 128
   bool slstm_seq = true;          // LRAM_SLSTM_SEQ=0: per-token recurrent GEMM + pointwise launches for slices beyond the token kernel's
   std::vector<DevBuf> gate_coef;  // mLSTM: folded i / f gate coefficients per block (mlstm_front.hip), geometries it covers
@@ -119,7 +115,7 @@ struct lram_engine {
   DevBuf ASCALE;  // per-row maxima of a GEMM's A operand computed by launch_row_amax, one region per stream slot (like
   size_t ascale_rows = 0;  // the split-K slabs)
   // row maxima handed over by the kernels that produce the projections' operands, indexed like the rows of X:
-  // XN (norm -> proj_up / ffn_up / in_proj), XA (Mamba conv -> x_proj), H (selective state update -> out_proj)
+  // XN (norm -> proj_up / ffn_up / in_proj), XA (Mamba conv -> x_proj), H (Mamba selective state update -> out_proj)
   DevBuf AMX_XN, AMX_XA, AMX_H;
   // front end / head
   const float *w_state = nullptr, *b_state = nullptr, *w_rtg = nullptr, *b_rtg = nullptr, *w_rew = nullptr,
@@ -140,49 +136,21 @@ struct lram_engine {
   bool lazy = false;        // effective choice for the current batch (decided in state_alloc / set_state_mode)
   bool lazy_ready = false;  // buffers allocated for the current batch
   int lazy_period = 13;
-  bool lean_front = true;   // LRAM_LEAN_FRONT=0
-  bool mamba_dt_fuse = true;  // LRAM_MAMBA_DT_FUSE: dt_proj inside the selective-state-update kernel (d_state 16, dt_rank <= 64)
   int gn_fuse = 2;          // LRAM_GN_FUSE: output group norm + skip in the read pass's epilogue, gate in proj_down's
                             // operand staging.  0 off, 1 on, 2 auto = on from 2048 env slots (round 3, same box, two
                             // rounds: 391.1k / 393.5k off vs 395.8k / 397.5k on at 4096 slots; 1024 slots: -0.4 %)
-                            // operand staging (measured: +0.7 % at 4096 env slots, -0.3 % at 1024: opt-in)
-  bool split_up = true;     // LRAM_SPLIT_UP=0: proj_up as one GEMM ahead of the front end
-  bool gate_in_pass = false;  // LRAM_GATE_IN_PASS=1: output gate + proj_down's row maxima in the read pass's epilogue, proj_up un-split.
-                              // Correct (front / full-size / real-batch / lazy suites green with it) and SLOWER: 436.5k / 433.0k ->
-                              // 428.9k / 424.5k env-steps/s on one box (profiles/r04_ab_gate_in_pass.txt) -- the row-maximum launches and
-                              // 0.7 GB of chain reads go, but the read pass, the critical queue, gets 14 us longer (0.516 -> 0.530 ms)
-  // fold + readout (mlstm_lazy.hip, LRAM_FOLD_FUSED=1): an env's fold runs right ahead of its slice's read pass, after the
-  // front end, and hands the read pass q . C_new for the 64-row strips it has just rewritten -- the due envs' matrix memory
-  // is then read once per fold step instead of twice (-2.3 GB of 48 per step).  Correct (lazy / real-batch / full-size
-  // suites green with it) and SLOWER: 420.6k -> 400.5k env-steps/s in the state-pass queue, 397.6k on the fold stream
-  // (same box, round 3): the read passes get 4 % shorter and the 14 half-size folds cost what the 7 full ones did, but a
-  // fold that needs this step's q sits on the slice's critical chain (front end -> fold -> read pass), while the q-free
-  // folds run in the state-pass queue's idle stretches.  Default off.
-  bool fold_fused = false;
-  bool fold_fused_stream = true;  // LRAM_FOLD_FUSED_STREAM=0: fused folds inside the state-pass queue
-  DevBuf YPART;  // [B, NH, DH / 64, T, DH]
-  int fold_gaps = 0;        // LRAM_FOLD_GAPS=g: the last g mLSTM blocks' folds run just ahead of their own read passes
-  int front_stagger = 0;    // LRAM_FRONT_STAGGER=1: in the step's first mLSTM block, slice k's front end waits for slice k-1's
+  bool mamba_dt_fuse = true;  // LRAM_MAMBA_DT_FUSE: dt_proj inside the selective-state-update kernel (d_state 16, dt_rank <= 64)
   int slstm_fused_rows = 512;  // LRAM_SLSTM_FUSED_ROWS: slices of slstm_fused_min .. this many envs (at sLSTM head dim <= 128; fewer above:
                                // x 128 / head dim) take the one-launch sLSTM token kernel (0 = never)
-  int slstm_fused_min = 1;     // LRAM_SLSTM_FUSED_MIN
   int gemm_skinny_rows = 384;  // LRAM_GEMM_SKINNY_ROWS: GEMMs with 9 .. this many operand rows (half of it for weights above 600k elements) ...
-  int slstm_gates_rows = 768;    // LRAM_SLSTM_GATES_ROWS: gate projections (head dim <= 128) of up to this many rows on the few-row kernel as well
-  bool slstm_gates_one = true;   // LRAM_SLSTM_GATES_ONE: the four sLSTM gate projections as one few-row GEMM launch (operand tables)
-  bool embed_fuse = true;        // LRAM_EMBED_FUSE: the scalar-token embeddings inside the embed_ln launch (single timesteps)
-  bool gemm_skinny_norm = true;  // LRAM_GEMM_SKINNY_NORM: the row norm ahead of proj_up / ffn_up inside the few-row kernel's prologue
+  static constexpr int slstm_gates_rows = 768;  // sLSTM gate projections (head dim <= 128) of up to this many rows on the few-row kernel as well
   int gemm_skinny_min = 5;     // LRAM_GEMM_SKINNY_MIN: fewest operand rows (below: the GEMV path; 16M at 1 env 0.372 vs 0.410 ms, at 2 envs 0.443 vs 0.418)
-  int gemm_skinny_k = 1024;    // LRAM_GEMM_SKINNY_K: ... and K up to this take the few-row kernel (rows 0 = never)
-  int stream_prio = 0;      // LRAM_STREAM_PRIO: 1 slice streams highest / state-pass stream lowest priority, 2 slices highest only,
-                            // 3 the reverse of 1 (measured: see profiles/EXPERIMENTS.md)
-  bool fold_spread = true;  // LRAM_FOLD_SPREAD: the folds behind the first read passes are shared out over all sLSTM stretches
-  int fold_bubbles = 2;     // LRAM_FOLD_BUBBLES=k: k folds before the first read pass, the rest behind the sLSTM block, all
-                            // on the state-pass stream (0 = folds on their own stream, one block ahead); measured on one
-                            // box: k = 0 364k, 1 367k, 2 368k, 3 367k, 4 366k env-steps/s
-  bool fold_ahead = false;  // LRAM_FOLD_AHEAD=1: every fold queued at the step start (measured: no gain over one block ahead)
+  static constexpr int gemm_skinny_k = 1024;  // ... and K up to this take the few-row kernel
+  static constexpr int fold_bubbles = 2;  // folds before the first read pass; the rest behind the sLSTM blocks, all on the state-pass
+                                          // stream (measured on one box: k = 0 -- own stream, one block ahead -- 364k, 1 367k, 2 368k,
+                                          // 3 367k, 4 366k env-steps/s)
   int64_t lazy_step = 0;    // steps taken in lazy mode: fold phase and ping-pong parity
   std::vector<int> lazy_bound;  // host-side upper bound of pending tokens per fold class (b % period)
-  int lazy_due_bound = 0;       // lazy_bound of the class that folds this step, before it is cleared
   bool lazy_compact = false;    // this step's fold launches may use the compact grid (no window can overflow)
   bool lazy_dirty = false;      // a lazy step ran since the last materialise: windows may hold pending tokens
   DevBuf LZ_COUNT;          // [2][B] int32 pending tokens per env
@@ -190,22 +158,8 @@ struct lram_engine {
   int B = 0;
   std::vector<BlockState> st;
   DevBuf X, XN, TOK, HID, U, Q, K, V, XA, H, G, SCAL, RY, LOGITS, RES, DTP;
-  DevBuf XN_L2; // [B*T] Euclidean norm of the mLSTM block's normed input rows (bound of the output gate: LRAM_AMAX_BOUND)
-  std::vector<float> z_norm_max;  // per mLSTM block: max_j |proj_up.weight[inner + j, :]|_2 (z half)
-  std::vector<float> h_bound_c0, h_bound_c1;  // per mLSTM block: |GN(h) g + b + skip xa| <= c0 + c1 max|xa| (c0 = sqrt(DH) max|g| + max|b|, c1 = max|skip|)
-  bool amax_bound = false;  // LRAM_AMAX_BOUND=1: proj_down's row scales from an upper bound assembled by the GEMM's prologue (max |xa| per
-                            // head from the front end, |xn| from the norm, constants from finalize) instead of a row-maximum launch over
-                            // h * silu(z): -14 launches, -0.75 GB per step, accuracy unchanged (a 1024 x loose bound still passes the fp64
-                            // bar) and the step 1.5 % SLOWER (426.5k / 422.7k -> 418.6k / 417.2k, profiles/r04_ab_amax_bound.txt): off
-  DevBuf G2;    // the gated mLSTM output as f16x2 operand planes [2][B*T, inner] f16 (proj_down pre-split: LRAM_DOWN_PRESPLIT)
   DevBuf XN2;   // the norm output as f16x2 operand planes [2][B*T, D] f16 (pre-split projections): its own buffer -- a slice inside an
                 // sLSTM block uses XN as fp32 while another slice's mLSTM block holds planes
-  // bf16x3 operand planes written by the producers of the big projections' A operands (row norm -> proj_up / in_proj,
-  // output gate -> proj_down, selective state update -> out_proj): three planes each, `*_plane` elements apart
-  uint16_t *XN3 = nullptr, *G3 = nullptr;
-  size_t xn3_plane = 0, g3_plane = 0;
-  bool use_a3 = false;               // LRAM_GEMM_A3=1: producers write pre-split operand planes (measured 1-2 % slower
-                                     // than splitting on the fly in the GEMM: 16M 372k vs 379k, Mamba-48M 316k vs 322k)
   DevBuf GATES, AMAT, VEC;           // chunkwise mLSTM prefill work buffers (allocated with the first long chunk)
   int tok_cap = 0;                   // tokens per env the activation workspace holds (kMaxTokens until a prefill grows it)
   bool chunk_prefill = true;         // LRAM_PREFILL_CHUNK=0: keep the token-sequential kernels for prefill
@@ -231,11 +185,9 @@ struct lram_engine {
   int compat_pass = 0, compat_passes = 1;
   bool compat_share = true;   // LRAM_COMPAT_SHARE=0: every repeated forward recomputes the front end and layer 0's in_proj
   bool compat_stale = false;  // a reset re-initialises layer 0 only; layers >= 1 keep the previous episode's state
-  int cell_unroll = 16;   // C rows in flight per thread (LRAM_CELL_UNROLL overrides: 8 / 16 / 32)
-  int cell_lds_pad = -1;  // -1 = auto;  // bytes of LDS the cell kernel requests per workgroup while pipelined (occupancy cap)
+  static constexpr int cell_unroll = 16;  // C rows in flight per thread of the materialised cell kernel
   std::vector<hipStream_t> micro_streams;
   hipStream_t hbm_stream = nullptr;
-  hipStream_t fold_stream = nullptr;  // lazy matrix memory: folds run beside the cells of the previous block
   std::vector<hipEvent_t> sync_events;
   size_t sync_used = 0;
   // profiling of the dominant recurrent kernel
@@ -248,7 +200,6 @@ struct lram_engine {
     drop_graph();
     if (capture_stream) (void)hipStreamDestroy(capture_stream);
     if (hbm_stream) (void)hipStreamDestroy(hbm_stream);
-    if (fold_stream) (void)hipStreamDestroy(fold_stream);
     for (hipStream_t ms : micro_streams) (void)hipStreamDestroy(ms);
     for (hipEvent_t ev : sync_events) (void)hipEventDestroy(ev);
     for (auto& e : prof_events) {
@@ -270,8 +221,6 @@ struct lram_engine {
     gate_coef.clear();
     for (DevBuf& b : slstm_rt2) b.release();
     slstm_rt2.clear();
-    for (DevBuf& b : slstm_gw) b.release();
-    slstm_gw.clear();
   }
   void drop_graph() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -296,12 +245,9 @@ struct lram_engine {
     lazy_ready = false;
     st.clear();
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
-                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &G2, &XN_L2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &YPART, &X0, &U0})
+                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &X0, &U0})
       b->release();
     ascale_rows = 0;
-    if (XN3) (void)hipFree(XN3);
-    if (G3) (void)hipFree(G3);
-    XN3 = G3 = nullptr;
     img_cap = 0;
     B = 0;
     tok_cap = 0;
@@ -368,7 +314,6 @@ void validate_config(const lram_config& c) {
 }
 
 void make_split(lram_engine* e, const float* w, size_t n);
-bool a3_for(const lram_engine* e, const float* w, int rows, int k, int64_t lda);
 bool presplit_for(const lram_engine* e, const float* w, int rows, int n, int k);
 
 void finalize(lram_engine* e) {
@@ -471,18 +416,6 @@ void finalize(lram_engine* e) {
   }
   // bf16 split planes of every GEMM weight (LRAM_GEMM=f32 keeps the exact fp32-MFMA kernels instead)
   e->drop_splits();
-  // sLSTM gate projections (i, f on the conv branch, z, o on the norm): the four [NH, SDH, SDH] weights side by side, so that
-  // a pair that shares its operand is ONE batched launch (nb1 = 2 gates x nb2 = NH heads) instead of two
-  e->slstm_gw.assign(c.n_blocks, DevBuf());
-  if (c.backbone == LRAM_BACKBONE_XLSTM && e->slstm_gates_pair) {
-    const size_t per = (size_t)c.d_model * (c.d_model / c.n_heads);
-    for (int i = 0; i < c.n_blocks; ++i) {
-      if (!c.block_is_slstm[i]) continue;
-      e->slstm_gw[i].alloc(4 * per);
-      for (int g = 0; g < 4; ++g)
-        LRAM_HIP_CHECK(hipMemcpy(e->slstm_gw[i].p + g * per, e->bw[i].gate_w[g], per * sizeof(float), hipMemcpyDeviceToDevice));
-    }
-  }
   if (const char* v = std::getenv("LRAM_GEMM")) {
     e->use_bf16x3 = std::string(v) != "f32";
     e->use_f16x2 = std::string(v) != "f32" && std::string(v) != "bf16x3";
@@ -527,8 +460,6 @@ void finalize(lram_engine* e) {
         ws.push_back(p);
     for (const float* p : ws)
       if (p != nullptr) make_split(e, p, numel(p));
-    for (DevBuf& b : e->slstm_gw)
-      if (b.p != nullptr) make_split(e, b.p, b.n);
     LRAM_HIP_CHECK(hipDeviceSynchronize());
   }
   e->gate_coef.assign(e->bw.size(), DevBuf());
@@ -540,29 +471,6 @@ void finalize(lram_engine* e) {
       launch_gate_coef(w.wq, w.wk, w.wv, w.wi, w.wf, c.inner, c.n_heads, e->gate_coef[i].p, nullptr);
     }
     LRAM_HIP_CHECK(hipDeviceSynchronize());
-  }
-  e->z_norm_max.assign(e->bw.size(), 0.f);
-  e->h_bound_c0.assign(e->bw.size(), 0.f), e->h_bound_c1.assign(e->bw.size(), 1.f);
-  if (c.backbone == LRAM_BACKBONE_XLSTM) {
-    DevBuf tmp;
-    tmp.alloc(1);
-    for (size_t i = 0; i < e->bw.size(); ++i) {
-      if (c.block_is_slstm[i]) continue;
-      launch_max_row_l2(e->bw[i].proj_up + (size_t)c.inner * c.d_model, c.inner, c.d_model, tmp.p, nullptr);
-      LRAM_HIP_CHECK(hipMemcpy(&e->z_norm_max[i], tmp.p, sizeof(float), hipMemcpyDeviceToHost));
-      float mg = 0.f, mb = 0.f, ms = 0.f;
-      launch_max_abs(e->bw[i].on_g, c.inner, tmp.p, nullptr);
-      LRAM_HIP_CHECK(hipMemcpy(&mg, tmp.p, sizeof(float), hipMemcpyDeviceToHost));
-      if (e->bw[i].on_b != nullptr) {
-        launch_max_abs(e->bw[i].on_b, c.inner, tmp.p, nullptr);
-        LRAM_HIP_CHECK(hipMemcpy(&mb, tmp.p, sizeof(float), hipMemcpyDeviceToHost));
-      }
-      launch_max_abs(e->bw[i].skip, c.inner, tmp.p, nullptr);
-      LRAM_HIP_CHECK(hipMemcpy(&ms, tmp.p, sizeof(float), hipMemcpyDeviceToHost));
-      // a group-normalised vector of DH elements has no element beyond sqrt(DH - 1) in magnitude
-      e->h_bound_c0[i] = std::sqrt((float)(c.inner / c.n_heads)) * mg + mb, e->h_bound_c1[i] = ms;
-    }
-    tmp.release();
   }
   e->slstm_rt2.assign(e->bw.size(), DevBuf());
   if (c.backbone == LRAM_BACKBONE_XLSTM && slstm_seq_supported(c.d_model, c.n_heads, c.tokens_per_step)) {
@@ -604,12 +512,9 @@ void alloc_workspace(lram_engine* e, int tokens) {
   const size_t parts = c.backbone == LRAM_BACKBONE_MAMBA ? std::max<size_t>(1, c.d_inner / 64) : 0;
   e->AMX_XN.alloc(BT);
   if (parts) e->AMX_XA.alloc(BT * parts), e->AMX_H.alloc(BT * parts);
-  if (c.backbone == LRAM_BACKBONE_XLSTM) e->AMX_H.alloc(BT * (size_t)c.n_heads);  // read pass -> proj_down (gate_in_pass)
   e->X.alloc(BT * D);
   e->XN.alloc(BT * D);
   if (e->gemm_presplit && e->use_f16x2) e->XN2.alloc(BT * D);
-  if (e->amax_bound && e->use_f16x2 && c.backbone == LRAM_BACKBONE_XLSTM) e->XN_L2.alloc(BT);
-  if (e->down_presplit && e->gemm_presplit && e->use_f16x2 && c.backbone == LRAM_BACKBONE_XLSTM) e->G2.alloc(BT * (size_t)c.inner);
   e->TOK.alloc(BT * D);
   e->HID.alloc(BT * D);
   e->LOGITS.alloc(B * c.act_dim * c.n_vocab);
@@ -640,16 +545,6 @@ void alloc_workspace(lram_engine* e, int tokens) {
       e->AMAT.alloc(B * c.n_heads * kChunkMaxTokens * kChunkMaxTokens);
       e->VEC.alloc(B * c.n_heads * 3 * kChunkMaxTokens);
     }
-  }
-  // operand planes of the big projections
-  if (e->XN3) (void)hipFree(e->XN3);
-  if (e->G3) (void)hipFree(e->G3);
-  e->XN3 = e->G3 = nullptr;
-  if (e->use_a3 && e->use_bf16x3) {
-    e->xn3_plane = BT * D;
-    e->g3_plane = BT * (c.backbone == LRAM_BACKBONE_MAMBA ? (size_t)c.d_inner : e->icols);
-    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->XN3), 3 * e->xn3_plane * sizeof(uint16_t)));
-    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&e->G3), 3 * e->g3_plane * sizeof(uint16_t)));
   }
   e->tok_cap = tokens;
 }
@@ -706,7 +601,6 @@ void lazy_alloc(lram_engine* e) {
   }
   e->LZ_COUNT.alloc(2 * B);
   e->LZ_COUNT.zero();
-  if (e->fold_fused) e->YPART.alloc(B * NH * (DH / 64) * 4 * DH);  // (lazy steps take at most 4 tokens)
   for (int i = 0; i < c.n_blocks; ++i) {
     if (c.block_is_slstm[i]) continue;
     BlockState& s = e->st[i];
@@ -825,7 +719,7 @@ bool takes_skinny(const lram_engine* e, const GemmArgs& g) {
 // ... and may the norm ahead of this projection move into its prologue?  (Then the caller skips the norm launch and hands
 // the un-normalised rows over with norm_g / norm_b / norm_eps / norm_rms set.)
 bool takes_skinny_with_norm(const lram_engine* e, const GemmArgs& g) {
-  return e->gemm_skinny_norm && takes_skinny(e, g) && gemm_skinny_norm_supported(g);
+  return takes_skinny(e, g) && gemm_skinny_norm_supported(g);
 }
 
 void count_gemm(lram_engine* e, int family, const GemmArgs& g) {
@@ -833,57 +727,72 @@ void count_gemm(lram_engine* e, int family, const GemmArgs& g) {
   e->gemm_counts[4 + family] += 2.0 * g.m * g.n * g.k * g.nb1 * g.nb2;
 }
 
-// GEMM dispatch: bf16x3 (fp32-accurate on the bf16 matrix cores) when the weight has split planes and the shape
-// allows 16-byte bf16 loads, else the exact fp32-MFMA kernel.
+// ---- which projections take the f16x2 kernels: ONE predicate for the dispatcher and for the producers of the operands ------
+// Row threshold: from 1024 rows -- below that a step is launch-bound (16M at 32 envs 0.66 ms on bf16x3, 0.83 ms with the f16x2
+// kernel's extra row-maximum launches) and the three-workgroups-per-CU advantage needs a grid that fills the chip; wide
+// weights -- the 206M stack's 5120 x 1280 / 1280 x 2560 -- pay from 512 rows (206M at 512 slots runs 768-row slices, 28.1k
+// env-steps/s on bf16x3 vs 29.5k on f16x2).
+bool f16x2_rows(const lram_engine* e, int rows, int n, int k) {
+  return e->use_f16x2 && (rows >= e->f16x2_min_rows || (rows >= 512 && (int64_t)n * k >= 2500000));
+}
+// The f16 planes of the weight tensor that contains w (a GEMM may address a row range of a weight: proj_up's halves): fills the
+// operand fields of g and returns true when w starts on a whole row of a split weight whose K equals ldw.
+bool f16x2_weight(const lram_engine* e, const float* w, int ldw, GemmArgs* g) {
+  auto it = e->split16.upper_bound(w);
+  if (it == e->split16.begin()) return false;
+  --it;
+  if (!(w < it->first + it->second.rows * it->second.k) || (int)it->second.k != ldw) return false;
+  const size_t row0 = (size_t)(w - it->first) / it->second.k;
+  if (row0 * it->second.k != (size_t)(w - it->first)) return false;   // planes are addressed by whole rows
+  if (g != nullptr) {
+    g->w2 = it->second.planes + row0 * 32;  // K-tile-major planes
+    g->w2_plane = (int64_t)split_f16x2_plane_elems(it->second.rows, it->second.k), g->w2_kt = (int64_t)it->second.rows * 32;
+    g->w_inv = it->second.inv + row0;
+  }
+  return true;
+}
+
+// Does the projection `rows x k` against weight w take the f16x2 kernel with BOTH operands pre-split (gemm_f16x2p.hip)?  The
+// producer of A (a row norm) asks before it chooses its output format, gemm() asks the same question through the a2 operand:
+// the two cannot drift apart.  K a multiple of the kernel's 32-deep tile (d_model <= 2048: the norm kernels' limit, checked by
+// validate_config).
+bool presplit_for(const lram_engine* e, const float* w, int rows, int n, int k) {
+  if (!e->gemm_presplit || (k & 31) != 0 || e->XN2.p == nullptr || !f16x2_rows(e, rows, n, k)) return false;
+  return f16x2_weight(e, w, k, nullptr);
+}
+
+int stream_slot(const lram_engine* e, hipStream_t s) {  // split-K slab / row-maximum region of the stream a GEMM runs on
+  for (size_t i = 0; i < e->micro_streams.size() && i + 1 < (size_t)lram_engine::kSplitKSlots; ++i)
+    if (e->micro_streams[i] == s) return (int)i + 1;
+  return 0;
+}
+
+// GEMM dispatch: f16x2 (both operands pre-split, or A split while it is staged) for the big un-batched projections, the
+// few-row kernel for tens of rows, bf16x3 for the batched per-head GEMMs and whatever is left, exact fp32 MFMA as the fallback.
 void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
-  if (e->SK.p != nullptr) {  // split-K slab slot of the stream this GEMM runs on
-    int slot = 0;
-    for (size_t i = 0; i < e->micro_streams.size() && i + 1 < (size_t)lram_engine::kSplitKSlots; ++i)
-      if (e->micro_streams[i] == s) slot = (int)i + 1;
-    g.splitk_ws = e->SK.p + (size_t)slot * lram_engine::kSplitKSlotElems;
+  if (e->SK.p != nullptr) {
+    g.splitk_ws = e->SK.p + (size_t)stream_slot(e, s) * lram_engine::kSplitKSlotElems;
     g.splitk_ws_elems = (int64_t)lram_engine::kSplitKSlotElems;
   }
-  // (from 1024 rows: below that a step is launch-bound -- 16M at 32 envs 0.66 ms on bf16x3, 0.83 ms with the f16x2 kernel's
-  // extra row-maximum launches -- and the three-workgroups-per-CU advantage needs a grid that fills the chip)
-  // (wide weights -- the 206M stack's 5120 x 1280 / 1280 x 2560 -- pay from 512 rows: 206M at 512 slots runs 768-row slices,
-  // 28.1k env-steps/s on bf16x3 vs 29.5k on f16x2)
   if (g.a2 != nullptr) {  // A handed over as f16x2 operand planes by its producer (presplit_for() said this GEMM takes them)
-    auto it = e->split16.upper_bound(g.w);
-    LRAM_REQUIRE(it != e->split16.begin() && (--it, g.w < it->first + it->second.rows * it->second.k) && (int)it->second.k == g.ldw,
-                 "gemm: pre-split A operand for a weight without f16x2 planes");
-    const size_t row0 = (size_t)(g.w - it->first) / it->second.k;
-    LRAM_REQUIRE(row0 * it->second.k == (size_t)(g.w - it->first), "gemm: a weight's f16x2 planes are addressed by whole rows");
-    g.w2 = it->second.planes + row0 * 32;  // K-tile-major planes
-    g.w2_plane = (int64_t)split_f16x2_plane_elems(it->second.rows, it->second.k), g.w2_kt = (int64_t)it->second.rows * 32;
-    g.w_inv = it->second.inv + row0;
+    LRAM_REQUIRE(f16x2_weight(e, g.w, (int)g.ldw, &g) && gemm_f16x2p_supported(g),
+                 "gemm: pre-split A operand for a projection the pre-split kernel does not serve");
     launch_gemm_f16x2p(g, s);
     count_gemm(e, 0, g);
     return;
   }
-  const bool f16_rows = g.m >= e->f16x2_min_rows || (g.m >= 512 && (int64_t)g.n * g.k >= 2500000);
-  if (e->use_f16x2 && f16_rows && g.nb1 * g.nb2 == 1 && g.a3 == nullptr && e->ASCALE.p != nullptr &&
-      (size_t)g.m <= e->ascale_rows) {
-    auto it = e->split16.upper_bound(g.w);
-    if (it != e->split16.begin() && (--it, g.w < it->first + it->second.rows * it->second.k) && (int)it->second.k == g.ldw) {
-      const size_t row0 = (size_t)(g.w - it->first) / it->second.k;  // a GEMM may address a row range of a weight
-      g.w2 = it->second.planes + row0 * 32;                          // (K-tile-major planes)
-      g.w2_plane = (int64_t)split_f16x2_plane_elems(it->second.rows, it->second.k), g.w2_kt = (int64_t)it->second.rows * 32;
-      g.w_inv = it->second.inv + row0;
-      if (row0 * it->second.k == (size_t)(g.w - it->first) && gemm_f16x2_supported(g)) {
-        if (g.a_amax == nullptr) {  // no producer handed the row maxima over: one small launch ahead of the GEMM
-          int slot = 0;
-          for (size_t i = 0; i < e->micro_streams.size() && i + 1 < (size_t)lram_engine::kSplitKSlots; ++i)
-            if (e->micro_streams[i] == s) slot = (int)i + 1;
-          float* sc = e->ASCALE.p + (size_t)slot * e->ascale_rows;
-          launch_row_amax(g.a, g.lda, g.gate, g.ldg, g.m, g.k, sc, s);
-          g.a_amax = sc, g.amax_parts = 1;
-        }
-        launch_gemm_f16x2(g, s);
-        count_gemm(e, 0, g);
-        return;
+  if (f16x2_rows(e, g.m, g.n, g.k) && g.nb1 * g.nb2 == 1 && e->ASCALE.p != nullptr && (size_t)g.m <= e->ascale_rows) {
+    if (f16x2_weight(e, g.w, (int)g.ldw, &g) && gemm_f16x2_supported(g)) {
+      if (g.a_amax == nullptr) {  // no producer handed the row maxima over: one small launch ahead of the GEMM
+        float* sc = e->ASCALE.p + (size_t)stream_slot(e, s) * e->ascale_rows;
+        launch_row_amax(g.a, g.lda, g.gate, g.ldg, g.m, g.k, sc, s);
+        g.a_amax = sc, g.amax_parts = 1;
       }
-      g.w2 = nullptr, g.w_inv = nullptr, g.w2_kt = 0;
+      launch_gemm_f16x2(g, s);
+      count_gemm(e, 0, g);
+      return;
     }
+    g.w2 = nullptr, g.w_inv = nullptr, g.w2_kt = 0;
   }
   // few operand rows (more than the GEMV's 8, at most gemm_skinny_rows): one 32 x 32 fp32 matrix-core tile per workgroup, operands
   // straight into registers, no split-K slab / reduce launch
@@ -910,27 +819,9 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
       }
     }
   }
-  LRAM_REQUIRE(g.a3 == nullptr, "gemm: a pre-split A operand was produced for a GEMM that does not take the bf16x3 kernel");
   LRAM_REQUIRE(g.gate == nullptr && g.act_silu_from < 0, "gemm: gated operand / output activation need the bf16x3 kernel");
   launch_gemm_f32(g, s);
   count_gemm(e, 2, g);
-}
-
-// Does the projection `rows x k` against weight w take the f16x2 kernel with BOTH operands pre-split (gemm_f16x2p.hip)?
-// Same row threshold as the on-the-fly f16x2 kernel; K a multiple of its 32-deep tile; the weight has f16 planes.
-bool presplit_for(const lram_engine* e, const float* w, int rows, int n, int k) {
-  if (!e->gemm_presplit || !e->use_f16x2 || e->use_a3 || (k & 31) != 0 || e->XN2.p == nullptr) return false;
-  if (!(rows >= e->f16x2_min_rows || (rows >= 512 && (int64_t)n * k >= 2500000))) return false;
-  auto it = e->split16.upper_bound(w);
-  return it != e->split16.begin() && (--it, w < it->first + it->second.rows * it->second.k) && (int)it->second.k == k;
-}
-
-// Does the projection `rows x k` against weight w take the bf16x3 kernel with a pre-split A operand?  (Same conditions
-// as gemm() uses to pick that kernel: the producer then writes planes instead of fp32.)
-bool a3_for(const lram_engine* e, const float* w, int rows, int k, int64_t lda) {
-  if (!e->use_a3 || !e->use_bf16x3 || e->XN3 == nullptr || rows <= 8 || (k & 7) != 0 || (lda & 7) != 0) return false;
-  auto it = e->split.upper_bound(w);
-  return it != e->split.begin() && (--it, w < it->first + it->second.n);
 }
 
 void make_split(lram_engine* e, const float* w, size_t n) {
@@ -996,15 +887,6 @@ hipEvent_t record_on(lram_engine* e, hipStream_t src) {
   return ev;
 }
 
-// level: +1 the device's highest stream priority, -1 its lowest, 0 default
-hipError_t create_stream(hipStream_t* s, int level) {
-  if (level == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-  int least = 0, greatest = 0;
-  hipError_t err = hipDeviceGetStreamPriorityRange(&least, &greatest);
-  if (err != hipSuccess) return err;
-  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, level > 0 ? greatest : least);
-}
-
 // Slices for this call.  One slice on the caller's stream unless micro-batching is on: then n_micro slices on
 // engine-owned streams plus one stream that serialises the HBM-bound cell kernels (see run_xlstm_stack).
 std::vector<Slice> make_slices(lram_engine* e, hipStream_t s, hipStream_t* hbm) {
@@ -1017,10 +899,10 @@ std::vector<Slice> make_slices(lram_engine* e, hipStream_t s, hipStream_t* hbm) 
   if (n == 1) return {Slice{0, e->B, s}};
   while ((int)e->micro_streams.size() < n) {
     hipStream_t ns;
-    LRAM_HIP_CHECK(create_stream(&ns, e->stream_prio == 1 || e->stream_prio == 2 ? +1 : (e->stream_prio == 3 ? -1 : 0)));
+    LRAM_HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
     e->micro_streams.push_back(ns);
   }
-  if (!e->hbm_stream) LRAM_HIP_CHECK(create_stream(&e->hbm_stream, e->stream_prio == 1 ? -1 : (e->stream_prio == 3 ? +1 : 0)));
+  if (!e->hbm_stream) LRAM_HIP_CHECK(hipStreamCreateWithFlags(&e->hbm_stream, hipStreamNonBlocking));
   *hbm = e->hbm_stream;
   std::vector<Slice> out;
   const int base = e->B / n, rem = e->B % n;
@@ -1045,37 +927,24 @@ void join_slices(lram_engine* e, const std::vector<Slice>& sl, hipStream_t hbm, 
 // ---- mLSTM block, split at the cell kernel -----------------------------------------------------------
 // proj_up in two halves pays from 2048 env slots (measured at 16M: 4096 slots 370k -> 374k env-steps/s, 1024 slots 292k
 // -> 287k, 32 slots 45.4k -> 40.0k: below that the extra launch costs more than the shorter critical path gives)
-// lean front end: the lazy read pass of the fused-score geometries rebuilds q, k, v itself (LRAM_LEAN_FRONT=0 keeps the
-// q / k / v round trip through HBM)
+// lean front end: the lazy read pass of the fused-score geometries rebuilds q, k, v itself (no q / k / v round trip through HBM)
 bool lean_front(const lram_engine* e, int T) {
-  return e->lean_front && lazy_active(e, T) && mlstm_lazy_fused_scores(e->cfg.inner / e->cfg.n_heads);
+  return lazy_active(e, T) && mlstm_lazy_fused_scores(e->cfg.inner / e->cfg.n_heads);
 }
 
-bool gn_fused(const lram_engine* e, int T);
-// Output gate inside the read pass too (its epilogue multiplies by silu(z) and hands proj_down the row maxima of the gated
-// rows): z must then be there before the pass -- proj_up runs un-split -- and proj_down loses its gate operand and the
-// row-maximum launch ahead of it (-50 MB of reads and one launch per slice and block at 4096 env slots).
-bool gate_in_pass(const lram_engine* e, int T) { return e->gate_in_pass && gn_fused(e, T); }
-
-bool split_up_now(const lram_engine* e) {
-  return e->split_up && e->B >= 2048 && !e->graph_mode && !gate_in_pass(e, e->cfg.tokens_per_step);
-}
+bool split_up_now(const lram_engine* e) { return e->B >= 2048 && !e->graph_mode; }
 
 // Output group norm + learnable skip inside the lazy read pass's epilogue (its workgroup holds a head's whole output
 // row), silu(z) written by proj_up's epilogue and multiplied onto proj_down's operand while that GEMM stages it: no
 // group-norm launch on the slice's chain, no [rows, inner] round trip for h.
+// (Measured and removed, profiles/EXPERIMENTS.md: the output gate and proj_down's row maxima in that epilogue too -- the
+// row-maximum launches and 0.7 GB of chain reads went, the step got 1.8 % SLOWER because the read pass, the critical queue,
+// got 14 us longer; proj_down's row scales from a Cauchy-Schwarz bound instead of a row-maximum launch: -1.5 %; the gated
+// operand pre-split by a row kernel: -0.5 %.)
 bool gn_fused(const lram_engine* e, int T) {
   const int dh = e->cfg.inner / e->cfg.n_heads;
-  return (e->gn_fuse == 1 || (e->gn_fuse == 2 && e->B >= 2048)) && lean_front(e, T) && e->use_bf16x3 && !e->use_a3 && (dh == 256 || dh == 128) && T <= 4 &&
+  return (e->gn_fuse == 1 || (e->gn_fuse == 2 && e->B >= 2048)) && lean_front(e, T) && e->use_bf16x3 && (dh == 256 || dh == 128) && T <= 4 &&
          e->cfg.inner % 8 == 0 && e->cfg.d_model % 8 == 0 && e->B >= 64;  // (fewer rows take the GEMV path)
-}
-
-// proj_down's f16x2 row scales without a row-maximum launch: max |GN(h) + skip xa| per (row, head) from the read pass's epilogue
-// (values it holds in registers) times a bound of the output gate, |silu(z_j)| <= |z_j| <= |xn| |W_z[j]| (Cauchy-Schwarz: the row
-// norm of the block's normed input from the norm kernel, the largest row norm of proj_up's z half from finalize).
-bool amax_bound_now(const lram_engine* e, int T, int slice_envs) {
-  return e->amax_bound && e->use_f16x2 && e->XN_L2.p != nullptr && gn_fused(e, T) && !gate_in_pass(e, T) && e->front_multi &&
-         slice_envs >= e->front_min_envs && mlstm_front_supported(e->cfg.inner, e->cfg.n_heads, e->cfg.conv_k, T);  // (max |xa| comes from the multi-env front end)
 }
 
 void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl) {
@@ -1084,7 +953,6 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   const size_t r0 = (size_t)sl.b0 * T, b0 = sl.b0;
   const BlockWeights& w = e->bw[i];
   BlockState& st = e->st[i];
-  const bool a3 = a3_for(e, w.proj_up, rows, D, D);  // the norm then writes the GEMM's operand planes, no fp32 copy
   float* amx = e->use_f16x2 ? e->AMX_XN.p + r0 : nullptr;  // the norm hands proj_up's operand row maxima over
   // proj_up in two halves: the x_m half feeds the conv / q / k / v front end and is on the block's critical path; the
   // z half is only needed by the output gate after the state pass and is issued beside it (mlstm_up_z)
@@ -1092,7 +960,7 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = w.proj_up, up.ldw = D, up.c = e->U.p + r0 * e->ucols, up.ldc = 2 * inner;
   up.m = rows, up.n = split_up_now(e) ? inner : 2 * inner, up.k = D;
   if (gn_fused(e, T) && !split_up_now(e)) up.act_silu_from = inner;  // the z half is stored as silu(z)
-  if (!a3 && !split_up_now(e) && !amax_bound_now(e, T, sl.nb) && takes_skinny_with_norm(e, up)) {  // (the bound needs the norm kernel's row norms)
+  if (!split_up_now(e) && takes_skinny_with_norm(e, up)) {
     // few rows: the norm runs in the projection's prologue (each workgroup normalises its 32 rows in registers)
     up.a = e->X.p + r0 * D, up.norm_g = w.norm_g, up.norm_b = w.norm_b, up.norm_eps = c.ln_eps, up.norm_rms = c.norm_is_rms;
     launch_gemm_skinny(up, sl.s);
@@ -1100,16 +968,14 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   } else {
     // f16x2 with both operands pre-split: the norm writes the two operand planes (into XN's memory: 2 x 2 bytes per
     // element) and the rows' inverse scales (into AMX_XN) instead of fp32 + row maxima; both halves of proj_up read them
-    const bool ps = !a3 && presplit_for(e, w.proj_up, rows, inner, D);
+    const bool ps = presplit_for(e, w.proj_up, rows, inner, D);
     uint16_t* xn2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * 32;  // K-tile-major planes: [D / 32][B * T][32]
     const int64_t xn2_kt = ps ? (int64_t)(e->XN2.n / D) * 32 : 0;
-    launch_row_norm(e->X.p + r0 * D, D, (a3 || ps) ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
-                    c.norm_is_rms, sl.s, nullptr, a3 ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, ps ? nullptr : amx,
-                    nullptr, ps ? xn2 : nullptr, (int64_t)e->XN2.n, ps ? amx : nullptr,
-                    amax_bound_now(e, T, sl.nb) ? e->XN_L2.p + r0 : nullptr, xn2_kt);
+    launch_row_norm(e->X.p + r0 * D, D, ps ? nullptr : e->XN.p + r0 * D, D, w.norm_g, w.norm_b, rows, D, c.ln_eps,
+                    c.norm_is_rms, sl.s, nullptr, ps ? nullptr : amx, nullptr, ps ? xn2 : nullptr, (int64_t)e->XN2.n,
+                    ps ? amx : nullptr, xn2_kt);
     up.a_amax = amx;
     if (ps) up.a = nullptr, up.a_amax = nullptr, up.a2 = xn2, up.a2_plane = (int64_t)e->XN2.n, up.a2_kt = xn2_kt, up.a2_inv = amx;
-    if (a3) up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
     gemm(e, up, sl.s);
   }
   if (e->front_multi && lean_front(e, T) && sl.nb >= e->front_min_envs && e->gate_coef[i].p != nullptr &&
@@ -1120,7 +986,6 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     fa.n_state = st.n.p + b0 * inner, fa.m_state = st.m.p + b0 * NH;
     fa.conv_w = w.conv_w, fa.conv_b = w.conv_b, fa.wq = w.wq, fa.wk = w.wk, fa.gc = e->gate_coef[i].p, fa.bi = w.bi, fa.bf = w.bf;
     fa.xa = e->XA.p + r0 * e->icols, fa.scal = e->SCAL.p + r0 * NH * 4, fa.reset = reset ? reset + b0 : nullptr;
-    if (amax_bound_now(e, T, sl.nb)) fa.xa_amax = e->AMX_H.p + r0 * NH;
     fa.B = sl.nb, fa.T = T, fa.inner = inner, fa.NH = NH, fa.K = c.conv_k;
     launch_mlstm_front(fa, sl.s);
     return;
@@ -1153,9 +1018,7 @@ void mlstm_up_z(lram_engine* e, int i, int T, const Slice& sl) {
   up.a = e->XN.p + r0 * D, up.lda = D, up.w = e->bw[i].proj_up + (size_t)inner * D, up.ldw = D;
   up.c = e->U.p + r0 * e->ucols + inner, up.ldc = 2 * inner, up.m = rows, up.n = inner, up.k = D;
   if (e->use_f16x2) up.a_amax = e->AMX_XN.p + r0;  // written by this block's norm launch (mlstm_front)
-  if (a3_for(e, e->bw[i].proj_up, rows, D, D)) {
-    up.a3 = e->XN3 + r0 * D, up.a3_plane = (int64_t)e->xn3_plane;
-  } else if (presplit_for(e, e->bw[i].proj_up, rows, inner, D)) {  // (same decision as mlstm_front: XN holds operand planes)
+  if (presplit_for(e, e->bw[i].proj_up, rows, inner, D)) {  // (same decision as mlstm_front: XN2 holds operand planes)
     up.a = nullptr, up.a_amax = nullptr;
     up.a2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * 32, up.a2_plane = (int64_t)e->XN2.n, up.a2_kt = (int64_t)(e->XN2.n / D) * 32;
     up.a2_inv = e->AMX_XN.p + r0;
@@ -1176,7 +1039,7 @@ void mlstm_cell(lram_engine* e, int i, int T, const uint8_t* reset, const Slice&
   // workgroups of the other slice do).  Measured on MI355X at B=4096/16M: 1.61 ms -> 1.47 ms per launch
   // (5.5 -> 6.0 TB/s) standalone; see DESIGN.md section 6.
   const long wgs = (long)sl.nb * NH * ((DH % 256 == 0) ? DH / 256 : (DH % 128 == 0) ? DH / 128 : DH / 64);
-  ca.min_lds_bytes = e->cell_lds_pad >= 0 ? e->cell_lds_pad : (wgs >= 1024 ? 84 * 1024 : 0);
+  ca.min_lds_bytes = wgs >= 1024 ? 84 * 1024 : 0;
   ca.unroll = e->cell_unroll;
   if (T > kMaxTokens) {
     ca.amat = e->AMAT.p + b0 * NH * kChunkMaxTokens * kChunkMaxTokens;
@@ -1197,25 +1060,7 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
     GemmArgs dn;
     dn.a = e->H.p + r0 * e->icols, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
     dn.m = rows, dn.n = D, dn.k = inner;
-    if (gate_in_pass(e, T)) {  // H is gated already; its row maxima came with it, one per head
-      if (e->use_f16x2) dn.a_amax = e->AMX_H.p + r0 * NH, dn.amax_parts = NH;
-    } else if (e->G2.p != nullptr && presplit_for(e, w.proj_down, rows, D, inner)) {
-      // the gated operand split ONCE per row (H * silu(z) -> two f16 planes + inverse row scales: one row kernel in place of
-      // the row-maximum launch) instead of in every workgroup of every N tile while it is staged
-      uint16_t* g2 = reinterpret_cast<uint16_t*>(e->G2.p) + r0 * 32;  // K-tile-major planes
-      const int64_t g2_kt = (int64_t)(e->G2.n / inner) * 32;
-      float* inv = e->AMX_H.p + r0;
-      launch_row_split_f16x2(e->H.p + r0 * e->icols, inner, e->U.p + r0 * e->ucols + inner, 2 * inner, rows, inner, g2, g2_kt,
-                             (int64_t)e->G2.n, inv, sl.s);
-      dn.a = nullptr, dn.a2 = g2, dn.a2_plane = (int64_t)e->G2.n, dn.a2_kt = g2_kt, dn.a2_inv = inv;
-    } else {
-      dn.gate = e->U.p + r0 * e->ucols + inner, dn.ldg = 2 * inner;
-      if (amax_bound_now(e, T, sl.nb)) {  // an upper bound of the gated rows' maxima, assembled by the GEMM's prologue
-        dn.a_amax = e->AMX_H.p + r0 * NH, dn.amax_parts = NH;
-        dn.a_amax_mul = e->XN_L2.p + r0, dn.a_amax_scale = 1.02f * e->z_norm_max[i];
-        dn.a_amax_c0 = e->h_bound_c0[i], dn.a_amax_c1 = e->h_bound_c1[i];
-      }
-    }
+    dn.gate = e->U.p + r0 * e->ucols + inner, dn.ldg = 2 * inner;
     gemm(e, dn, sl.s);
     return;
   }
@@ -1223,13 +1068,10 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
   ga.h = e->H.p + r0 * e->icols, ga.gamma = w.on_g, ga.beta = w.on_b, ga.skip = w.skip, ga.xa = e->XA.p + r0 * e->icols;
   ga.u = e->U.p + r0 * e->ucols, ga.out = e->G.p + r0 * e->icols, ga.rows = rows, ga.NH = NH, ga.DH = DH, ga.mode = 0;
   ga.eps = c.ln_eps;
-  const bool a3 = a3_for(e, w.proj_down, rows, inner, inner);
-  if (a3) ga.out = nullptr, ga.planes = e->G3 + r0 * e->icols, ga.plane_stride = (int64_t)e->g3_plane;
   launch_group_norm(ga, sl.s);
   GemmArgs dn;
   dn.a = e->G.p + r0 * e->icols, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
   dn.m = rows, dn.n = D, dn.k = inner;
-  if (a3) dn.a3 = e->G3 + r0 * e->icols, dn.a3_plane = (int64_t)e->g3_plane;
   gemm(e, dn, sl.s);
 }
 
@@ -1265,21 +1107,11 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   bool tab_aligned = true;
   for (int g = 0; g < 4; ++g)
     tab_aligned = tab_aligned && ((reinterpret_cast<uintptr_t>((g < 2) ? XC : XN) | reinterpret_cast<uintptr_t>(w.gate_w[g])) & 15) == 0;
-  if (e->slstm_gates_one && tab_aligned && (takes_skinny(e, g4) || gates_big)) {
+  if (tab_aligned && (takes_skinny(e, g4) || gates_big)) {
     for (int g = 0; g < 4; ++g)
       g4.a_tab[g] = (g < 2) ? XC : XN, g4.w_tab[g] = w.gate_w[g], g4.c_tab[g] = gates + (int64_t)g * Hs;
     launch_gemm_skinny(g4, s);
     count_gemm(e, 3, g4);
-  } else if (e->slstm_gw[i].p != nullptr && e->use_bf16x3) {
-    for (int pr = 0; pr < 2; ++pr) {  // pair 0: i, f from the conv branch; pair 1: z, o from the norm
-      GemmArgs ga;
-      ga.a = pr == 0 ? XC : XN, ga.lda = D, ga.sA1 = 0, ga.sA2 = SDH;
-      ga.w = e->slstm_gw[i].p + (size_t)pr * 2 * NH * SDH * SDH, ga.ldw = SDH;
-      ga.sW1 = (int64_t)NH * SDH * SDH, ga.sW2 = (int64_t)SDH * SDH;
-      ga.c = gates + (int64_t)pr * 2 * Hs, ga.ldc = 4 * Hs, ga.sC1 = Hs, ga.sC2 = SDH;
-      ga.m = rows, ga.n = SDH, ga.k = SDH, ga.nb1 = 2, ga.nb2 = NH;
-      gemm(e, ga, s);
-    }
   } else {
     for (int g = 0; g < 4; ++g) {
       GemmArgs ga;
@@ -1290,11 +1122,11 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
       gemm(e, ga, s);
     }
   }
-  // few env rows (slstm_fused_min .. slstm_fused_rows): recurrent projection + pointwise cell as ONE lean launch per token instead of a
+  // few env rows (up to slstm_fused_rows): recurrent projection + pointwise cell as ONE lean launch per token instead of a
   // batched matrix-core GEMM (fixed latency of a 128-row tile) and the pointwise kernel
   // (measured, same box each: 16M 1 env +1.9 %, 8 +4.2 %, 12 +6.6 %, 32 +6.0 %, 128 +3.3 %, 512-env slices +1.6 %, 1024-env
   // slices +-0; 206M 16 envs +6.1 %, 64 +2.9 %, 256-env slices -1.4 %: the row limit scales with 128 / head dim)
-  const bool tok_fused = e->slstm_fused_rows > 0 && sl.nb >= e->slstm_fused_min &&
+  const bool tok_fused = e->slstm_fused_rows > 0 &&
                          (int64_t)sl.nb * std::max(SDH, 128) <= (int64_t)e->slstm_fused_rows * 128 && slstm_token_supported(Hs, NH);
   for (int t = 0; tok_fused && t < T; ++t) {
     SlstmTokenArgs ta;
@@ -1338,7 +1170,7 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
     launch_gemm_skinny(up, s);
     count_gemm(e, 3, up);
   } else {
-    launch_row_norm(X, D, XN, D, w.ffn_norm_g, w.ffn_norm_b, rows, D, c.ln_eps, c.norm_is_rms, s, nullptr, nullptr, 0, amx);
+    launch_row_norm(X, D, XN, D, w.ffn_norm_g, w.ffn_norm_b, rows, D, c.ln_eps, c.norm_is_rms, s, nullptr, amx);
     up.a_amax = amx;
     gemm(e, up, s);
   }
@@ -1367,7 +1199,6 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
       e->lazy_compact = false;
     }
     const int c_due = (P - (int)(e->lazy_step % P)) % P;
-    e->lazy_due_bound = e->lazy_bound[c_due];  // pending tokens of the envs this step's compact fold covers, at most
     for (int cls = 0; cls < P; ++cls) {
       if (cls == c_due)
         e->lazy_bound[cls] = 0;
@@ -1377,62 +1208,36 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
     }
   }
   // This step's folds depend on nothing this step computes (window rows, coefficients and counts are last step's).
-  // They run on their own stream, one block ahead of the cells: block i's cells wait for fold(i), and fold(i + 1) is
-  // enqueued right then, so it streams beside the cells of block i (the read-only cell pass leaves HBM headroom).
-  // fold + readout: no separate fold schedule at all, each slice's fold is launched right ahead of its read pass
-  const bool fused = lazy && e->fold_fused && e->YPART.p != nullptr && T <= 4;
-  hipStream_t fs = hbm;
-  if (lazy && (!fused || e->fold_fused_stream) && sl.size() > 1) {
-    if (!e->fold_stream) LRAM_HIP_CHECK(hipStreamCreateWithFlags(&e->fold_stream, hipStreamNonBlocking));
-    fs = e->fold_stream;
-    stream_after(e, fs, hbm);  // hbm was forked from the caller's stream: inherit that dependency
-  }
+  // Two slices: they go onto the state-pass stream itself, into the two stretches of a step where that stream has nothing to
+  // run -- fold_bubbles of them before the first read pass (the step's front end and block 0's projections are still under
+  // way), the rest while both slices are inside an sLSTM block -- instead of beside the read passes, which they slow down.
+  // One slice (everything on the caller's stream): fold(i) right ahead of block i.
+  // (Measured and removed, profiles/EXPERIMENTS.md: folds on their own stream one block ahead of the cells, every fold queued
+  // at the step start, folds fused with the readout of the envs they rewrite, gaps / staggered front ends.)
+  const bool bubbles = lazy && sl.size() > 1;
+  std::vector<char> folded(c.n_blocks, 0);
   auto launch_folds = [&](int i) {  // one launch per block over all env slots: folds do not care about the slices
     MlstmLazyArgs la = lazy_args(e, i, T, reset, 0, e->B);
-    la.compact = e->lazy_compact ? 1 : 0, la.fold_wmax = e->lazy_compact ? e->lazy_due_bound : 0;
-    prof_record(e, fs, true, true);
-    launch_mlstm_lazy_fold(la, fs);
-    prof_record(e, fs, false, true);
+    la.compact = e->lazy_compact ? 1 : 0;
+    prof_record(e, hbm, true, true);
+    launch_mlstm_lazy_fold(la, hbm);
+    prof_record(e, hbm, false, true);
+    folded[i] = 1;
   };
   auto next_mlstm = [&](int i) {
     for (int k = i + 1; k < c.n_blocks; ++k)
       if (!c.block_is_slstm[k]) return k;
     return -1;
   };
-  // fold_ahead: every block's fold is queued when the step starts (own stream, one event per block), so the folds
-  // stream through HBM while the state pass has nothing to do -- the first front end of the step and the sLSTM
-  // blocks -- instead of one block ahead of the cells, beside them.
-  const bool fold_ahead = lazy && !fused && fs != hbm && e->fold_ahead;
-  // fold_bubbles: the folds go onto the state-pass stream itself, into the two stretches of a step where that stream has
-  // nothing to run -- before the first read pass (the step's front end and block 0's projections are still under way) and
-  // while both slices are inside an sLSTM block -- instead of beside the read passes, which they slow down.
-  const int fold_bubbles = (lazy && !fused && fs != hbm && !fold_ahead) ? e->fold_bubbles : 0;
-  std::vector<char> folded(c.n_blocks, 0);
-  auto launch_folds_on_hbm = [&](int i) {
-    MlstmLazyArgs la = lazy_args(e, i, T, reset, 0, e->B);
-    la.compact = e->lazy_compact ? 1 : 0, la.fold_wmax = e->lazy_compact ? e->lazy_due_bound : 0;
-    prof_record(e, hbm, true, true);
-    launch_mlstm_lazy_fold(la, hbm);
-    prof_record(e, hbm, false, true);
-    folded[i] = 1;
-  };
-  std::vector<hipEvent_t> fold_done(c.n_blocks, nullptr);
-  if (fold_bubbles > 0) {
+  if (bubbles) {
     int k = 0;
-    for (int i = next_mlstm(-1); i >= 0 && k < fold_bubbles; i = next_mlstm(i), ++k) launch_folds_on_hbm(i);
-  } else if (fold_ahead) {
-    for (int i = next_mlstm(-1); i >= 0; i = next_mlstm(i)) {
-      launch_folds(i);
-      fold_done[i] = record_on(e, fs);
-    }
-  } else if (lazy && !fused && next_mlstm(-1) >= 0) {
-    launch_folds(next_mlstm(-1));
+    for (int i = next_mlstm(-1); i >= 0 && k < lram_engine::fold_bubbles; i = next_mlstm(i), ++k) launch_folds(i);
   }
   for (int i = 0; i < c.n_blocks; ++i) {
     if (c.block_is_slstm[i]) {
       // (enqueued BEFORE the sLSTM block's ~50 launches: with short kernels the host is only just ahead of the device
       // there, and folds queued behind them reached the state-pass stream 0.26 ms after it had gone idle -- 206M, 512 slots)
-      if (fold_bubbles > 0) {
+      if (bubbles) {
         // the folds still outstanding run behind the previous block's read passes, shared out over this and the later sLSTM
         // blocks of the stack (206M: three stretches, five folds each, instead of fifteen in the first and none in the
         // other two); at least the blocks whose read passes come before the next sLSTM block
@@ -1440,29 +1245,17 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
         for (int k = next_mlstm(i); k >= 0; k = next_mlstm(k)) left += folded[k] ? 0 : 1;
         for (int k = i; k < c.n_blocks; ++k) stretches += c.block_is_slstm[k] ? 1 : 0;
         for (int k = i + 1; k < c.n_blocks && !c.block_is_slstm[k]; ++k) must += folded[k] ? 0 : 1;
-        int take = std::max(0, left - e->fold_gaps);
-        if (e->fold_spread && stretches > 1) take = std::max((take + stretches - 1) / stretches, std::min(must, take));
+        int take = left;
+        if (stretches > 1) take = std::max((take + stretches - 1) / stretches, std::min(must, take));
         for (int k = next_mlstm(i); k >= 0 && take > 0; k = next_mlstm(k))
-          if (!folded[k]) launch_folds_on_hbm(k), --take;
+          if (!folded[k]) launch_folds(k), --take;
       }
       for (const Slice& x : sl) slstm_block(e, i, T, reset, x);
       continue;
     }
-    if (fold_bubbles > 0) {
-      if (!folded[i]) launch_folds_on_hbm(i);  // (stacks without an sLSTM block: one fold ahead of its read passes)
-    } else if (fold_ahead) {
-      LRAM_HIP_CHECK(hipStreamWaitEvent(hbm, fold_done[i], 0));  // fold(i) done before cell(i)
-    } else if (lazy && !fused) {
-      stream_after(e, hbm, fs);  // fold(i) done before cell(i)
-      const int nxt = next_mlstm(i);
-      if (nxt >= 0) launch_folds(nxt);
-    }
-    hipEvent_t front_done = nullptr;
+    if (lazy && !folded[i]) launch_folds(i);  // (one slice, or a stack without an sLSTM block: the fold ahead of its read passes)
     for (const Slice& x : sl) {
-      if (e->front_stagger && i == next_mlstm(-1) && front_done != nullptr)
-        LRAM_HIP_CHECK(hipStreamWaitEvent(x.s, front_done, 0));
       mlstm_front(e, i, T, reset, x);
-      if (e->front_stagger && i == next_mlstm(-1) && sl.size() > 1) front_done = record_on(e, x.s);
       if (lazy) {
         // lazy matrix memory: on the HBM stream the read-only pass with the window scores, the window attention and the
         // step's bookkeeping
@@ -1472,30 +1265,13 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
         la.scal = e->SCAL.p + r0 * c.n_heads * 4, la.h = e->H.p + r0 * e->icols;
         // the read-only pass runs best with two workgroups per CU (one's prologue / epilogue under the other's
         // stream; 362k vs 308k env-steps/s at B = 4096 against the single-workgroup cap the read-modify-write kernel likes)
-        la.min_lds_bytes = e->cell_lds_pad >= 0 ? e->cell_lds_pad : 0;
+        la.min_lds_bytes = 0;
         if (!mlstm_lazy_fused_scores(la.DH)) launch_mlstm_lazy_book(la, x.s);  // scores beside the front end
         if (lean_front(e, T)) {
           const BlockWeights& w = e->bw[i];
           la.lean_xa = e->XA.p + r0 * e->icols, la.lean_u = e->U.p + r0 * e->ucols;
           la.lean_wq = w.wq, la.lean_wk = w.wk, la.lean_wv = w.wv;
           if (gn_fused(e, T)) la.gn_g = w.on_g, la.gn_b = w.on_b, la.gn_skip = w.skip, la.gn_eps = c.ln_eps;
-          if (gate_in_pass(e, T)) {
-            la.gn_gate = e->U.p + r0 * e->ucols + c.inner, la.gn_ldg = 2 * c.inner;
-            la.gn_amax = e->AMX_H.p + r0 * c.n_heads;
-          }
-        }
-        if (fused) {  // this slice's due envs: C_base <- g C_base + window, and q . C_new for the read pass, in one pass
-          la.ypart = e->YPART.p + (size_t)x.b0 * c.n_heads * (la.DH / 64) * T * la.DH;
-          MlstmLazyArgs fa = la;
-          fa.compact = e->lazy_compact ? 1 : 0;
-          // on the fold stream (fs != hbm): as soon as the slice's front end is through, beside whatever read pass is
-          // running, instead of in the state-pass queue between that pass and this slice's own
-          if (fs != hbm) stream_after(e, fs, x.s);
-          else stream_after(e, hbm, x.s);
-          prof_record(e, fs, true, true);
-          launch_mlstm_lazy_fold(fa, fs);
-          prof_record(e, fs, false, true);
-          if (fs != hbm) stream_after(e, hbm, fs);
         }
         stream_after(e, hbm, x.s);
         prof_record(e, hbm, true);
@@ -1512,7 +1288,6 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
     }
     for (const Slice& x : sl) mlstm_back(e, i, T, x);
   }
-  if (lazy && fs != hbm) stream_after(e, hbm, fs);
   if (lazy) {
     ++e->lazy_step;
     e->lazy_dirty = true;
@@ -1549,7 +1324,6 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   // only layer 0 starts the episode from an empty state
   const uint8_t* rs = (reset && !(e->compat_stale && i > 0)) ? reset + b0 : nullptr;
   hipStream_t gs = sl.s;
-  const bool a3_in = a3_for(e, w.in_proj, rows, D, D), a3_out = a3_for(e, w.out_proj, rows, di, di);
   // f16x2 projections: the kernels that produce their operands hand the row maxima over -- the norm writes XN's (one
   // wave per row), the conv and the state-update kernels one partial maximum per wave (d_inner / 64 per row, plain
   // stores; the GEMM's prologue takes their maximum).  Atomic maxima were measured first: +20 us on the conv launch,
@@ -1562,12 +1336,11 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   float* amx_xa = amx ? e->AMX_XA.p + r0 * parts : nullptr;
   float* amx_h = amx ? e->AMX_H.p + r0 * parts : nullptr;
   // in_proj with both operands pre-split: the norm writes XN as two f16 planes + inverse row scales (see mlstm_front)
-  const bool ps_in = !a3_in && amx && presplit_for(e, w.in_proj, rows, 2 * di, D);
+  const bool ps_in = amx && presplit_for(e, w.in_proj, rows, 2 * di, D);
   uint16_t* xn2 = reinterpret_cast<uint16_t*>(e->XN2.p) + r0 * 32;  // K-tile-major planes: [D / 32][B * T][32]
   const int64_t xn2_kt = ps_in ? (int64_t)(e->XN2.n / D) * 32 : 0;
   if (stage == 0) {
-    launch_add_rms_norm(X, RES_in, RES_out, (a3_in || ps_in) ? nullptr : XN, w.norm_g, rows, D, c.norm_eps, sl.s,
-                        a3_in ? e->XN3 + r0 * D : nullptr, (int64_t)e->xn3_plane, ps_in ? nullptr : amx_xn,
+    launch_add_rms_norm(X, RES_in, RES_out, ps_in ? nullptr : XN, w.norm_g, rows, D, c.norm_eps, sl.s, ps_in ? nullptr : amx_xn,
                         ps_in ? xn2 : nullptr, (int64_t)e->XN2.n, ps_in ? amx_xn : nullptr, xn2_kt);
   } else if (stage == 1) {
     MambaConvArgs ca;
@@ -1580,7 +1353,6 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     sa.A_log = w.A_log, sa.Dp = w.Dp, sa.xz = U, sa.y = H, sa.reset = rs;
     sa.B = sl.nb, sa.T = T, sa.d_inner = di, sa.N = N, sa.R = R, sa.amax = amx_h;
     if (dt_fused) sa.dt_wt = e->dt_wt[i].p, sa.dtp = nullptr;
-    if (a3_out) sa.y = nullptr, sa.y3 = e->G3 + r0 * di, sa.y3_plane = (int64_t)e->g3_plane;
     prof_record(e, sl.s, true);
     launch_mamba_ssm(sa, sl.s);
     prof_record(e, sl.s, false);
@@ -1590,7 +1362,6 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     in.a = XN, in.lda = D, in.w = w.in_proj, in.ldw = D, in.c = U, in.ldc = 2 * di, in.bias = w.in_proj_b;
     in.m = rows, in.n = 2 * di, in.k = D, in.a_amax = amx_xn;
     if (ps_in) in.a = nullptr, in.a_amax = nullptr, in.a2 = xn2, in.a2_plane = (int64_t)e->XN2.n, in.a2_kt = xn2_kt, in.a2_inv = amx_xn;
-    if (a3_in) in.a3 = e->XN3 + r0 * D, in.a3_plane = (int64_t)e->xn3_plane;
     gemm(e, in, gs);
   } else if (stage == 1) {
     GemmArgs xp;
@@ -1607,7 +1378,6 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     GemmArgs op;
     op.a = H, op.lda = di, op.w = w.out_proj, op.ldw = di, op.c = X, op.ldc = D, op.bias = w.out_proj_b;
     op.m = rows, op.n = D, op.k = di, op.a_amax = amx_h, op.amax_parts = amx ? parts : 1;
-    if (a3_out) op.a3 = e->G3 + r0 * di, op.a3_plane = (int64_t)e->g3_plane;
     gemm(e, op, gs);
   }
 }
@@ -1728,20 +1498,19 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
           gemm(e, ge, x.s);
         }
         // (a single timestep per call: the scalar tokens are built by the embed_ln launch below)
-        if (Lc > 1 || T != 3 || !e->embed_fuse)
+        if (Lc > 1 || T != 3)
           launch_embed_scalars(Xj, rtg + b0 * L + l + j, rew + b0 * L + l + j, L, e->w_rtg, e->b_rtg, e->w_rew, e->b_rew,
                                x.nb, Tc, D, x.s);
       }
       // embed_ln in place; single env-steps of small batches also keep a copy for lram_get_taps (written by the same launch)
       ScalarTokens stok;
-      const bool stok_on = Lc == 1 && T == 3 && e->embed_fuse;
+      const bool stok_on = Lc == 1 && T == 3;
       if (stok_on) {
         stok.rtg = rtg + b0 * L + l, stok.rew = rew + b0 * L + l, stok.in_stride = L, stok.T = T;
         stok.w_rtg = e->w_rtg, stok.b_rtg = e->b_rtg, stok.w_rew = e->w_rew, stok.b_rew = e->b_rew;
       }
       launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s,
-                      (L == 1 && e->B <= kTokenTapMaxBatch) ? e->TOK.p + r0 * D : nullptr, nullptr, 0, nullptr,
-                      stok_on ? &stok : nullptr);
+                      (L == 1 && e->B <= kTokenTapMaxBatch) ? e->TOK.p + r0 * D : nullptr, nullptr, stok_on ? &stok : nullptr);
     }
     run_stack(e, Tc, l == 0 ? reset : nullptr, sl, hbm);
   }
@@ -1856,46 +1625,24 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     auto e = std::make_unique<lram_engine>();
     e->cfg = *cfg;
     e->device = device;
-    if (const char* v = std::getenv("LRAM_CELL_LDS_PAD_KB")) e->cell_lds_pad = std::atoi(v) * 1024;
-    if (const char* v = std::getenv("LRAM_CELL_UNROLL")) e->cell_unroll = std::atoi(v);
+    // Environment knobs (measurement / test switches; the table is in DESIGN.md section 5)
     if (const char* v = std::getenv("LRAM_PREFILL_CHUNK")) e->chunk_prefill = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_STATE")) {
       const std::string m(v);
       e->lazy_mode = m == "lazy" ? 1 : (m == "eager" || m == "materialised" || m == "materialized") ? 0 : 2;
     }
+    if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_F16_MIN_ROWS")) e->f16x2_min_rows = std::max(9, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_GEMM_PRESPLIT")) e->gemm_presplit = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_COMPAT_SHARE")) e->compat_share = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_MAMBA_DT_FUSE")) e->mamba_dt_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
-    if (const char* v = std::getenv("LRAM_LEAN_FRONT")) e->lean_front = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_GEMM_A3")) e->use_a3 = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_SPLIT_UP")) e->split_up = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_GATE_IN_PASS")) e->gate_in_pass = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_FOLD_AHEAD")) e->fold_ahead = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_FOLD_BUBBLES")) e->fold_bubbles = std::max(0, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_FOLD_SPREAD")) e->fold_spread = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_SLSTM_FUSED_MIN")) e->slstm_fused_min = std::max(1, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_ROWS")) e->gemm_skinny_rows = std::max(0, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_K")) e->gemm_skinny_k = std::max(0, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_SLSTM_GATES_ROWS")) e->slstm_gates_rows = std::max(0, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_SLSTM_GATES_ONE")) e->slstm_gates_one = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_EMBED_FUSE")) e->embed_fuse = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_NORM")) e->gemm_skinny_norm = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_MIN")) e->gemm_skinny_min = std::max(1, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_STREAM_PRIO")) e->stream_prio = std::max(0, std::min(3, std::atoi(v)));
-    if (const char* v = std::getenv("LRAM_FOLD_FUSED")) e->fold_fused = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_FOLD_FUSED_STREAM")) e->fold_fused_stream = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_FOLD_GAPS")) e->fold_gaps = std::max(0, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_FRONT_STAGGER")) e->front_stagger = std::atoi(v);
-    if (const char* v = std::getenv("LRAM_FRONT_MULTI")) e->front_multi = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_SLSTM_GATES_PAIR")) e->slstm_gates_pair = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_GEMM_PRESPLIT")) e->gemm_presplit = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_DOWN_PRESPLIT")) e->down_presplit = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_AMAX_BOUND")) e->amax_bound = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_ROWS")) e->gemm_skinny_rows = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_GEMM_SKINNY_MIN")) e->gemm_skinny_min = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_FRONT_MULTI")) e->front_multi = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FRONT_MIN_ENVS")) e->front_min_envs = std::max(1, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_LAZY_PERIOD")) e->lazy_period = std::max(1, std::min(14, std::atoi(v)));
     *out = e.release();
   });
 }
@@ -2147,6 +1894,26 @@ int32_t lram_set_state_mode(lram_engine* e, int32_t mode, int32_t fold_period) {
 
 int32_t lram_get_state_mode(const lram_engine* e) { return (e != nullptr && e->lazy && e->lazy_ready) ? 1 : 0; }
 
+int32_t lram_lazy_peek(lram_engine* e, int32_t block, int32_t which, float* dev_dst, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0 && dev_dst, "lram_lazy_peek: bad argument");
+    LRAM_REQUIRE(e->lazy && e->lazy_ready, "lram_lazy_peek: the lazy representation is not in effect");
+    LRAM_REQUIRE(block >= 0 && block < e->cfg.n_blocks && !e->cfg.block_is_slstm[block] && which >= 0 && which <= 2,
+                 "lram_lazy_peek: no such tensor");
+    LRAM_HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t B = e->B, NH = e->cfg.n_heads;
+    const int side = (int)(e->lazy_step & 1);  // what the next step reads = what the last one wrote
+    if (which == 0) {
+      LRAM_HIP_CHECK(hipMemcpyAsync(dev_dst, e->st[block].gsc.p + side * B * NH, B * NH * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else if (which == 1) {
+      LRAM_HIP_CHECK(hipMemcpyAsync(dev_dst, e->st[block].m.p, B * NH * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+      launch_lazy_counts_as_float(reinterpret_cast<const int32_t*>(e->LZ_COUNT.p) + side * B, dev_dst, (int)B, s);
+    }
+  });
+}
+
 int32_t lram_set_micro_batches(lram_engine* e, int32_t n) {
   return guarded([&] {
     LRAM_REQUIRE(e != nullptr && n >= 0 && n <= 8, "lram_set_micro_batches: n must be in 0..8 (0 = auto)");
@@ -2296,9 +2063,6 @@ int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int
       g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
       g.residual = accumulate ? dev_c : nullptr;
       g.m = m, g.n = n, g.k = k, g.w2 = planes, g.w2_plane = (int64_t)numel, g.w2_kt = 32 * (int64_t)n, g.w_inv = scales, g.a_amax = scales + n;
-      // test hook: the row maxima handed over as an upper bound that is `slack` times too large (the engine's producers may
-      // hand over bounds instead of maxima: GemmArgs::a_amax_mul / a_amax_scale)
-      if (const char* v = std::getenv("LRAM_TEST_AMAX_SLACK")) g.a_amax_scale = std::max(1.f, (float)std::atof(v));
       launch_gemm_f16x2(g, s);
       LRAM_HIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {
@@ -2338,32 +2102,6 @@ int32_t lram_gemm_f16x2_presplit(const float* dev_a, int64_t lda, const float* d
       throw;
     }
     (void)hipFree(wp), (void)hipFree(ap), (void)hipFree(scales);
-  });
-}
-
-int32_t lram_gemm_bf16x3_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
-                                  const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
-  return guarded([&] {
-    LRAM_REQUIRE(ldw == k && lda == k, "lram_gemm_bf16x3_presplit: A and W must be contiguous [m, k] / [n, k]");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t nw = (size_t)n * k, na = (size_t)m * k;
-    uint16_t* planes = nullptr;
-    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&planes), 3 * (nw + na) * sizeof(uint16_t)));
-    try {
-      launch_split_bf16x3(dev_w, planes, nw, s);
-      launch_split_bf16x3(dev_a, planes + 3 * nw, na, s);  // what a producer kernel writes with split3_store
-      GemmArgs g;
-      g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
-      g.residual = accumulate ? dev_c : nullptr;
-      g.m = m, g.n = n, g.k = k, g.w3 = planes, g.w3_plane = (int64_t)nw;
-      g.a3 = planes + 3 * nw, g.a3_plane = (int64_t)na;
-      launch_gemm_bf16x3(g, s);
-      LRAM_HIP_CHECK(hipStreamSynchronize(s));
-    } catch (...) {
-      (void)hipFree(planes);
-      throw;
-    }
-    (void)hipFree(planes);
   });
 }
 

@@ -36,14 +36,13 @@ __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16&
   lo = (__bf16)r2;
 }
 
-// A_PRE: the activation operand arrives pre-split (three bf16 planes written by its producer, g.a3): staged like W with
-// 16-byte loads and conflict-free 16-byte LDS writes, no fp32 -> 3 x bf16 conversion (about a quarter of a wave's
-// instruction stream per K step) and no 8-byte plane writes in the loop.
+// (A pre-split A operand -- three bf16 planes written by its producer -- was built in round 2, measured 1-2 % slower end to end
+// than the split on the fly and removed in round 5: profiles/EXPERIMENTS.md.)
 // BM = 128: 64 x 64 per wave (2 x 2 MFMA tiles).  BM = 64: 32 x 64 per wave -- twice the workgroups for outputs with few
 // 128-wide column tiles (proj_down, out_proj, ffn_down: N = 512 .. 1280 gives 192 .. 290 tiles of 128 x 128 for 512
 // workgroup slots), 46 KB of LDS instead of 61 KB.
 // GATE: the fp32 A operand is multiplied element-wise by g.gate while it is staged (mLSTM output gate).
-template <bool HAS_BIAS, bool HAS_RES, bool A_PRE, int BM, bool GATE = false>
+template <bool HAS_BIAS, bool HAS_RES, int BM, bool GATE = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   constexpr int WM = BM / 2;          // rows per wave
   constexpr int TI = WM / 32;         // MFMA row tiles per wave
@@ -61,7 +60,6 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   const int z1 = z / g.nb2, z2 = z - z1 * g.nb2;
   const float* A = g.a + z1 * g.sA1 + z2 * g.sA2;
   const __bf16* W3 = reinterpret_cast<const __bf16*>(g.w3) + z1 * g.sW1 + z2 * g.sW2;
-  const __bf16* A3 = A_PRE ? reinterpret_cast<const __bf16*>(g.a3) + z1 * g.sA1 + z2 * g.sA2 : nullptr;
   float* C = g.c + z1 * g.sC1 + z2 * g.sC2;
   const float* R = HAS_RES ? g.residual + z1 * g.sC1 + z2 * g.sC2 : nullptr;
   const float* bias = HAS_BIAS ? g.bias + z1 * g.sBias1 + z2 * g.sBias2 : nullptr;
@@ -79,25 +77,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
   const int lr = tid >> 3;        // A: row within a 32-row slab
   const int lc = (tid & 7) << 2;  // A: k offset 0,4,..,28
   constexpr int NA = BM / 32;          // fp32 A: float4 per thread and K tile
-  constexpr int NAP = 3 * BM * 4 / 256;  // pre-split A: 16-byte chunks per thread and K tile
-  float4 ra[A_PRE ? 1 : NA];
+  float4 ra[NA];
   float4 rz[GATE ? NA : 1];
   (void)rz;
-  uint4 rap[A_PRE ? NAP : 1];
   uint4 rw[6];
   auto load_tile = [&](int k0) {
-    if (A_PRE) {
-#pragma unroll
-      for (int j = 0; j < NAP; ++j) {
-        const int q = tid + 256 * j;          // 16-byte chunk id: 3 planes x BM rows x 4 chunks
-        const int plane = q / (BM * 4), rem = q % (BM * 4);
-        const int r = rem >> 2, c = (rem & 3) << 3;
-        const int gm = m0 + r, kk = k0 + c;
-        rap[j] = (gm < g.m && kk < g.k)
-                     ? *reinterpret_cast<const uint4*>(A3 + (int64_t)plane * g.a3_plane + (int64_t)gm * g.lda + kk)
-                     : make_uint4(0u, 0u, 0u, 0u);
-      }
-    } else {
+    {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int gm = m0 + lr + 32 * i, kk = k0 + lc;
@@ -120,17 +105,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
     }
   };
   auto store_tile = [&]() {
-    if (A_PRE) {
 #pragma unroll
-      for (int j = 0; j < NAP; ++j) {
-        const int q = tid + 256 * j;
-        const int plane = q / (BM * 4), rem = q % (BM * 4);
-        const int r = rem >> 2, c = (rem & 3) << 3;
-        *reinterpret_cast<uint4*>(As + plane * APLANE + r * PITCH + c) = rap[j];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < (A_PRE ? 0 : NA); ++i) {
+    for (int i = 0; i < NA; ++i) {
       bf16x4 hi, mid, lo;
       float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
       if (GATE) xs[0] *= rz[i].x, xs[1] *= rz[i].y, xs[2] *= rz[i].z, xs[3] *= rz[i].w;
@@ -262,29 +238,25 @@ bool gemm_bf16x3_supported(const GemmArgs& g) {
          ((g.sW1 | g.sW2) & 7) == 0 && ((g.sA1 | g.sA2) & 3) == 0 && (g.w3_plane & 7) == 0;
 }
 
-template <bool A_PRE, int BM>
+template <int BM>
 static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
   const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
   dim3 block(256);
   if (hb && hr)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, A_PRE, BM>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, BM>), grid, block, 0, stream, g);
   else if (hb)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, A_PRE, BM>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, BM>), grid, block, 0, stream, g);
   else if (hr)
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, A_PRE, BM>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, BM>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, A_PRE, BM>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, BM>), grid, block, 0, stream, g);
 }
 
 void launch_gemm_bf16x3(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
   // waves inside their MFMA block issue ahead of the co-resident workgroup's staging code (s_setprio 1): Mamba-48M
-  // 319.1k -> 322.5k env-steps/s, 16M 403.8k -> 404.4k (LRAM_GEMM_PRIO=0 switches it off)
-  static const int prio = [] {
-    const char* v = std::getenv("LRAM_GEMM_PRIO");
-    return v ? std::atoi(v) : 1;
-  }();
-  g.mfma_prio = prio;
+  // 319.1k -> 322.5k env-steps/s, 16M 403.8k -> 404.4k
+  g.mfma_prio = 1;
   int S = 1;
   if (g.act_silu_from >= 0)
     g.split_k = 1, g.k_tiles_per_split = 0;  // the output activation is applied by this kernel's epilogue: K unsplit
@@ -298,42 +270,27 @@ void launch_gemm_bf16x3(const GemmArgs& g_in, hipStream_t stream) {
   // 192 tiles): 64-row tiles give twice the workgroups.  Measured standalone 67 -> 62 us (proj_down), 141 -> 101 us
   // (206M proj_down), 131 -> 117 us (Mamba out_proj); inside the two-slice pipelines, where the other slice fills the
   // chip anyway, only the narrow 16M shapes gain (+1 % end to end) while Mamba-48M and 206M lose 2.5 % to the smaller
-  // tile's lower reuse -- hence the tiles_n limit.  LRAM_GEMM_BM=64 / 128 forces one tile (measurement knob).
-  static const int force_bm = [] {
-    const char* v = std::getenv("LRAM_GEMM_BM");
-    return v ? std::atoi(v) : 0;
-  }();
-  // ... and every GEMM of at most LRAM_BF16_BM64_ROWS operand rows (default 1024: slices of up to 341 envs, where a step is a
+  // tile's lower reuse -- hence the tiles_n limit.
+  // ... and every GEMM of at most 1024 operand rows (slices of up to 341 envs, where a step is a
   // chain of short launches and twice the workgroups per launch shorten each: 16M at 192 / 256 / 341 envs +1.6 / +2.1 / +6 %,
   // Mamba-48M at 64 / 256 envs +4.7 / +7.3 %; weights above 2.5M elements -- the 206M stack -- keep the 128-row tile's reuse:
   // 128 envs -3.8 % otherwise)
-  static const int bm64_rows = [] {
-    const char* v = std::getenv("LRAM_BF16_BM64_ROWS");
-    return v ? std::atoi(v) : 1024;
-  }();
-  const bool small = force_bm == 64 || (force_bm == 0 && g.m > 64 &&
-                                        ((S == 1 && g.nb1 * g.nb2 == 1 && tiles128 < 512 && tiles_n <= 4) ||
-                                         (g.m <= bm64_rows && (int64_t)g.n * g.k <= 2500000)));
+  constexpr int bm64_rows = 1024;
+  const bool small = g.m > 64 && ((S == 1 && g.nb1 * g.nb2 == 1 && tiles128 < 512 && tiles_n <= 4) ||
+                                  (g.m <= bm64_rows && (int64_t)g.n * g.k <= 2500000));
   const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;
   dim3 grid(tiles, g.nb1 * g.nb2, S);
   if (g.gate != nullptr) {
-    LRAM_REQUIRE(g.a3 == nullptr && g.nb1 * g.nb2 == 1 && (g.ldg & 3) == 0 && g.residual != nullptr && g.bias == nullptr,
+    LRAM_REQUIRE(g.nb1 * g.nb2 == 1 && (g.ldg & 3) == 0 && g.residual != nullptr && g.bias == nullptr,
                  "gemm bf16x3: the gated operand form is the un-batched fp32-A residual GEMM (proj_down)");
     if (small)
-      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, false, 64, true>), grid, dim3(256), 0, stream, g);
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 64, true>), grid, dim3(256), 0, stream, g);
     else
-      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, false, 128, true>), grid, dim3(256), 0, stream, g);
-  } else if (g.a3 != nullptr) {
-    LRAM_REQUIRE((g.lda & 7) == 0 && (g.a3_plane & 7) == 0 && ((g.sA1 | g.sA2) & 7) == 0,
-                 "gemm bf16x3: pre-split A needs lda / plane stride / batch strides in multiples of 8");
-    if (small)
-      launch_bm<true, 64>(g, grid, stream);
-    else
-      launch_bm<true, 128>(g, grid, stream);
+      hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, 128, true>), grid, dim3(256), 0, stream, g);
   } else if (small) {
-    launch_bm<false, 64>(g, grid, stream);
+    launch_bm<64>(g, grid, stream);
   } else {
-    launch_bm<false, 128>(g, grid, stream);
+    launch_bm<128>(g, grid, stream);
   }
   LRAM_HIP_CHECK(hipGetLastError());
   if (S > 1) launch_splitk_reduce(g, stream);

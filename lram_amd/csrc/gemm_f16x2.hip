@@ -88,7 +88,6 @@ __global__ __launch_bounds__(256, (PF == 1 && !DB) ? 3 : 2) void gemm_f16x2_kern
     if (gm < g.m) {
       const float* ap = g.a_amax + (int64_t)gm * g.amax_parts;
       for (int q = 0; q < g.amax_parts; ++q) mx = fmaxf(mx, ap[q]);
-      mx = (g.a_amax_c0 + g.a_amax_c1 * mx) * (g.a_amax_mul != nullptr ? g.a_amax_mul[gm] : 1.f) * g.a_amax_scale;
     }
     srow[tid] = gm < g.m ? pow2_scale(mx) : 0.f;
     if (!DB) sinv[tid] = gm < g.m ? 1.f / pow2_scale(mx) : 0.f;  // (exact: a power of two)
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* w, int ro
 
 bool gemm_f16x2_supported(const GemmArgs& g) {
   return g.w2 != nullptr && g.w_inv != nullptr && g.nb1 * g.nb2 == 1 && (g.k & 7) == 0 && g.w2_kt >= 32 * (int64_t)g.n &&
-         (g.w2_kt & 7) == 0 && (g.lda & 3) == 0 && (g.w2_plane & 7) == 0 && g.a3 == nullptr && (g.gate == nullptr || (g.ldg & 3) == 0);
+         (g.w2_kt & 7) == 0 && (g.lda & 3) == 0 && (g.w2_plane & 7) == 0 && (g.gate == nullptr || (g.ldg & 3) == 0);
 }
 
 void launch_row_amax(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, float* amax,
@@ -409,22 +408,14 @@ static void launch_bm_pf(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 
 template <int BM, bool GATE>
 static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
-  // LRAM_F16_PF (measurement knob): K tiles of global loads in flight per workgroup (1: three workgroups per CU; 2: two)
-  static const int pf = [] {
-    const char* v = std::getenv("LRAM_F16_PF");
-    return v ? std::atoi(v) : 1;
-  }();
   // Two LDS stages + one barrier per K tile (the kernel's DB note) pay where the launch cannot fill the chip with
   // workgroups anyway -- at most one per CU: 206M proj_down (240 workgroups) 109 -> 86 us -- and lose where three
   // single-stage workgroups per CU can overlap each other's phases (16M proj_up 62 -> 75 us, Mamba in_proj 128 -> 140).
-  // LRAM_F16_DB = 0 / 1 forces either (measurement knob), default 2 = by grid size.
-  static const int db = [] {
-    const char* v = std::getenv("LRAM_F16_DB");
-    return v ? std::atoi(v) : 2;
-  }();
+  // (Two K tiles of global loads in flight per workgroup -- PF = 2 -- pushed the kernel from three workgroups per CU to two: 94 ->
+  // 118 us on proj_up; removed.)
   // (also tried for split-K launches -- Mamba's x_proj, 45 -> 35 us standalone: no end-to-end difference, 365.4k vs 365.1k)
   const long wgs = (long)grid.x * grid.y * grid.z;
-  if ((db == 1 || (db == 2 && wgs <= 256)) && !GATE) {
+  if (wgs <= 256 && !GATE) {
     const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
     dim3 block(256);
     if (hb && hr)
@@ -437,20 +428,13 @@ static void launch_bm(const GemmArgs& g, dim3 grid, hipStream_t stream) {
       hipLaunchKernelGGL((gemm_f16x2_kernel<false, false, BM, false, 2, true>), grid, block, 0, stream, g);
     return;
   }
-  if (pf == 2)
-    launch_bm_pf<BM, GATE, 2>(g, grid, stream);
-  else
-    launch_bm_pf<BM, GATE, 1>(g, grid, stream);
+  launch_bm_pf<BM, GATE, 1>(g, grid, stream);
 }
 
 // g.a_amax: per-row largest magnitude of A (of the gated rows when g.gate is set), from launch_row_amax or A's producer.
 void launch_gemm_f16x2(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
-  static const int prio = [] {
-    const char* v = std::getenv("LRAM_GEMM_PRIO");
-    return v ? std::atoi(v) : 1;
-  }();
-  g.mfma_prio = prio;
+  g.mfma_prio = 1;
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
   LRAM_REQUIRE(gemm_f16x2_supported(g) && g.a_amax != nullptr, "gemm f16x2: unsupported operand layout");
   int S = 1;
@@ -463,19 +447,11 @@ void launch_gemm_f16x2(const GemmArgs& g_in, hipStream_t stream) {
   // 64-row tiles where 128-row tiles leave workgroup slots empty (three workgroups per CU: 768 slots) and the launch is narrow, or
   // where they would leave CUs without any workgroup and K is short (1536 x 1024 x 512: 31.6 us with 96 tiles of 128 rows, 20.5
   // with 192 of 64; long-K launches: see launch_gemm_f16x2p)
-  static const int force_bm = [] {
-    const char* v = std::getenv("LRAM_GEMM_BM");
-    return v ? std::atoi(v) : 0;
-  }();
-  static const int bm64_below = [] {
-    const char* v = std::getenv("LRAM_GEMM_BM64_BELOW");
-    return v ? std::atoi(v) : 256;
-  }();
-  static const int bm64_anyk = [] {   // LRAM_GEMM_BM64_ANYK: below this many tiles 64-row tiles whatever K (under half a workgroup per CU)
-    const char* v = std::getenv("LRAM_GEMM_BM64_ANYK");
-    return v ? std::atoi(v) : 128;
-  }();
-  const bool small = force_bm == 64 || (force_bm == 0 && g.m > 64 && ((S == 1 && tiles128 < 768 && tiles_n <= 6) || ((long)tiles128 * S < bm64_below && g.k <= 768) || (long)tiles128 * S < bm64_anyk));
+  // (LRAM_GEMM_TILE = 64 / 128 forces one: the knob of launch_gemm_f16x2p)
+  const char* fv = std::getenv("LRAM_GEMM_TILE");
+  const int force_bm = fv ? std::atoi(fv) : 0;
+  constexpr int bm64_below = 256, bm64_anyk = 128;
+  const bool small = force_bm == 64 || (force_bm != 128 && g.m > 64 && ((S == 1 && tiles128 < 768 && tiles_n <= 6) || ((long)tiles128 * S < bm64_below && g.k <= 768) || (long)tiles128 * S < bm64_anyk));
   const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;
   dim3 grid(tiles, 1, S);
   gemm_choose_xcd_split(g, small ? 64 : 128, BN, 4);

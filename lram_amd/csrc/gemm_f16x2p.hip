@@ -33,20 +33,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
-constexpr int BN = 128, BK = 32;
-constexpr int PLANE = 128 * BK;      // f16 elements of one 128-row plane tile of W (8 KiB)
+constexpr int BK = 32;
 
-// BMT: tile height, 128 (64 x 64 per wave) or 64 (32 x 64 per wave: launches that would leave CUs without a workgroup)
-template <bool HAS_BIAS, bool HAS_RES, int NSTAGE, int BMT = 128>
-__global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
-  constexpr int TI = BMT / 64;                      // MFMA row tiles per wave
+// Workgroup tile = WM x WN waves, each wave a (32 TI) x 64 block of the output (TI x 2 accumulator tiles of the 32 x 32 MFMA):
+//   TI 1, 2 x 2 waves:  64 x 128  (launches that would leave CUs without a workgroup)
+//   TI 2, 2 x 2 waves: 128 x 128  (rounds 3-4: 32 KB per K tile for 96 MFMAs = 341 B of operand delivery per MFMA -- the
+//                                  kernel is bound by global -> LDS delivery, ~29 B / clock / CU out of L2, i.e. 11.8 clocks per
+//                                  MFMA against the 8 the four SIMDs need: profiles/EXPERIMENTS.md "Projection GEMM ...")
+//   TI 2, 4 x 2 waves: 256 x 128  (round 5: 48 KB per K tile for 192 MFMAs = 256 B per MFMA; 8 waves)
+//   TI 2, 4 x 4 waves: 256 x 256  (round 5: 64 KB for 384 MFMAs = 171 B per MFMA; 16 waves, one workgroup per CU)
+// The per-wave code is the same in all four; what changes is how many waves share a staged tile.
+template <bool HAS_BIAS, bool HAS_RES, int NSTAGE, int TI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 1 || WM * WN > 8) ? 4 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
+  constexpr int NW = WM * WN;                       // waves per workgroup
+  constexpr int BMT = 32 * TI * WM, BN = 64 * WN;   // workgroup tile
   constexpr int APL = BMT * BK;                     // f16 elements of one A plane tile
+  constexpr int PLANE = BN * BK;                    // ... of one W plane tile
   constexpr int STG = 2 * APL + 2 * PLANE;          // one LDS stage: A hi, A lo, W hi, W lo
   constexpr int NPA = 2 * (BMT / 16);               // 1 KiB DMA pieces of the A planes
-  constexpr int NPIECE = NPA + 16, PPW = NPIECE / 4;  // ... of a stage, per wave
+  constexpr int NPIECE = NPA + 2 * (BN / 16), PPW = NPIECE / NW;  // ... of a stage, per wave
+  static_assert(NPA % NW == 0 && NPIECE % NW == 0, "a wave's DMA pieces of one round belong to one operand");
+  static_assert(NSTAGE != 1 || BMT + BN <= 64 * NW, "scale staging: one thread per row / column of the tile");
   __shared__ __attribute__((aligned(1024))) _Float16 lds[NSTAGE * STG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   const int tiles_n = (g.n + BN - 1) / BN;
   const int tiles_m = (g.m + BMT - 1) / BMT;
@@ -67,8 +77,8 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
     else if (t < BMT + BN) scl[t] = g.w_inv[min(n0 + t - BMT, g.n - 1)];
   }
 
-  // ---- DMA sources: 32 pieces of 1 KiB per stage (4 planes x 8 row blocks of 16 rows), 8 per wave.  Wave w takes
-  // pieces w, w + 4, ...: piece p = plane (p >> 3), row block (p & 7).  Lane l fills linear position (row = 16 rb + l / 4,
+  // ---- DMA sources: pieces of 1 KiB per stage (2 A planes x BMT / 16 row blocks of 16 rows, then 2 W planes x BN / 16), PPW per
+  // wave.  Wave w takes pieces w, w + NW, ...  Lane l fills linear position (row = 16 rb + l / 4,
   // chunk position l & 3) and fetches logical chunk (l & 3) ^ ((row >> 2) & 3) of that row.  Rows beyond M / N are clamped
   // (their products land in rows / columns the epilogue drops).
   const _Float16* A2 = reinterpret_cast<const _Float16*>(g.a2);
@@ -76,10 +86,10 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
   const _Float16* src[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int p = wave + 4 * i;
+    const int p = wave + NW * i;
     const bool is_a = p < NPA;
     const int q = is_a ? p : p - NPA;                 // piece within its operand
-    const int rbs = is_a ? BMT / 16 : 8;              // row blocks per plane
+    const int rbs = is_a ? BMT / 16 : BN / 16;        // row blocks per plane
     const int plane = q / rbs, rb = q % rbs;
     const int row = 16 * rb + (lane >> 2);
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
@@ -94,8 +104,8 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
   auto dma_tile = [&](int stage, int kt) {  // (K-tile-major planes: the tile's rows of a plane are one contiguous run)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const int p = wave + 4 * i;
-      const int64_t k0 = (int64_t)kt * (4 * i < NPA ? g.a2_kt : g.w2_kt);  // (pieces 4 i .. 4 i + 3 belong to one operand)
+      const int p = wave + NW * i;
+      const int64_t k0 = (int64_t)kt * (NW * i < NPA ? g.a2_kt : g.w2_kt);  // (pieces NW i .. NW i + NW - 1 belong to one operand)
       // (LDS destination: wave-uniform base of the piece -- pieces lie in the stage in piece order: A hi, A lo, W hi, W lo;
       // the hardware adds lane * 16)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
@@ -119,11 +129,11 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
     for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        ainv_r[i][r] = g.a2_inv[min(m0 + (BMT / 2) * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh, g.m - 1)];
+        ainv_r[i][r] = g.a2_inv[min(m0 + 32 * TI * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh, g.m - 1)];
 #pragma unroll
     for (int j = 0; j < 2; ++j) winv_r[j] = g.w_inv[min(n0 + 64 * wn + 32 * j + li, g.n - 1)];
   }
-  const _Float16* a_base = lds + ((BMT / 2) * wm + li) * BK;
+  const _Float16* a_base = lds + (32 * TI * wm + li) * BK;
   const _Float16* b_base = lds + 2 * APL + (64 * wn + li) * BK;
 
   const int nk_all = g.k / BK;
@@ -156,11 +166,12 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
     if (g.mfma_prio) __builtin_amdgcn_s_setprio(0);
   };
 
+  if (NSTAGE == 1 && kt0 >= nk) __syncthreads();  // (an empty K range: the scales are still read by other threads below)
   if (NSTAGE == 2) {
     // tile kt sits in stage kt & 1 once the barrier at the top of its iteration is passed (__syncthreads drains the issuing
     // waves' DMAs: an LDS-DMA is a pending LDS write on the VM counter); the DMA of tile kt + 1 is issued right behind that
     // barrier -- every wave has then finished reading that stage (tile kt - 1) -- and is in flight under tile kt's MFMAs
-    dma_tile(0, kt0);
+    if (kt0 < nk) dma_tile(0, kt0);  // (an empty K split must not read past the operand planes)
     for (int kt = kt0; kt < nk; ++kt) {
       const int cur = (kt - kt0) & 1;
       __syncthreads();
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
     float ainv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + (BMT / 2) * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int row = m0 + 32 * TI * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
       ainv[r] = NSTAGE == 1 ? scl[row - m0] : ainv_r[NSTAGE == 1 ? 0 : i][NSTAGE == 1 ? 0 : r];
     }
 #pragma unroll
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(256, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(G
       // (per (i, j) one base pointer; the 16 rows of the accumulator tile are compile-time multiples of the row pitch from it --
       // the per-element 64-bit row * pitch products, bounds checks and libm SiLU of the first form were ~60 instructions per
       // stored value, as many in the epilogue as in the whole K loop)
-      const int row0 = m0 + (BMT / 2) * wm + 32 * i + 4 * lh;
+      const int row0 = m0 + 32 * TI * wm + 32 * i + 4 * lh;
       const bool act = g.act_silu_from >= 0 && col >= g.act_silu_from;
       const bool rows_in = row0 + 27 < g.m;  // (uniform but for tiles on the lower edge)
       if (S != nullptr) {  // raw partial sums into this split's slab [M][N]; bias / residual are applied by the reduce
@@ -262,7 +273,7 @@ bool gemm_f16x2p_supported(const GemmArgs& g) {
   return g.a2 != nullptr && g.a2_inv != nullptr && g.w2 != nullptr && g.w_inv != nullptr && g.nb1 * g.nb2 == 1 &&
          (g.k % BK) == 0 && g.w2_kt >= 32 * (int64_t)g.n && g.a2_kt >= 32 * (int64_t)g.m && (g.w2_plane & 7) == 0 && (g.a2_plane & 7) == 0 &&
          (g.w2_kt & 7) == 0 && (g.a2_kt & 7) == 0 &&
-         g.gate == nullptr && g.a3 == nullptr && (reinterpret_cast<uintptr_t>(g.a2) & 15) == 0 &&
+         g.gate == nullptr && (reinterpret_cast<uintptr_t>(g.a2) & 15) == 0 &&
          (reinterpret_cast<uintptr_t>(g.w2) & 15) == 0;
 }
 
@@ -275,35 +286,44 @@ void launch_row_split_f16x2(const float* a, int64_t lda, const float* gate, int6
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
-template <int NSTAGE, int BMT>
+template <int NSTAGE, int TI, int WM, int WN>
 static void launch_stage(const GemmArgs& g, dim3 grid, hipStream_t stream) {
   const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
-  dim3 block(256);
+  dim3 block(64 * WM * WN);
   if (hb && hr)
-    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, true, NSTAGE, BMT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, true, NSTAGE, TI, WM, WN>), grid, block, 0, stream, g);
   else if (hb)
-    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, false, NSTAGE, BMT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<true, false, NSTAGE, TI, WM, WN>), grid, block, 0, stream, g);
   else if (hr)
-    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, true, NSTAGE, BMT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, true, NSTAGE, TI, WM, WN>), grid, block, 0, stream, g);
   else
-    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, false, NSTAGE, BMT>), grid, block, 0, stream, g);
+    hipLaunchKernelGGL((gemm_f16x2p_kernel<false, false, NSTAGE, TI, WM, WN>), grid, block, 0, stream, g);
+}
+
+// Workgroup tile of a launch.  64 x 128 where 128-row tiles would leave CUs without a workgroup AND K is short (16M at 1024
+// slots: proj_up's 1536 x 1024 x 512 halves are 96 tiles of 128 x 128 -- 26.0 us -- or 192 of 64 x 128 -- 17.8 us); long-K
+// launches keep 128 rows (inside the two-slice pipeline the small tile's 1.5 x operand traffic per flop costs Mamba-48M 2.3 %
+// and the 206M stack 1.5 %: profiles/r04_ab_tile_height.txt).  256-row tiles (round 5) where they still give every CU work:
+// the kernel is bound by operand delivery, and a tile twice as high moves 3/4 (256 x 128) or 1/2 (256 x 256) of the bytes per
+// MFMA.  LRAM_GEMM_TILE (measurement knob): 64, 128, 256 (= 256 x 128), 512 (= 256 x 256) force one.
+int gemm_f16x2p_tile(const GemmArgs& g, int S) {
+  const char* fv = std::getenv("LRAM_GEMM_TILE");  // (read per launch: the bit-identity test walks through the tiles)
+  const int force = fv ? std::atoi(fv) : 0;
+  if (force == 64 || force == 128 || force == 256 || force == 512) return force;
+  const long tiles128 = (long)((g.m + 127) / 128) * ((g.n + 127) / 128);
+  if (g.m > 64 && ((tiles128 * S < 256 && g.k <= 768) || tiles128 * S < 128)) return 64;
+  return 128;
 }
 
 void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
-  static const int prio = [] {
-    const char* v = std::getenv("LRAM_GEMM_PRIO");
-    return v ? std::atoi(v) : 1;
-  }();
-  // LRAM_F16P_STAGES (measurement knob): 1 = one LDS stage, two barriers per K tile, up to four workgroups per CU;
-  // 2 = two stages, the next tile's DMA under the current tile's MFMAs, one barrier per K tile, two workgroups per CU
+  // LRAM_F16P_STAGES (measurement knob): 1 = one LDS stage, two barriers per K tile, several workgroups per CU;
+  // 2 = two stages, the next tile's DMA under the current tile's MFMAs, one barrier per K tile
   // default 0 = by grid size (same box, standalone: 16M proj_up 768 tiles 55 us with one stage / 65 with two; Mamba in_proj 576
   // tiles 67 / 80; 16M proj_down 192 tiles 50 / 40; Mamba out_proj 144 tiles 65 / 51 -- profiles/r04_gemm_f16x2p_durations.txt)
-  static const int stages_env = [] {
-    const char* v = std::getenv("LRAM_F16P_STAGES");
-    return v ? std::atoi(v) : 0;
-  }();
-  g.mfma_prio = prio;
+  const char* sv = std::getenv("LRAM_F16P_STAGES");
+  const int stages_env = sv ? std::atoi(sv) : 0;
+  g.mfma_prio = 1;
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
   LRAM_REQUIRE(gemm_f16x2p_supported(g), "gemm f16x2 (pre-split operands): unsupported operand layout");
   int S = 1;
@@ -311,34 +331,27 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
     g.split_k = 1, g.k_tiles_per_split = 0;  // output activation: K unsplit
   else
     S = gemm_choose_split_k(g);
-  // 64-row tiles where 128-row tiles would leave CUs without a workgroup AND K is short (16M at 1024 slots: proj_up's
-  // 1536 x 1024 x 512 halves are 96 tiles of 128 x 128 -- 26.0 us -- or 192 of 64 x 128 -- 17.8 us; 1024 / 2048 slots +1.0 / +1.9 %).
-  // Standalone the 64-row tiles win on every launch below ~400 tiles (Mamba's out_proj 3072 x 768 x 1536: 43 vs 51 us, the 206M
-  // proj_down 768 x 1280 x 2560: 56 vs 82 us), but inside the two-slice pipeline -- where the other slice's kernels fill the idle
-  // CUs anyway -- their 1.5 x operand traffic per flop costs Mamba-48M 2.3 % and the 206M stack 1.5 %: long-K launches keep 128 rows
-  // (profiles/r04_ab_tile_height.txt; LRAM_GEMM_BM = 64 / 128 forces either, LRAM_GEMM_BM64_BELOW moves the tile-count limit)
-  static const int force_bm = [] {
-    const char* v = std::getenv("LRAM_GEMM_BM");
-    return v ? std::atoi(v) : 0;
-  }();
-  static const int bm64_below = [] {
-    const char* v = std::getenv("LRAM_GEMM_BM64_BELOW");
-    return v ? std::atoi(v) : 256;
-  }();
-  static const int bm64_anyk = [] {   // LRAM_GEMM_BM64_ANYK: below this many tiles 64-row tiles whatever K (under half a workgroup per CU)
-    const char* v = std::getenv("LRAM_GEMM_BM64_ANYK");
-    return v ? std::atoi(v) : 128;
-  }();
-  const int tiles128 = ((g.m + 127) / 128) * ((g.n + BN - 1) / BN);
-  const bool bm64 = force_bm == 64 || (force_bm == 0 && g.m > 64 && (((long)tiles128 * S < bm64_below && g.k <= 768) || (long)tiles128 * S < bm64_anyk));
-  const int tiles = bm64 ? ((g.m + 63) / 64) * ((g.n + BN - 1) / BN) : tiles128;
+  // (the split-K chooser counts K tiles of its own BK: an empty split would read past the operand planes)
+  LRAM_REQUIRE(S == 1 || (int64_t)(S - 1) * g.k_tiles_per_split < g.k / BK, "gemm f16x2 (pre-split operands): empty K split");
+  const int tile = gemm_f16x2p_tile(g, S);
+  const int bm = tile == 64 ? 64 : (tile == 128 ? 128 : 256), bn = tile == 512 ? 256 : 128;
+  const int tiles = ((g.m + bm - 1) / bm) * ((g.n + bn - 1) / bn);
   dim3 grid(tiles, 1, S);
-  gemm_choose_xcd_split(g, bm64 ? 64 : 128, BN, 4);
+  gemm_choose_xcd_split(g, bm, bn, 4);
   const int stages = stages_env > 0 ? stages_env : ((long)tiles * S >= 384 ? 1 : 2);
-  if (bm64) {
-    if (stages == 1) launch_stage<1, 64>(g, grid, stream); else launch_stage<2, 64>(g, grid, stream);
-  } else {
-    if (stages == 1) launch_stage<1, 128>(g, grid, stream); else launch_stage<2, 128>(g, grid, stream);
+  switch (tile) {
+    case 64:
+      if (stages == 1) launch_stage<1, 1, 2, 2>(g, grid, stream); else launch_stage<2, 1, 2, 2>(g, grid, stream);
+      break;
+    case 128:
+      if (stages == 1) launch_stage<1, 2, 2, 2>(g, grid, stream); else launch_stage<2, 2, 2, 2>(g, grid, stream);
+      break;
+    case 256:  // 48 KB per stage: one stage = up to three workgroups per CU by LDS (two by registers), two stages = one
+      if (stages == 1) launch_stage<1, 2, 4, 2>(g, grid, stream); else launch_stage<2, 2, 4, 2>(g, grid, stream);
+      break;
+    default:   // 256 x 256: 64 KB per stage, 16 waves
+      if (stages == 1) launch_stage<1, 2, 4, 4>(g, grid, stream); else launch_stage<2, 2, 4, 4>(g, grid, stream);
+      break;
   }
   LRAM_HIP_CHECK(hipGetLastError());
   if (S > 1) launch_splitk_reduce(g, stream);

@@ -475,7 +475,7 @@ bool gemm_small_m(const GemmArgs& g) { return g.m <= kGemvMaxM; }
 
 bool gemm_skinny_supported(const GemmArgs& g) {
   return g.m >= 1 && g.k >= 32 && (g.k & 3) == 0 && (g.lda & 3) == 0 && (g.ldw & 3) == 0 &&
-         ((g.sA1 | g.sA2 | g.sW1 | g.sW2) & 3) == 0 && g.gate == nullptr && g.act_silu_from < 0 && g.a3 == nullptr &&
+         ((g.sA1 | g.sA2 | g.sW1 | g.sW2) & 3) == 0 && g.gate == nullptr && g.act_silu_from < 0 &&
          (reinterpret_cast<uintptr_t>(g.a) & 15) == 0 && (reinterpret_cast<uintptr_t>(g.w) & 15) == 0;
 }
 
@@ -518,13 +518,7 @@ void launch_gemm_skinny(const GemmArgs& g, hipStream_t stream) {
                        ((reinterpret_cast<uintptr_t>(g.a_tab[i]) | reinterpret_cast<uintptr_t>(g.w_tab[i])) & 15) == 0,
                    "gemm: operand tables need 16-byte aligned operands for every entry");
   }
-  // LRAM_GEMM_SKINNY_FORM (measurement knob): 0 = always the multi-round <4, 8> instance, 1 = one round where it fits
-  static const int form = [] {
-    const char* v = std::getenv("LRAM_GEMM_SKINNY_FORM");
-    return v ? std::atoi(v) : 1;
-  }();
   const int nq = g.k >> 2;
-  if (form == 0 && g.norm_g == nullptr) return launch_gemm_skinny_inst<4, 8, true>(g, stream);
   if ((nq + 7) / 8 <= 8) return launch_gemm_skinny_inst<4, 8, false>(g, stream);
   if ((nq + 7) / 8 <= 16) return launch_gemm_skinny_inst<4, 16, false>(g, stream);
   // (an 8-wave instance with one round up to K = 1024 measured slower: Mamba-48M at 16 envs 0.887 -> 0.948 ms)

@@ -206,7 +206,6 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
       const float yv = yo[et / T][et % T][c];
       yabs = fabsf(yv);
       if (a.y != nullptr) a.y[off] = yv;
-      if (a.y3 != nullptr) split3_store(yv, a.y3 + off, a.y3_plane);
     }
     if (a.amax != nullptr && cpb == 64) {  // one wave = one (env, token) row segment of 64 channels
       const float m = wave_max(yabs);
@@ -228,8 +227,8 @@ __global__ __launch_bounds__(256) void mamba_ssm_kernel(MambaSsmArgs a) {
 // already requested; the per-channel constants -- dt_proj's R weights, A = -exp(A_log), D, dt_bias -- are loaded once per
 // wave, not once per 4 envs.  Everything that is per (env, token) and shared by the channels -- the raw dt row, B_t, C_t
 // -- has a wave-uniform address: scalar loads, SGPR operands, no LDS, no barrier, no cross-lane reduction (y_t is a
-// 16-term in-lane dot).  Same arithmetic as the 4-lane form (dt bit for bit: same k-ordered fma chain); y sums its 16
-// terms in lane order instead of 4 + shuffle tree.  Reference: selective_state_update as called from Mamba.step
+// 16-term in-lane dot).  Same arithmetic as the 4-lane form to fp32 rounding: dt_proj's 48 products and y's 16 terms are summed
+// as four interleaved partial chains (a 48-long dependent fma chain leaves the SIMD idle between issues), not in k order.  Reference: selective_state_update as called from Mamba.step
 // (src/algos/models/decision_mamba.py:136-138, [3P] mamba_ssm 2.1.0).
 // TR: the state block of a wave and an env -- 64 channels x 16 states, one contiguous 4 KB run -- moves between HBM and the
 // registers COALESCED (instruction q of a lane: 16 bytes at 1 KB * q + 16 * lane) and is transposed to / from the lane = channel
@@ -393,41 +392,14 @@ void launch_mamba_ssm(const MambaSsmArgs& a, hipStream_t stream) {
   LRAM_REQUIRE(a.dt_wt != nullptr || a.dtp != nullptr, "selective state update needs dtp or dt_w");
   dim3 block(256);
   // lane = channel form: env-steps of the d_state-16 geometries with dt_proj fused (Mamba-48M: dt_rank 48)
-  static const int lane_form = [] {   // LRAM_MAMBA_SSM_LANE (measurement knob): 0 keeps the 4-lanes-per-channel kernel
-    const char* v = std::getenv("LRAM_MAMBA_SSM_LANE");
-    return v ? std::atoi(v) : 1;
-  }();
-  static const int epw_env = [] {     // LRAM_MAMBA_SSM_EPW (measurement knob): env slots per wave
-    const char* v = std::getenv("LRAM_MAMBA_SSM_EPW");
-    return v ? std::atoi(v) : 0;
-  }();
-  if (lane_form && a.T == 3 && a.N == 16 && a.R == 48 && a.dt_wt != nullptr && a.y3 == nullptr && a.y != nullptr &&
-      a.d_inner % 64 == 0 && a.B >= 64) {
-    static const int ilp = [] {   // LRAM_MAMBA_SSM_ILP (measurement knob): 0 = one dependent chain per dot product
-      const char* v = std::getenv("LRAM_MAMBA_SSM_ILP");
-      return v ? std::atoi(v) : 1;
-    }();
-    const int epw = epw_env > 0 ? epw_env : 8;
+  // (variants measured and removed, profiles/EXPERIMENTS.md "Mamba state update": one dependent chain per dot product, four
+  // waves per SIMD with spills, each lane moving its own 64 contiguous state bytes, other env counts per wave)
+  if (a.T == 3 && a.N == 16 && a.R == 48 && a.dt_wt != nullptr && a.y != nullptr && a.d_inner % 64 == 0 && a.B >= 64) {
+    const int epw = 8;  // env slots per wave
     const long waves = (long)(a.d_inner / 64) * ((a.B + epw - 1) / epw);
     const dim3 grid((unsigned)((waves + 3) / 4));
-    static const int occ = [] {   // LRAM_MAMBA_SSM_OCC (measurement knob): waves per SIMD the register budget is cut for (3: 138 VGPRs, 4: 128 + 5 spilled)
-      const char* v = std::getenv("LRAM_MAMBA_SSM_OCC");
-      return v ? std::atoi(v) : 3;
-    }();
-    static const int tr = [] {   // LRAM_MAMBA_SSM_TR (measurement knob): 0 = each lane moves its own 64 contiguous state bytes
-      const char* v = std::getenv("LRAM_MAMBA_SSM_TR");
-      return v ? std::atoi(v) : 1;
-    }();
-#define LRAM_SSM_LANE(ILPV, OCCV, XV)                                                                                          \
-  hipLaunchKernelGGL((mamba_ssm_lane_kernel<3, 48, ILPV, OCCV, XV>), grid, block, 0, stream, a.ssm_state, a.xc, a.xz, a.xdb, a.dt_wt, \
-                     a.dt_bias, a.A_log, a.Dp, a.reset, a.y, a.amax, a.B, a.d_inner, epw)
-    if (tr) {
-      if (occ == 4) LRAM_SSM_LANE(true, 4, true); else LRAM_SSM_LANE(true, 3, true);
-    } else if (ilp && occ == 4) LRAM_SSM_LANE(true, 4, false);
-    else if (ilp) LRAM_SSM_LANE(true, 3, false);
-    else if (occ == 4) LRAM_SSM_LANE(false, 4, false);
-    else LRAM_SSM_LANE(false, 3, false);
-#undef LRAM_SSM_LANE
+    hipLaunchKernelGGL((mamba_ssm_lane_kernel<3, 48, true, 3, true>), grid, block, 0, stream, a.ssm_state, a.xc, a.xz, a.xdb, a.dt_wt,
+                       a.dt_bias, a.A_log, a.Dp, a.reset, a.y, a.amax, a.B, a.d_inner, epw);
     LRAM_HIP_CHECK(hipGetLastError());
     return;
   }

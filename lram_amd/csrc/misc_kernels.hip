@@ -22,9 +22,8 @@ constexpr int kNormMaxV = 8;  // float4 per lane: d <= 2048
 // so the scalar embeddings need no launch of their own.
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t in_stride, float* out,
                                                        int64_t out_stride, const float* gamma, const float* beta,
-                                                       int rows, int d, float eps, int rms, float* out2,
-                                                       uint16_t* planes, int64_t plane_stride, float* amax,
-                                                       ScalarTokens st, _Float16* h2, int64_t h2_plane, float* h2_inv, float* l2, int64_t h2_kt) {
+                                                       int rows, int d, float eps, int rms, float* out2, float* amax,
+                                                       ScalarTokens st, _Float16* h2, int64_t h2_plane, float* h2_inv, int64_t h2_kt) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -86,16 +85,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     if (out != nullptr) *reinterpret_cast<float4*>(dst + 4 * i) = o;
     if (out2 != nullptr) *reinterpret_cast<float4*>(out2 + (int64_t)row * out_stride + 4 * i) = o;  // second copy (taps)
-    if (planes != nullptr) split3_store4(o, planes + (int64_t)row * out_stride + 4 * i, plane_stride);  // GEMM operand
     v[j] = o;
-  }
-  if (l2 != nullptr) {  // (uniform) Euclidean norm of the output row: |w . out| <= |w| |out| bounds whatever a projection makes of it
-    float sq = 0.f;
-#pragma unroll
-    for (int j = 0; j < kNormMaxV; ++j)
-      if (lane + 64 * j < nv) sq += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
-    sq = wave_sum(sq);
-    if (lane == 0) l2[row] = sqrtf(sq);
   }
   if (amax != nullptr || h2 != nullptr) mx = wave_max(mx);  // (uniform) the row's largest magnitude
   if (amax != nullptr && lane == 0) amax[row] = mx;         // the f16x2 GEMM derives its operand scale from it
@@ -114,8 +104,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* in, int64_t 
 // res_out = hidden + res_in ; normed = res_out * rsqrt(mean(res_out^2) + eps) * gamma
 __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, const float* res_in, float* res_out,
                                                            float* normed, const float* gamma, int rows, int d,
-                                                           float eps, uint16_t* planes, int64_t plane_stride,
-                                                           float* amax, _Float16* h2, int64_t h2_plane, float* h2_inv, int64_t h2_kt) {
+                                                           float eps, float* amax, _Float16* h2, int64_t h2_plane, float* h2_inv, int64_t h2_kt) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -156,7 +145,6 @@ __global__ __launch_bounds__(256) void add_rms_norm_kernel(const float* hidden, 
     o.w = v[j].w * rstd * g.w;
     mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     if (normed != nullptr) *reinterpret_cast<float4*>(normed + base + 4 * i) = o;
-    if (planes != nullptr) split3_store4(o, planes + base + 4 * i, plane_stride);
     v[j] = o;
   }
   if (amax != nullptr || h2 != nullptr) mx = wave_max(mx);
@@ -335,56 +323,24 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* buf, const uint8_
 }  // namespace
 
 // out[0] = max over rows of the Euclidean norm of w[r][0 .. k)  (one workgroup; finalize-time helper)
-__global__ __launch_bounds__(256) void max_row_l2_kernel(const float* w, int rows, int k, float* out) {
-  __shared__ float red[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float best = 0.f;
-  for (int r = wave; r < rows; r += 4) {
-    float sq = 0.f;
-    for (int c = lane; c < k; c += 64) sq += w[(int64_t)r * k + c] * w[(int64_t)r * k + c];
-    best = fmaxf(best, sqrtf(wave_sum(sq)));
-  }
-  if (lane == 0) red[wave] = best;
-  __syncthreads();
-  if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-__global__ __launch_bounds__(256) void max_abs_kernel(const float* v, int n, float* out) {
-  __shared__ float red[4];
-  float best = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) best = fmaxf(best, fabsf(v[i]));
-  best = wave_max(best);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
-  __syncthreads();
-  if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-void launch_max_abs(const float* v, int n, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(256), 0, stream, v, n, out);
-  LRAM_HIP_CHECK(hipGetLastError());
-}
-void launch_max_row_l2(const float* w, int rows, int k, float* out, hipStream_t stream) {
-  hipLaunchKernelGGL(max_row_l2_kernel, dim3(1), dim3(256), 0, stream, w, rows, k, out);
-  LRAM_HIP_CHECK(hipGetLastError());
-}
-
 void launch_row_norm(const float* in, int64_t in_stride, float* out, int64_t out_stride, const float* gamma,
                      const float* beta, int rows, int d, float eps, int rms, hipStream_t stream, float* out2,
-                     uint16_t* planes, int64_t plane_stride, float* amax, const ScalarTokens* st, uint16_t* h2, int64_t h2_plane,
-                     float* h2_inv, float* l2, int64_t h2_kt) {
+                     float* amax, const ScalarTokens* st, uint16_t* h2, int64_t h2_plane, float* h2_inv, int64_t h2_kt) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "row norm: d must be a multiple of 4 and <= 2048");
   LRAM_REQUIRE(h2 == nullptr || (h2_inv != nullptr && h2_kt >= 32 * (int64_t)rows), "row norm: f16x2 operand planes need the inverse-scale output and the K-tile pitch");
   hipLaunchKernelGGL(row_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, in, in_stride, out, out_stride,
-                     gamma, beta, rows, d, eps, rms, out2, planes, plane_stride, amax, st ? *st : ScalarTokens(),
-                     reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv, l2, h2_kt);
+                     gamma, beta, rows, d, eps, rms, out2, amax, st ? *st : ScalarTokens(),
+                     reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv, h2_kt);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
 void launch_add_rms_norm(const float* hidden, const float* res_in, float* res_out, float* normed,
-                         const float* gamma, int rows, int d, float eps, hipStream_t stream, uint16_t* planes,
-                         int64_t plane_stride, float* amax, uint16_t* h2, int64_t h2_plane, float* h2_inv, int64_t h2_kt) {
+                         const float* gamma, int rows, int d, float eps, hipStream_t stream, float* amax, uint16_t* h2,
+                         int64_t h2_plane, float* h2_inv, int64_t h2_kt) {
   LRAM_REQUIRE(d % 4 == 0 && d <= 256 * kNormMaxV, "rms norm: d must be a multiple of 4 and <= 2048");
   LRAM_REQUIRE(h2 == nullptr || (h2_inv != nullptr && h2_kt >= 32 * (int64_t)rows), "rms norm: f16x2 operand planes need the inverse-scale output and the K-tile pitch");
   hipLaunchKernelGGL(add_rms_norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, hidden, res_in, res_out,
-                     normed, gamma, rows, d, eps, planes, plane_stride, amax, reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv, h2_kt);
+                     normed, gamma, rows, d, eps, amax, reinterpret_cast<_Float16*>(h2), h2_plane, h2_inv, h2_kt);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

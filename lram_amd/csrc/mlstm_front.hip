@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void mlstm_front_kernel(MlstmFrontArgs a) {
 
     // ---- conv -> SiLU, q / k, gate partial sums ----
     float4 q[T], k[T];
-    float pg[T * kNG], xmax[T];
+    float pg[T * kNG];
     auto token = [&](int t, const float4& p0, const float4& p1, const float4& p2, const float4& p3) {
       float4 y;
       y.x = p0.x * cw[0].x + p1.x * cw[0].y + p2.x * cw[0].z + p3.x * cw[0].w + cb.x;
@@ -129,7 +129,6 @@ __global__ __launch_bounds__(256) void mlstm_front_kernel(MlstmFrontArgs a) {
       y.w = p0.w * cw[3].x + p1.w * cw[3].y + p2.w * cw[3].z + p3.w * cw[3].w + cb.w;
       const float4 xa = make_float4(silu_f(y.x), silu_f(y.y), silu_f(y.z), silu_f(y.w));
       *reinterpret_cast<float4*>(a.xa + ((int64_t)b * T + t) * inner + c0) = xa;
-      xmax[t] = fmaxf(fmaxf(fabsf(xa.x), fabsf(xa.y)), fmaxf(fabsf(xa.z), fabsf(xa.w)));
       q[t] = make_float4(dot4(wq[0], xa), dot4(wq[1], xa), dot4(wq[2], xa), dot4(wq[3], xa));
       k[t] = make_float4(dot4(wk[0], xa), dot4(wk[1], xa), dot4(wk[2], xa), dot4(wk[3], xa));
 #pragma unroll
@@ -193,13 +192,6 @@ __global__ __launch_bounds__(256) void mlstm_front_kernel(MlstmFrontArgs a) {
       d[t] = wave_sum(dot4(q[t], n));
     }
     *reinterpret_cast<float4*>(a.n_state + (int64_t)b * inner + c0) = n;
-    if (a.xa_amax != nullptr) {  // (uniform) max |xa| of this wave's head per token: proj_down's row-scale bound is built from it
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const float mx = wave_max(xmax[t]);
-        if (lane == 0) a.xa_amax[((int64_t)b * T + t) * kNH + h] = mx;
-      }
-    }
     if (lane == 0) {
       a.m_state[(int64_t)b * kNH + h] = m;
 #pragma unroll

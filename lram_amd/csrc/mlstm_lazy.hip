@@ -83,21 +83,15 @@ __device__ __forceinline__ int acc_row(int r, int lh) { return (r & 3) + 8 * (r 
 constexpr int kFC = 128;   // columns per workgroup
 constexpr int kFPV = 136;  // LDS pitch of the V rows
 constexpr int kFPK = 40;   // LDS pitch of the scaled khat tile (32 rows of DH)
-#ifndef LRAM_KFR
-#define LRAM_KFR 64
-#endif
-constexpr int kFR = LRAM_KFR;    // rows of C per workgroup (two 32-row MFMA tiles): many short workgroups hide the
+constexpr int kFR = 64;    // rows of C per workgroup (two 32-row MFMA tiles): many short workgroups hide the
                            // load -> MFMA -> store latency of a fold better than few long ones
-
-constexpr int kFT = 4;      // at most this many tokens per step (readout partials of the fused fold)
-
-// WF: window rows held in LDS (48; 40 -- opt-in, when the host's bound on the pending tokens of the folding envs allows it --
-// is 34.6 KB of LDS = four workgroups per CU instead of three); READOUT: the fold + readout form (a.ypart)
-template <int WF, bool READOUT>
+constexpr int WF = W;      // window rows held in LDS
+// (Removed after measurement, profiles/EXPERIMENTS.md: a 40-row LDS window for four workgroups per CU -- the fold got 25 %
+// shorter, the step did not; a fold + readout form that handed the read pass q . C_new for the strips it had just rewritten --
+// 2.3 GB of 48 fewer per step and 4-5 % SLOWER, because a fold that needs this step's q sits on the slice's critical chain.)
 __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
   __shared__ __attribute__((aligned(16))) float Vs[WF * kFPV];
   __shared__ __attribute__((aligned(16))) float Ks[(kFR / 32) * WF * kFPK];
-  __shared__ float Qs[READOUT ? kFT * kFR : 1];  // q_t of this workgroup's rows (fold + readout: a.ypart != nullptr)
   const int DH = a.DH, NH = a.NH;
   const int nsl = DH / kFC;
   int wid = blockIdx.x;
@@ -137,20 +131,6 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
   const float* wkb = a.wk + (((int64_t)b * NH + h) * W) * DH + row0;
   const float* wvb = a.wv + (((int64_t)b * NH + h) * W) * DH + slice * kFC;
   const float* cfb = a.coef_in + ((int64_t)b * NH + h) * W;
-  constexpr bool readout = READOUT;
-  if (readout && tid < a.T * kFR) {  // this step's q_t for the workgroup's 64 rows (the step's front end has run)
-    const int t = tid / kFR, r = tid % kFR;
-    const int ch = h * DH + row0 + r, inner = NH * DH;
-    float qv;
-    if (a.lean_wq != nullptr) {  // lean front end: q rebuilt from the conv branch with the block-diagonal 4 x 4 weights
-      const float4 xa = *reinterpret_cast<const float4*>(a.lean_xa + ((int64_t)b * a.T + t) * inner + (ch & ~3));
-      const float* wq = a.lean_wq + (int64_t)ch * 4;
-      qv = wq[0] * xa.x + wq[1] * xa.y + wq[2] * xa.z + wq[3] * xa.w;
-    } else {
-      qv = a.q[((int64_t)b * a.T + t) * inner + ch];
-    }
-    Qs[t * kFR + r] = qv;
-  }
   // every global load of the workgroup is issued before the first use: one memory round trip, not one per phase
   if (!early) {
 #pragma unroll
@@ -201,9 +181,6 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
     }
   }
   __syncthreads();
-  float yp[kFT];
-#pragma unroll
-  for (int x = 0; x < kFT; ++x) yp[x] = 0.f;
 #pragma unroll
   for (int t = 0; t < kFR / 32; ++t) {
     f32x16 acc;
@@ -219,27 +196,6 @@ __global__ __launch_bounds__(256) void mlstm_lazy_fold_kernel(MlstmLazyArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) cp0[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * DH] = acc[r];
-    if (readout) {  // q_t . (this lane's 16 rows of the NEW tile): column 32 w + li, rows 32 t + acc_row(r, lh)
-#pragma unroll
-      for (int x = 0; x < kFT; ++x) {
-        if (x < a.T) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) yp[x] += Qs[x * kFR + 32 * t + acc_row(r, lh)] * acc[r];
-        }
-      }
-    }
-  }
-  if (readout) {
-    // the two lane halves hold different rows of the same column; one partial per (env, head, row split, token, column),
-    // summed in fixed order by the read pass: deterministic, no atomics
-    float* yo = a.ypart + ((((int64_t)b * NH + h) * nrs + rsplit) * a.T) * DH + slice * kFC + 32 * w + li;
-#pragma unroll
-    for (int x = 0; x < kFT; ++x) {
-      if (x < a.T) {
-        const float v = yp[x] + __shfl_xor(yp[x], 32, 64);
-        if (lh == 0) yo[(int64_t)x * DH] = v;
-      }
-    }
   }
 }
 
@@ -419,21 +375,25 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
 // Column slice 0 also appends the step's T tokens to the window and writes the bookkeeping of the next step
 // (coefficients, scale, pending count) into the "out" side.
 // =============================================================================================
+// KPL selects how the window scores are formed:
+//   4  (256-wide heads, LPR == 64; "W4" below): the window's khat AND v rows are fetched as one float4 per lane and row -- wave
+//      w keeps rows w, w + 4, ... of both, lane l their columns 4 l .. 4 l + 3 -- and the scores are reduced BEFORE the pass over
+//      C_base (the khat registers are dead while it runs and hold its rows in flight instead).  The memory pipeline handles a
+//      wave's request in the same time whether its lanes ask for 4 or for 16 bytes, and the narrow per-lane form this replaced
+//      cost the pass as much request time as the whole stream over C_base (with the stream switched off the pass took 0.32 of
+//      its 0.92 ms).  A wave reduces its rows' scores itself (DPP adds, broadcast by readlane), multiplies them onto its v rows
+//      right away and hands the sums to the row-group reduction of the pass (red = G y_partial + window partial).
+//   0  (128-wide heads): scores after the pass, window rows loaded late, four at a time per wave.
+//  -1  (several column slices per head: 384 .. 896): scores and bookkeeping come from mlstm_lazy_score_kernel.
 // WP: window rows the register prefetch covers (W, or fewer when the fold period bounds the pending count: with the
-// default period of 13 and 3 tokens per step at most 36 rows are pending when a read pass starts, and the 24 registers
-// saved keep the kernel at 144 VGPRs -- three of its waves then leave room for a projection GEMM's wave on the SIMD).
-// SF: the window scores are reduced BEFORE the pass over C_base (the khat registers are dead while it runs and hold
-// its rows in flight instead) rather than after it.
-// W4 (KPL == 4, LPR == 64, scores first): the window's khat AND v rows are fetched as one float4 per lane and row -- wave w keeps
-// rows w, w + 4, ... of both, lane l their columns 4 l .. 4 l + 3 -- instead of one float per lane and (row, 64-column group) for
-// khat and one float per thread and row for v: 19 wide requests per lane in place of 76 narrow ones.  The memory pipeline
-// handles a wave's request in the same time whether its lanes ask for 4 or for 16 bytes, and the narrow form cost the pass as
-// much request time as the whole stream over C_base (64 wide requests per lane): with the stream switched off the pass took 0.32
-// of its 0.92 ms.  A wave reduces its rows' scores itself (DPP adds, broadcast by readlane), multiplies them onto its v rows
-// right away and hands the sums to the row-group reduction of the pass (red = G y_partial + window partial).
-template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false, bool EARLY = false, bool W4 = false>
+// default period of 13 and 3 tokens per step at most 36 rows are pending when a read pass starts; rows beyond it take a
+// late-load path).  Variants that were measured and removed (narrow requests, scores after the pass, first rows of C_base
+// requested before the scores, other row counts in flight): profiles/EXPERIMENTS.md.
+template <int T, int LPR, int UNR, int KPL, int WP = W>
 __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
-  static_assert(!W4 || (KPL == 4 && LPR == 64 && SF && !EARLY), "W4: 256-wide heads, scores first");
+  static_assert(KPL == 4 || KPL == 0 || KPL == -1, "KPL: 4 (wide window rows, scores first), 0 (late loads), -1 (score kernel)");
+  static_assert(KPL != 4 || LPR == 64, "wide window rows: 256-wide heads");
+  constexpr bool W4 = KPL == 4, SF = W4;
   constexpr int kRowsPerWave = (WP + T + 3) / 4;
   constexpr int CW = 4 * LPR;
   constexpr int RP = 256 / LPR;
@@ -444,7 +404,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   float* red = ks + T * DH;         // [RP][T][CW]
   float* pw = red + RP * T * CW;    // [T][WT]
   float* s_coef = pw + T * WT;      // [W]
-  float* gnred = s_coef + W;        // [3][4][T] group-norm partial sums (mean, then variance) and output maxima per wave
+  float* gnred = s_coef + W;        // [2][4][T] group-norm partial sums (mean, then variance) per wave
 
   const int b = blockIdx.z, h = blockIdx.y, slice = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -532,8 +492,6 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   }
   // window khat rows of this wave (rows wave, wave + 4, ...), KPL values per lane and row
   const float* wkb = a.wk + base * DH;
-  float kreg[(KPL > 0 && !W4) ? kRowsPerWave : 1][(KPL > 0 && !W4) ? KPL : 1];
-  (void)kreg;
   v4f k4[W4 ? kRowsPerWave : 1], v4w[W4 ? kRowsPerWave : 1];
   (void)k4, (void)v4w;
   if (W4) {
@@ -543,13 +501,6 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       const int j = wave + 4 * i;
       k4[W4 ? i : 0] = j < n ? *reinterpret_cast<const v4f*>(wkb + (int64_t)j * DH + 4 * lane) : (v4f)(0.f);
       v4w[W4 ? i : 0] = (j < n && j < WP) ? *reinterpret_cast<const v4f*>(wvr + (int64_t)j * DH + 4 * lane) : (v4f)(0.f);
-    }
-  } else if (KPL > 0) {
-#pragma unroll
-    for (int i = 0; i < kRowsPerWave; ++i) {
-      const int j = wave + 4 * i;
-#pragma unroll
-      for (int c = 0; c < KPL; ++c) kreg[i][c] = j < n ? wkb[(int64_t)j * DH + lane + 64 * c] : 0.f;
     }
   }
   // (this step's v operands last: their combination waits for everything requested above, the window rows included)
@@ -624,45 +575,6 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
         }
       }
     }
-  } else if (KPL > 0) {
-#pragma unroll
-    for (int i = 0; i < kRowsPerWave; ++i) {
-      const int j = wave + 4 * i;
-      if (j < n + T) {
-        float p[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) p[t] = 0.f;
-#pragma unroll
-        for (int c = 0; c < KPL; ++c) {
-          const int r = lane + 64 * c;
-          const float kv = j < n ? kreg[i][c] : ks[(j - n) * DH + r];
-#pragma unroll
-          for (int t = 0; t < T; ++t) p[t] += qs[t * DH + r] * kv;
-        }
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const float sm = wave_sum(p[t]);
-          if (lane == 0) pw[t * WT + j] = coefficient(j, t) * sm;
-        }
-      }
-    }
-    if (WP < W) {  // rows beyond the register prefetch (only when more than WP tokens are pending)
-      for (int j = wave + 4 * kRowsPerWave; j < n + T; j += 4) {
-        float p[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) p[t] = 0.f;
-        for (int r = lane; r < DH; r += 64) {
-          const float kv = j < n ? wkb[(int64_t)j * DH + r] : ks[(j - n) * DH + r];
-#pragma unroll
-          for (int t = 0; t < T; ++t) p[t] += qs[t * DH + r] * kv;
-        }
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const float sm = wave_sum(p[t]);
-          if (lane == 0) pw[t * WT + j] = coefficient(j, t) * sm;
-        }
-      }
-    }
   } else {
     for (int j0 = 4 * wave; j0 < n + T; j0 += 16) {  // four rows per wave at a time (their loads are issued together)
       float p[4][T];
@@ -699,33 +611,10 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = (v4f)(0.f);
   const float* Cb = a.C + (((int64_t)b * NH + h) * DH) * DH + col0;
-  const bool from_fold = lv.fold && a.ypart != nullptr;  // q . C_base comes from the fold kernel's partial readouts
-  const bool stream = !lv.zero && !from_fold;            // (after a restart C_base holds nothing until the env's next fold)
-  // EARLY (scores-first instances): the first UNR rows of C_base are requested before the window scores are reduced, so
-  // the pass does not start with a full memory round trip after them
-  v4f c0[(SF && EARLY) ? UNR : 1];
-  if (SF && EARLY && stream) {
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int r = rg + u * RP;
-      c0[u] = r < DH ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(Cb + (int64_t)r * DH)) : (v4f)(0.f);
-    }
-  }
+  const bool stream = !lv.zero;  // (after a restart C_base holds nothing until the env's next fold)
   if (SF) window_scores();
   if (stream) {
-    int r_begin = rg;
-    if (SF && EARLY) {
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int r = rg + u * RP;
-        if (r < DH) {
-#pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] += qs[t * DH + r] * c0[u];
-        }
-      }
-      r_begin = rg + RP * UNR;
-    }
-    for (int r0 = r_begin; r0 < DH; r0 += RP * UNR) {
+    for (int r0 = rg; r0 < DH; r0 += RP * UNR) {
       v4f c[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -760,13 +649,7 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       float y = 0.f;
 #pragma unroll
       for (int g = 0; g < RP; ++g) y += red[(g * T + t) * CW + c];
-      float yf = 0.f;
-      if (from_fold) {
-        const int nrs = DH / kFR;
-        const float* yi = a.ypart + ((((int64_t)b * NH + h) * nrs) * T + t) * DH + slice * CW + c;
-        for (int g = 0; g < nrs; ++g) yf += yi[(int64_t)g * T * DH];
-      }
-      hn[t] = W4 ? y + G[t] * yf : G[t] * (y + yf);  // (W4: the row groups' sums hold G y + the window rows' part already)
+      hn[t] = W4 ? y : G[t] * y;  // (W4: the row groups' sums hold G y + the window rows' part already)
     }
     if (!W4) {
 #pragma unroll
@@ -813,42 +696,21 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       if (lane == 0) gnred[4 * T + wave * T + t] = sq;
     }
     __syncthreads();
-    float gmx[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) gmx[t] = 0.f;
     if (tid < CW) {
       const int ch = h * DH + tid;
       const float gg = a.gn_g[ch], bb = a.gn_b != nullptr ? a.gn_b[ch] : 0.f, sk = a.gn_skip[ch];
       // (all of the epilogue's operands requested before the first store)
-      float xs[T], zs[T];
+      float xs[T];
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int64_t row = (int64_t)b * T + t;
-        xs[t] = a.lean_xa[row * inner + ch];
-        zs[t] = a.gn_gate != nullptr ? a.gn_gate[row * a.gn_ldg + ch] : 1.f;
-      }
+      for (int t = 0; t < T; ++t) xs[t] = a.lean_xa[((int64_t)b * T + t) * inner + ch];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float* q4 = gnred + 4 * T;
         const float var = (q4[t] + q4[T + t] + q4[2 * T + t] + q4[3 * T + t]) / (float)DH;
         const float rstd = 1.f / sqrtf(var + a.gn_eps);
         const int64_t off = ((int64_t)b * T + t) * inner + ch;
-        float o = dv[t] * rstd * gg + bb + sk * xs[t];
-        if (a.gn_gate != nullptr) o *= zs[t];
-        gmx[t] = fabsf(o);
-        a.h[off] = o;
+        a.h[off] = dv[t] * rstd * gg + bb + sk * xs[t];
       }
-    }
-    if (a.gn_amax != nullptr) {  // (uniform) largest magnitude of this (row, head) slice of the gated output
-      float* mxs = gnred + 8 * T;  // [4][T]
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const float mx = wave_max(gmx[t]);
-        if (lane == 0) mxs[wave * T + t] = mx;
-      }
-      __syncthreads();
-      if (tid < T)
-        a.gn_amax[((int64_t)b * T + tid) * NH + h] = fmaxf(fmaxf(mxs[tid], mxs[T + tid]), fmaxf(mxs[2 * T + tid], mxs[3 * T + tid]));
     }
   }
   if (slice == 0) {
@@ -883,99 +745,42 @@ __global__ __launch_bounds__(256) void mlstm_lazy_clear_kernel(int32_t* count, f
   if (gid == b * NH) count[b] = 0;
 }
 
-template <int T, int LPR, int UNR, int KPL, int WP = W, bool SF = false, bool EARLY = false, bool W4 = false>
+template <int T, int LPR, int UNR, int KPL, int WP = W>
 void launch_cell_tluk(const MlstmLazyArgs& a, hipStream_t s) {
   constexpr int CW = 4 * LPR, RP = 256 / LPR;
   dim3 grid(a.DH / CW, a.NH, a.B), block(256);
-  size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW + T * kLazyWT + W + 12 * T);
+  size_t shmem = sizeof(float) * (2 * T * a.DH + RP * T * CW + T * kLazyWT + W + 8 * T);
   shmem = std::max(shmem, (size_t)a.min_lds_bytes);
   // 116 VGPRs would let four workgroups share a CU; three (41 KB of LDS each) leave 152 registers per SIMD lane free,
   // so the slice streams' front-end and 64-row GEMM workgroups start beside them at once and a 128-row GEMM
   // workgroup (224 registers) after ONE read-pass workgroup retires: 386k vs 381k env-steps/s (two: 56 KB, 381k)
-  if (SF && a.min_lds_bytes == 0) shmem = std::max(shmem, (size_t)41 * 1024);
+  if (KPL == 4 && a.min_lds_bytes == 0) shmem = std::max(shmem, (size_t)41 * 1024);
   if (shmem > 48 * 1024) {
     static uint64_t raised = 0;
     if (first_use_on_device(raised)) {
-      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF, EARLY, W4>),
+      LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
   }
-  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP, SF, EARLY, W4>), grid, block, shmem, s, a);
+  hipLaunchKernelGGL((mlstm_lazy_cell_kernel<T, LPR, UNR, KPL, WP>), grid, block, shmem, s, a);
 }
 
 template <int T>
 void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
-  // LRAM_LAZY_UNROLL (measurement knob, T == 3 on the 256-wide geometry only): C_base rows in flight per lane
-  static const int unroll = [] {
-    const char* v = std::getenv("LRAM_LAZY_UNROLL");
-    // measured at 4096 env slots.  Scores after the pass (165 / 189 / 251 VGPRs): 4 rows in flight 377k env-steps/s,
-    // 8: 371k, 16: 362k.  Scores first (116 VGPRs for 4 and 8 rows, 177 for 16): 4: 381k, 8: 386k, 16: 363k.
-    return v ? std::atoi(v) : 8;
-  }();
-  static const bool prefetch = [] {
-    const char* v = std::getenv("LRAM_LAZY_KPREFETCH");
-    return v ? std::atoi(v) != 0 : true;
-  }();
-  static const bool narrow = [] {
-    const char* v = std::getenv("LRAM_LAZY_NARROW");
-    return v ? std::atoi(v) != 0 : true;
-  }();
-  if (a.DH == 256 && prefetch) {
-    // pending rows when a read pass starts: (period - 1) * T = 36 at most with the default period (the env's fold
-    // empties the window first); longer windows (other periods, calls with other token counts) take the kernel's
-    // late-load path for the rows beyond the prefetch
-    static const int scores_first = [] {
-      const char* v = std::getenv("LRAM_LAZY_SCORES_FIRST");
-      return v ? std::atoi(v) : 1;
-    }();
-    if (T == 3 && narrow && scores_first) {
-      if (unroll == 16) return launch_cell_tluk<T, 64, 16, 4, 36, true>(a, s);
-      static const int early = [] {   // LRAM_LAZY_EARLY (measurement knob): first C_base rows requested before the scores
-        const char* v = std::getenv("LRAM_LAZY_EARLY");
-        return v ? std::atoi(v) : 0;
-      }();
-      if (unroll == 8 && early) return launch_cell_tluk<T, 64, 8, 4, 36, true, true>(a, s);
-      static const int w4 = [] {   // LRAM_LAZY_W4 (measurement knob): 0 = narrow per-lane requests for the window rows
-        const char* v = std::getenv("LRAM_LAZY_W4");
-        return v ? std::atoi(v) : 1;
-      }();
-      if (unroll == 8 && w4) return launch_cell_tluk<T, 64, 8, 4, 36, true, false, true>(a, s);
-      if (unroll == 8) return launch_cell_tluk<T, 64, 8, 4, 36, true>(a, s);
-      if (unroll == 4) return launch_cell_tluk<T, 64, 4, 4, 36, true>(a, s);
-    }
-    if (T == 3 && narrow) {
-      if (unroll == 8) return launch_cell_tluk<T, 64, 8, 4, 36>(a, s);
-      if (unroll == 4) return launch_cell_tluk<T, 64, 4, 4, 36>(a, s);
-    }
-    if (T == 3 && unroll == 4) return launch_cell_tluk<T, 64, 4, 4>(a, s);
-    if (T == 3 && unroll == 8) return launch_cell_tluk<T, 64, 8, 4>(a, s);
-    return launch_cell_tluk<T, 64, 16, 4>(a, s);
-  }
+  // 256-wide heads (the 16M geometry): wide window rows, scores first, 8 rows of C_base in flight per lane, 36-row window
+  // prefetch (pending rows when a read pass starts: (period - 1) * T = 36 at most with the default period -- the env's fold
+  // empties the window first; longer windows take the kernel's late-load path for the rows beyond it).  Measured at 4096 env
+  // slots: 4 rows in flight 381k env-steps/s, 8: 386k, 16: 363k.
+  if (a.DH == 256) return launch_cell_tluk<T, 64, 8, 4, 36>(a, s);
   // one column slice per head: fused scores (mlstm_lazy_fused_scores: the engine allocates no score buffer and runs the
-  // lean front end for these head dims, so every branch for them must be a fused-score instance -- DH 256 with the
-  // k-hat register prefetch switched off takes the late-load form DH 128 uses)
-  if (a.DH == 256) return launch_cell_tluk<T, 64, 16, 0>(a, s);
+  // lean front end for these head dims, so every branch for them must be a fused-score instance)
   if (a.DH == 128) return launch_cell_tluk<T, 32, 16, 0>(a, s);
-  // several column slices per head: scores from mlstm_lazy_score_kernel (launch_mlstm_lazy_book)
+  // several column slices per head: scores from mlstm_lazy_score_kernel (launch_mlstm_lazy_book).  36-row prefetch, 16 rows in
+  // flight (174 VGPRs; 206M at 512 env slots 27.7k env-steps/s; 48-row prefetch 27.5k; 8 rows in flight -- 113 VGPRs, the pass
+  // itself 0.41 -> 0.31 ms -- 27.1k: the projections of that model are the longer side of the pipeline and lose what the pass gains)
   LRAM_REQUIRE(a.pw != nullptr, "lazy mLSTM: missing score buffer");
-  // LRAM_LAZY_EXT_VARIANT (measurement knob, 206M at 512 env slots): 0 = 48-row window prefetch, 16 rows in flight
-  // (185 VGPRs) 27.5k env-steps/s; 1 = 36-row prefetch, 8 rows (113 VGPRs, read pass 0.41 -> 0.31 ms) 27.1k -- the
-  // projections of this model are the longer side of the pipeline and lose what the pass gains; 2 = 36-row prefetch,
-  // 16 rows (174 VGPRs) 27.7k
-  static const int ext_variant = [] {
-    const char* v = std::getenv("LRAM_LAZY_EXT_VARIANT");
-    return v ? std::atoi(v) : 2;
-  }();
-  if (T == 3 && ext_variant == 1) {
-    if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 8, -1, 36>(a, s);
-    return launch_cell_tluk<T, 32, 8, -1, 36>(a, s);
-  }
-  if (T == 3 && ext_variant == 2) {
-    if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 16, -1, 36>(a, s);
-    return launch_cell_tluk<T, 32, 16, -1, 36>(a, s);
-  }
-  if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 16, -1>(a, s);
-  launch_cell_tluk<T, 32, 16, -1>(a, s);
+  if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 16, -1, 36>(a, s);
+  launch_cell_tluk<T, 32, 16, -1, 36>(a, s);
 }
 
 }  // namespace
@@ -985,7 +790,6 @@ bool mlstm_lazy_supported(int DH, int T) { return DH % 128 == 0 && T >= 1 && T <
 void launch_mlstm_lazy_fold(const MlstmLazyArgs& a_in, hipStream_t stream) {
   MlstmLazyArgs a = a_in;
   LRAM_REQUIRE(a.DH % kFC == 0 && a.DH % kFR == 0, "lazy mLSTM: head dim must be a multiple of 128");
-  LRAM_REQUIRE(a.ypart == nullptr || (a.T >= 1 && a.T <= kFT), "lazy mLSTM: fold + readout takes 1..4 tokens per step");
   long envs = a.B;
   if (a.compact) {
     a.first = (a.period - a.phase % a.period) % a.period;  // smallest b with (phase + b) % period == 0
@@ -993,23 +797,7 @@ void launch_mlstm_lazy_fold(const MlstmLazyArgs& a_in, hipStream_t stream) {
     envs = (a.B - a.first + a.period - 1) / a.period;
   }
   const long nwg = envs * a.NH * (a.DH / kFC) * (a.DH / kFR);
-  // 40 window rows in LDS when no folding env can hold more pending tokens (host bound; 0 = unknown)
-  // opt-in (LRAM_FOLD_W40=1): the fold itself gets 25 % shorter inside the pipeline (0.243 -> 0.183 ms at 16M / 4096 slots),
-  // the step does not -- the sLSTM chains beside it slow down by as much (16M +0.5 %, 1024 slots -0.8 %, 206M -1 %;
-  // profiles/r03_ab_fold_w40.txt)
-  static const bool allow40 = [] {
-    const char* v = std::getenv("LRAM_FOLD_W40");
-    return v != nullptr && std::atoi(v) != 0;
-  }();
-  const bool w40 = allow40 && a.fold_wmax > 0 && a.fold_wmax <= 40 && a.force == 0 && a.compact != 0;
-  const dim3 grid((unsigned)nwg), block(256);
-  if (a.ypart != nullptr) {
-    hipLaunchKernelGGL((mlstm_lazy_fold_kernel<W, true>), grid, block, 0, stream, a);
-  } else if (w40) {
-    hipLaunchKernelGGL((mlstm_lazy_fold_kernel<40, false>), grid, block, 0, stream, a);
-  } else {
-    hipLaunchKernelGGL((mlstm_lazy_fold_kernel<W, false>), grid, block, 0, stream, a);
-  }
+  hipLaunchKernelGGL(mlstm_lazy_fold_kernel, dim3((unsigned)nwg), dim3(256), 0, stream, a);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
@@ -1043,6 +831,19 @@ void launch_mlstm_lazy_cell(const MlstmLazyArgs& a, hipStream_t stream) {
 void launch_mlstm_lazy_clear(int32_t* count, float* g, const uint8_t* mask, int B, int NH, hipStream_t stream) {
   hipLaunchKernelGGL(mlstm_lazy_clear_kernel, dim3((unsigned)((B * NH + 255) / 256)), dim3(256), 0, stream, count, g,
                      mask, B, NH);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+namespace {
+__global__ void lazy_counts_as_float_kernel(const int32_t* count, float* out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) out[b] = (float)(count[b] & 0xFFFF);
+}
+}  // namespace
+
+// pending window tokens per env (low 16 bits of the count word) as floats: lram_lazy_peek
+void launch_lazy_counts_as_float(const int32_t* count, float* out, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(lazy_counts_as_float_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, count, out, B);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

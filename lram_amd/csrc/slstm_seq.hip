@@ -173,6 +173,9 @@ void launch_slstm_pack_rt(const float* rt, float* rt2, int NH, int SDH, hipStrea
 
 void launch_slstm_seq(const SlstmSeqArgs& a, hipStream_t stream) {
   LRAM_REQUIRE(slstm_seq_supported(a.H, a.NH, a.T) && a.rt2 != nullptr, "sLSTM step kernel: head dim 128, 1..4 tokens");
+  // (the kernel's row offsets into gates / yout / state are 32-bit: slices beyond ~700k envs at H = 512 would wrap)
+  LRAM_REQUIRE((int64_t)a.B * a.T * 4 * a.H < (1ll << 32) && (int64_t)a.state_B * a.H < (1ll << 30),
+               "sLSTM step kernel: slice too large for its 32-bit row offsets");
   const dim3 grid((unsigned)(a.NH * ((a.B + kEnv - 1) / kEnv))), block(256);
   switch (a.T) {
     case 1: hipLaunchKernelGGL(slstm_seq_kernel<1>, grid, block, 0, stream, a); break;

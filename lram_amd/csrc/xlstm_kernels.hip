@@ -579,7 +579,6 @@ __global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
       o.z = (o.z + sk.z * xa.z) * silu_f(z.z);
       o.w = (o.w + sk.w * xa.w) * silu_f(z.w);
       if (a.out != nullptr) *reinterpret_cast<float4*>(dst) = o;
-      if (a.planes != nullptr) split3_store4(o, a.planes + (int64_t)row * D + hd, a.plane_stride);
     } else {
       float4 x = *reinterpret_cast<const float4*>(dst);
       x.x += o.x;
@@ -821,12 +820,8 @@ __global__ __launch_bounds__(256) void gelu_gate_kernel(const float* p, float* o
 template <int T>
 static void launch_pre_t(const MlstmPreArgs& a, hipStream_t s) {
   dim3 grid(a.B), block(kPreThreads);
-  // one channel group per thread: the variant with one dependent memory round trip (LRAM_PRE_SINGLE=0: three, as before)
-  static const bool allow_single = [] {
-    const char* v = std::getenv("LRAM_PRE_SINGLE");
-    return v ? std::atoi(v) != 0 : true;
-  }();
-  const bool single = allow_single && (a.inner >> 2) <= kPreThreads;
+  // one channel group per thread: the variant with one dependent memory round trip
+  const bool single = (a.inner >> 2) <= kPreThreads;
   switch (a.NH) {
     case 1: hipLaunchKernelGGL((mlstm_pre_kernel<T, 1>), grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL((mlstm_pre_kernel<T, 2>), grid, block, 0, s, a); break;

@@ -41,6 +41,7 @@ _VP = ctypes.c_void_p
 _SYMBOLS = {
     "lram_last_error": (ctypes.c_char_p, []),
     "lram_abi_version": (ctypes.c_int32, []),
+    "lram_build_id": (ctypes.c_char_p, []),
     "lram_create": (ctypes.c_int32, [ctypes.POINTER(LramConfig), ctypes.c_int32, ctypes.POINTER(_VP)]),
     "lram_destroy": (ctypes.c_int32, [_VP]),
     "lram_set_weight": (ctypes.c_int32, [_VP, ctypes.c_char_p, _VP, ctypes.c_size_t]),
@@ -74,11 +75,10 @@ _SYMBOLS = {
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_f16x2_presplit": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
-    "lram_gemm_bf16x3_presplit": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
-                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_embed_images": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
     "lram_set_state_mode": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32]),
     "lram_get_state_mode": (ctypes.c_int32, [_VP]),
+    "lram_lazy_peek": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
     "lram_stream_rmw": (ctypes.c_int32, [_VP, ctypes.c_size_t, _VP]),
     "lram_stream_read": (ctypes.c_int32, [_VP, ctypes.c_size_t, _VP, _VP]),
     "lram_gemm_counts": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.c_int32]),
@@ -379,6 +379,15 @@ class Engine:
     def state_mode(self) -> str:
         return "lazy" if self.lib.lram_get_state_mode(self._h) else "materialised"
 
+    def lazy_peek(self, block: int, which: str) -> torch.Tensor:
+        """Lazy representation looked at without folding: 'g' [B, NH] (scale of C_base since the last fold), 'm' [B, NH]
+        (stabiliser state), 'pending' [B] (window tokens) -- lram_lazy_peek."""
+        w = {"g": 0, "m": 1, "pending": 2}[which]
+        shape = (self.batch,) if w == 2 else (self.batch, self.spec.n_heads)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        _check(self.lib, self.lib.lram_lazy_peek(self._h, block, w, _ptr(out), _stream_ptr(self.device)))
+        return out
+
     def set_micro_batches(self, n: int):
         """Env slices pipelined on separate HIP streams (0 = auto, 1 = off); results are independent of n."""
         _check(self.lib, self.lib.lram_set_micro_batches(self._h, int(n)))
@@ -426,7 +435,7 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
     """out[M,N] = a[M,K] @ w[N,K]^T (+ bias) (+ out) through the library's fp32-MFMA kernel (kernel="f32") or the
     bf16x3 kernel (kernel="bf16x3") the engine uses for its projections."""
     lib = load_library()
-    fn = {"f32": lib.lram_gemm_f32, "bf16x3": lib.lram_gemm_bf16x3, "bf16x3_presplit": lib.lram_gemm_bf16x3_presplit,
+    fn = {"f32": lib.lram_gemm_f32, "bf16x3": lib.lram_gemm_bf16x3, 
           "f16x2": lib.lram_gemm_f16x2, "f16x2p": lib.lram_gemm_f16x2_presplit, "skinny": lib.lram_gemm_skinny}[kernel]
     M, K = a.shape
     N = w.shape[0]

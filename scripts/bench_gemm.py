@@ -24,6 +24,8 @@ SHAPES = [  # (tag, M, N, K)
     ("c2_down", 1536, 512, 1024), ("c2_up_x", 1536, 1024, 512), ("c2_up", 1536, 2048, 512),
     # 206M at 512 env slots: two slices of 256 envs, 768 rows per projection launch (weights beyond one XCD's L2)
     ("206m_up_s", 768, 5120, 1280), ("206m_down_s", 768, 1280, 2560),
+    # C5 prefill: 206M, 512 slots in two slices x 63-token chunks = 16128 rows per projection launch
+    ("c5_up", 16128, 5120, 1280), ("c5_down", 16128, 1280, 2560),
 ]
 REPS = 5
 

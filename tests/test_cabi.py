@@ -58,3 +58,15 @@ def test_header_is_plain_c_and_error_path_without_gpu(hip_lib):
     cfg.abi_version = 99
     assert hip_lib.lram_create(ctypes.byref(cfg), 0, ctypes.byref(h)) != 0
     assert b"abi_version" in hip_lib.lram_last_error()
+
+
+def test_build_identity_follows_the_sources(hip_lib, monkeypatch):
+    """lram_build_id() = sha256 over sources + headers + flags; build.needs_build() compares the marker inside the .so file
+    with the tree, so any edit (here: a flag) makes the library on disk stale -- mtimes play no part."""
+    from lram_amd import build
+    want = build.source_hash()
+    assert len(want) == 64 and hip_lib.lram_build_id().decode() == want == build.library_build_id()
+    assert not build.needs_build()
+    monkeypatch.setattr(build, "FLAGS", build.FLAGS + ["-DX=1"])
+    assert build.source_hash() != want and build.needs_build()
+    assert build.library_build_id(os.path.join(ROOT, "no_such.so")) is None

@@ -1,0 +1,193 @@
+"""The step path at the reference's real episode length (tests/golden/make_horizon_fixture.py).
+
+The reference loop runs an episode to `done` -- 1000 steps on DMControl, 200 on Meta-World -- without clearing the cache
+(src/callbacks/evaluation.py:130-177, src/algos/decision_transformer_sb3.py:663-666): the recurrent state integrates 3000
+(600) tokens, the mLSTM stabiliser m drifts, the lazy matrix memory folds ~77 times per env.  The engine is driven by
+lram_step over the fixture's inputs; actions / logits / hidden at the marked steps and the recurrent state at the end of the
+episode and of the run are compared with the CPU oracle's (fp32 fixture; float64 fixture for the conditioning rule of
+tests/helpers.py::assert_close_or_as_close_as_fp32_oracle, escape hatch capped at 5 % of the compared rows).
+
+Three engine configurations on the xLSTM trajectory: lazy at 8 slots, materialised at 8 slots, and the headline
+configuration -- 4096 slots, two slices, the lean front end / fused group norm / pre-split projections, fold period 13 --
+with the fixture's 8 envs planted among 4088 slots of random traffic (every fold phase of the period is hit)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lram_amd import init_state_dict, preset
+from tests.golden.make_horizon_fixture import B as FB
+from tests.golden.make_horizon_fixture import CASES, SSM_ENVS, WEIGHT_SEED, horizon_inputs, probe, weight_checksum
+from tests.helpers import (assert_actions_match, assert_close_or_as_close_as_fp32_oracle, rel_err, relaxed_rows_fraction,
+                           relaxed_rows_reset)
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REPORT = {}
+
+
+def _fixtures(case):
+    c = CASES[case]
+    fx = np.load(os.path.join(GOLD, c["file"] + ".npz"))
+    fx64 = np.load(os.path.join(GOLD, c["file"] + "_fp64.npz"))
+    assert abs(float(fx64["weight_checksum"]) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"])
+    return c, fx, fx64
+
+
+def _closer(fx, fx64):
+    def close(got, key, what, tol=2e-4):
+        want32, want64 = torch.from_numpy(fx[key]), torch.from_numpy(fx64[key])
+        got = got.detach().cpu().reshape(want32.shape)
+        if got.dim() == 1:
+            got, want32, want64 = got.unsqueeze(0), want32.unsqueeze(0), want64.unsqueeze(0)
+        assert_close_or_as_close_as_fp32_oracle(got, want32, want64, tol=tol, what=what)
+    return close
+
+
+def _write_report():
+    out = os.path.join(os.path.dirname(GOLD), "..", "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "horizon_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    if os.environ.get("LRAM_TEST_REPORT"):
+        print("[report] horizon:", json.dumps(REPORT, sort_keys=True))
+
+
+def _run_xlstm(mode, slots, where):
+    """Drive lram_step over the 1060-step fixture trajectory.  `where`: slot index of each fixture env."""
+    from lram_amd.engine import Engine
+    c, fx, fx64 = _fixtures("xlstm")
+    close = _closer(fx, fx64)
+    spec = preset(c["preset"])
+    sd = init_state_dict(spec, seed=WEIGHT_SEED)
+    assert abs(weight_checksum(sd) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"]), \
+        "seeded weights differ from the ones the fixture was computed with"
+    obs, rtg, mask = horizon_inputs(spec, "xlstm")
+    n_steps = obs.shape[0]
+    eng = Engine(spec, sd, slots, device="cuda:0")
+    if mode is not None:
+        eng.set_state_mode(mode)
+    lazy = eng.state_mode == "lazy"
+    assert lazy == (mode != "eager")
+    where = torch.as_tensor(where, device="cuda")
+    d_obs_all, d_rtg_all, d_mask_all = obs.cuda(), rtg.cuda(), mask.cuda()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    d_obs = torch.zeros(slots, spec.state_dim, device="cuda")
+    d_rtg = torch.full((slots,), 4.5, device="cuda")
+    d_rew = torch.zeros(slots, device="cuda")
+    d_mask = torch.zeros(slots, dtype=torch.uint8, device="cuda")
+    relaxed_rows_reset()
+    ties = 0
+    g_lo, m_lo, m_hi, pend_hi = float("inf"), float("inf"), float("-inf"), 0
+    name = f"xlstm16m_{mode or 'auto'}_{slots}"
+    for t in range(n_steps):
+        if slots > FB:   # background traffic: random observations, restarts about every 300 steps, own rtg schedule
+            d_obs[:, :17] = torch.rand(slots, 17, generator=g, device="cuda") * 2 - 1
+            d_mask.copy_((torch.rand(slots, generator=g, device="cuda") < (1.0 if t == 0 else 0.0033)).to(torch.uint8))
+            d_rtg.copy_(torch.where(d_mask.bool(), torch.full_like(d_rtg, 4.5), d_rtg - 0.01))
+        d_obs[where] = d_obs_all[t]
+        d_rtg[where] = d_rtg_all[t]
+        d_mask[where] = d_mask_all[t]
+        a, _ = eng.step(d_obs, d_rtg, d_rew, d_mask)
+        if lazy and (t % 7 == 0 or t + 1 in c["marks"]):   # looked at without folding (lram_lazy_peek)
+            for blk in c["blocks"]:
+                gg, mm = eng.lazy_peek(blk, "g")[where], eng.lazy_peek(blk, "m")[where]
+                g_lo, m_lo, m_hi = min(g_lo, float(gg.min())), min(m_lo, float(mm.min())), max(m_hi, float(mm.max()))
+            pend_hi = max(pend_hi, int(eng.lazy_peek(c["blocks"][0], "pending")[where].max()))
+        if t + 1 in c["marks"]:
+            torch.cuda.synchronize()
+            _, hidden, logits = eng.taps()
+            want_logits = torch.from_numpy(fx[f"logits_{t + 1}"])
+            try:
+                close(hidden[where], f"hidden_{t + 1}", f"{name} step {t + 1} hidden")
+                close(logits[where], f"logits_{t + 1}", f"{name} step {t + 1} logits")
+                ties += assert_actions_match(a[where], torch.from_numpy(fx[f"actions_{t + 1}"]), want_logits, spec,
+                                             what=f"{name} step {t + 1}")
+            except AssertionError as ex:
+                raise AssertionError(f"first diverging mark: step {t + 1}: {ex}") from None
+        if t + 1 == c["episode"] or t + 1 == n_steps:
+            # (an export folds every pending window: done only where the fixture holds the state, i.e. twice per run)
+            tag = "ep" if t + 1 == c["episode"] else "end"
+            for i in c["blocks"]:
+                cm = eng.export_state_tensor(i, 0)[where]
+                r = probe(cm.shape[-1]).cuda()
+                close(cm @ r, f"{tag}_b{i}_Cr", f"{name} {tag} block {i} C r")
+                close(r @ cm, f"{tag}_b{i}_rC", f"{name} {tag} block {i} r C")
+                close(cm.abs().amax(dim=(-1, -2)), f"{tag}_b{i}_Cabsmax", f"{name} {tag} block {i} max |C|")
+                close(eng.export_state_tensor(i, 1)[where].squeeze(-1), f"{tag}_b{i}_n", f"{name} {tag} block {i} n")
+                assert rel_err(eng.export_state_tensor(i, 2)[where], fx[f"{tag}_b{i}_m"]) < 1e-4, (tag, i)
+                close(eng.export_state_tensor(i, 3)[where], f"{tag}_b{i}_conv", f"{name} {tag} block {i} conv")
+            close(eng.export_state_tensor(c["slstm"], 0)[:, where], f"{tag}_b{c['slstm']}_slstm", f"{name} {tag} sLSTM state")
+    frac = relaxed_rows_fraction()
+    REPORT[name] = {"steps": n_steps, "action_ties_below_2e-4": ties, "rows_on_the_float64_rule": round(frac, 4),
+                    "oracle_m_range": {f"b{i}": [float(x) for x in fx[f"m_range_b{i}"]] for i in c["blocks"]}}
+    if lazy:
+        REPORT[name].update({"engine_m_min": m_lo, "engine_m_max": m_hi, "g_min_between_folds": g_lo,
+                             "max_pending_window_tokens": pend_hi})
+        assert g_lo > 0.0, "the scale of C_base underflowed between folds"
+    _write_report()
+    assert frac <= 0.05, frac
+    eng.close()
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["lazy", "eager"])
+def test_xlstm_16m_1000_step_episode_vs_oracle_fixture(hip_lib, mode):
+    _run_xlstm(mode, FB, list(range(FB)))
+
+
+def test_xlstm_16m_1000_step_episode_inside_the_headline_batch(hip_lib):
+    """4096 slots, default modes (lazy, two slices, multi-env front end, fused group norm, pre-split projections): the
+    fixture's envs sit at both ends of both slices and in the middle; their fold phases (slot % 13) differ."""
+    _run_xlstm(None, 4096, [0, 1, 2047, 2048, 2049, 3000, 4094, 4095])
+
+
+def test_mamba_48m_200_step_episode_vs_oracle_fixture(hip_lib):
+    from lram_amd.engine import Engine
+    c, fx, fx64 = _fixtures("mamba")
+    close = _closer(fx, fx64)
+    spec = preset(c["preset"])
+    sd = init_state_dict(spec, seed=WEIGHT_SEED)
+    assert abs(weight_checksum(sd) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"])
+    obs, rtg, mask = horizon_inputs(spec, "mamba")
+    for slots, where in ((FB, list(range(FB))), (2048, [0, 1, 1023, 1024, 1025, 1500, 2046, 2047])):
+        eng = Engine(spec, sd, slots, device="cuda:0")
+        idx = torch.as_tensor(where, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(12)
+        d_obs = torch.zeros(slots, spec.state_dim, device="cuda")
+        d_rtg = torch.full((slots,), 6.5, device="cuda")
+        d_rew = torch.zeros(slots, device="cuda")
+        d_mask = torch.zeros(slots, dtype=torch.uint8, device="cuda")
+        relaxed_rows_reset()
+        ties = 0
+        name = f"mamba48m_{slots}"
+        for t in range(obs.shape[0]):
+            if slots > FB:
+                d_obs[:, :39] = torch.rand(slots, 39, generator=g, device="cuda") * 2 - 1
+                d_mask.copy_((torch.rand(slots, generator=g, device="cuda") < (1.0 if t == 0 else 0.01)).to(torch.uint8))
+                d_rtg.copy_(torch.where(d_mask.bool(), torch.full_like(d_rtg, 6.5), d_rtg - 0.02))
+            d_obs[idx], d_rtg[idx], d_mask[idx] = obs[t].cuda(), rtg[t].cuda(), mask[t].cuda()
+            a, _ = eng.step(d_obs, d_rtg, d_rew, d_mask)
+            if t + 1 in c["marks"]:
+                torch.cuda.synchronize()
+                _, hidden, logits = eng.taps()
+                try:
+                    close(hidden[idx], f"hidden_{t + 1}", f"{name} step {t + 1} hidden")
+                    close(logits[idx], f"logits_{t + 1}", f"{name} step {t + 1} logits")
+                    ties += assert_actions_match(a[idx], torch.from_numpy(fx[f"actions_{t + 1}"]),
+                                                 torch.from_numpy(fx[f"logits_{t + 1}"]), spec, what=f"{name} step {t + 1}")
+                except AssertionError as ex:
+                    raise AssertionError(f"first diverging mark: step {t + 1}: {ex}") from None
+            if t + 1 == c["episode"] or t + 1 == obs.shape[0]:
+                tag = "ep" if t + 1 == c["episode"] else "end"
+                for i in c["blocks"]:
+                    close(eng.export_state_tensor(i, 0)[idx[list(SSM_ENVS)]], f"{tag}_l{i}_ssm", f"{name} {tag} layer {i} ssm")
+                    close(eng.export_state_tensor(i, 3)[idx], f"{tag}_l{i}_conv", f"{name} {tag} layer {i} conv")
+        REPORT[name] = {"steps": int(obs.shape[0]), "action_ties_below_2e-4": ties,
+                        "rows_on_the_float64_rule": round(relaxed_rows_fraction(), 4)}
+        _write_report()
+        assert relaxed_rows_fraction() <= 0.05
+        eng.close()
+        torch.cuda.empty_cache()

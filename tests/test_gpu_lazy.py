@@ -202,34 +202,3 @@ def test_lazy_fused_group_norm_variant(hip_lib, monkeypatch):
     for blk in (0, 2, 7):
         assert rel_err(fused.export_state_tensor(blk, 0), base.export_state_tensor(blk, 0)) < 2e-4
     base.close(), fused.close()
-
-
-@pytest.mark.parametrize("B", [64, 600])
-def test_lazy_fold_with_readout_variant(hip_lib, monkeypatch, B):
-    """LRAM_FOLD_FUSED=1 (opt-in, measured slower: profiles/EXPERIMENTS.md): an env's fold runs after the step's front end,
-    leaves q . C_new of its 64-row strips for the read pass, and the read pass skips the stream over C_base for the envs that
-    just folded.  Same trajectory as the default schedule (fold first, then a full read pass) and as the oracle; 600 env
-    slots run two pipelined slices with the folds on the fold stream."""
-    from lram_amd.engine import Engine
-    spec = preset("xlstm_16m")
-    sd = init_state_dict(spec, seed=58)
-    steps = 32
-    seq = make_inputs(spec, B, steps, seed=28, reset_prob=0.04)
-    base = Engine(spec, sd, B, device="cuda:0")
-    base.set_state_mode(True)
-    monkeypatch.setenv("LRAM_FOLD_FUSED", "1")
-    fused = Engine(spec, sd, B, device="cuda:0")
-    monkeypatch.delenv("LRAM_FOLD_FUSED")
-    fused.set_state_mode(True)
-    a_b, a_f = _run(base, seq), _run(fused, seq)
-    d = (a_b - a_f).abs() > 1e-4
-    assert int(d.sum()) <= max(1, int(1e-4 * d.numel()))        # (numerical ties of the top two logits only)
-    ora = dt_ref.OraclePolicy(spec, sd)
-    sample = [0, 17, B - 1]
-    for t, (obs, rtg, rew, mask) in enumerate(seq):
-        ref, dbg = ora.step(obs[sample], rtg[sample], rew[sample], mask[sample], return_debug=True)
-        assert_actions_match(a_f[t][sample], ref, dbg["logits"], spec, what=f"fold + readout step {t}")
-    for blk in (0, 2, 7):
-        for which in (0, 1, 2):
-            assert rel_err(fused.export_state_tensor(blk, which), base.export_state_tensor(blk, which)) < 2e-4, (blk, which)
-    base.close(), fused.close()

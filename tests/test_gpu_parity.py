@@ -89,12 +89,15 @@ def test_gemm_bf16x3_matches_fp64(hip_lib, m, n, k):
     torch.cuda.synchronize()
     e3 = ((out3.cpu().double() - ref).abs() / scale).max().item()
     e1 = ((out1.cpu().double() - ref).abs() / scale).max().item()
-    assert e3 < 1.5 * e1 + 1e-7, (m, n, k, e3, e1)   # e1: the exact fp32 fma-chain kernel on the same data
+    # e1: the exact fp32 fma-chain kernel on the same data.  No additive slack (round 4 removed it from the f16x2 gate, round 5
+    # here): a single 8-deep K tile, where the chain is all but exact, gets the measured factor instead
+    assert e3 < (1.5 if k >= 32 else 3.0) * e1, (m, n, k, e3, e1, e3 / e1)
     base = torch.randn(m, n, generator=g)
     out2 = gemm_f32(a.cuda(), w.cuda(), None, out=base.clone().cuda(), accumulate=True, kernel="bf16x3")
     torch.cuda.synchronize()
     ref2 = base.double() + a.double() @ w.double().t()
-    assert ((out2.cpu().double() - ref2).abs() / (scale + 1)).max().item() < 1.5 * e1 + 1e-7
+    # (accumulating into a base tensor adds one fp32 rounding of |base| ~ 1 per output: 6e-8 on the (scale + 1) metric)
+    assert ((out2.cpu().double() - ref2).abs() / (scale + 1)).max().item() < (1.5 if k >= 32 else 3.0) * e1 + 6e-8
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (96, 2192, 512), (300, 80, 1536), (1000, 1408, 512),
@@ -163,19 +166,29 @@ def test_gemm_f16x2_presplit_operands_are_bit_identical(hip_lib, m, n, k):
     assert torch.equal(want2, got2)
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 128, 32), (300, 80, 1536), (4096, 512, 1024), (257, 129, 48)])
-def test_gemm_bf16x3_presplit_operand_is_bit_identical(hip_lib, m, n, k):
-    """The projection kernel fed with pre-split A planes (what the norm / gate / state-update kernels write) gives
-    exactly the result of the on-the-fly split."""
+@pytest.mark.parametrize("tile", [64, 128, 256, 512])
+@pytest.mark.parametrize("stages", [1, 2])
+def test_gemm_f16x2_presplit_every_tile_is_bit_identical(hip_lib, monkeypatch, tile, stages):
+    """The pre-split kernel's four workgroup tiles (64 x 128, 128 x 128, and round 5's 256 x 128 on 8 waves and 256 x 256 on
+    16) in their one- and two-stage forms: every wave runs the same K-ordered product sequence whatever the tile, so each
+    form equals the on-the-fly-split kernel bit for bit -- ragged tiles on both edges, a single K tile, bias, accumulation."""
     from lram_amd.engine import gemm_f32
-    g = torch.Generator().manual_seed(m + n)
-    a = (torch.randn(m, k, generator=g) * torch.exp(torch.randn(m, 1, generator=g))).cuda()
-    w = torch.randn(n, k, generator=g).cuda()
-    bias = torch.randn(n, generator=g).cuda()
-    ref = gemm_f32(a, w, bias, kernel="bf16x3")
-    out = gemm_f32(a, w, bias, kernel="bf16x3_presplit")
-    torch.cuda.synchronize()
-    assert torch.equal(ref, out)
+    monkeypatch.setenv("LRAM_GEMM_TILE", str(tile))
+    monkeypatch.setenv("LRAM_F16P_STAGES", str(stages))
+    for m, n, k in [(257, 129, 96), (300, 80, 1536), (1000, 700, 32), (3072, 3072, 768), (6144, 2048, 512)]:
+        g = torch.Generator().manual_seed(m * 13 + n + tile)
+        a = (torch.randn(m, k, generator=g) * torch.exp(torch.randn(m, 1, generator=g))).cuda()
+        w = (torch.randn(n, k, generator=g) * torch.exp(torch.randn(n, 1, generator=g) * 0.5)).cuda()
+        bias = torch.randn(n, generator=g).cuda()
+        want = gemm_f32(a, w, bias, kernel="f16x2")
+        got = gemm_f32(a, w, bias, kernel="f16x2p")
+        torch.cuda.synchronize()
+        assert torch.equal(want, got), (m, n, k, float((want - got).abs().max()))
+        base = torch.randn(m, n, generator=g).cuda()
+        want2 = gemm_f32(a, w, None, out=base.clone(), accumulate=True, kernel="f16x2")
+        got2 = gemm_f32(a, w, None, out=base.clone(), accumulate=True, kernel="f16x2p")
+        torch.cuda.synchronize()
+        assert torch.equal(want2, got2), (m, n, k)
 
 
 def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=2e-4, state_tol=2e-4, spec=None,
@@ -556,22 +569,3 @@ def test_presplit_projection_operands_change_nothing(hip_lib, name, B, monkeypat
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("slack", [4.0, 64.0, 1024.0])
-def test_gemm_f16x2_tolerates_a_loose_row_bound(hip_lib, slack, monkeypatch):
-    """The kernel derives each A row's power-of-two scale from the row's largest magnitude -- or from an UPPER BOUND of it
-    (the engine assembles proj_down's from max |h| per head x a Cauchy-Schwarz bound of the output gate instead of
-    launching a row-maximum kernel).  The split is floating point: a scale 2^k too small only costs precision for elements
-    below 2^(k-18) of the row's largest.  With bounds 4 x, 64 x and 1024 x too large the error against fp64 stays within
-    the bar of the exact-maximum case (1.25 x the fp32 fma chain's) on realistic rows."""
-    from lram_amd.engine import gemm_f32
-    m, n, k = 1536, 512, 1024
-    g = torch.Generator().manual_seed(7)
-    a = torch.randn(m, k, generator=g) * torch.exp(torch.randn(m, 1, generator=g))
-    w = torch.randn(n, k, generator=g) * 0.03
-    ref = a.double() @ w.double().t()
-    scale = a.double().abs() @ w.double().abs().t() + 1e-300
-    e1 = ((gemm_f32(a.cuda(), w.cuda(), None, kernel="f32").cpu().double() - ref).abs() / scale).max().item()
-    monkeypatch.setenv("LRAM_TEST_AMAX_SLACK", str(slack))
-    e2 = ((gemm_f32(a.cuda(), w.cuda(), None, kernel="f16x2").cpu().double() - ref).abs() / scale).max().item()
-    monkeypatch.delenv("LRAM_TEST_AMAX_SLACK")
-    assert e2 < 1.25 * e1, (slack, e2, e1, e2 / e1)
