@@ -44,7 +44,7 @@ constexpr int BK = 32;
 //   TI 2, 4 x 4 waves: 256 x 256  (round 5: 64 KB for 384 MFMAs = 171 B per MFMA; 16 waves, one workgroup per CU)
 // The per-wave code is the same in all four; what changes is how many waves share a staged tile.
 template <bool HAS_BIAS, bool HAS_RES, int NSTAGE, int TI, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 1 || WM * WN > 8) ? 4 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 1 || WM * WN > 8) ? 4 : (NSTAGE >= 3 && WM * WN <= 4) ? 1 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;                       // waves per workgroup
   constexpr int BMT = 32 * TI * WM, BN = 64 * WN;   // workgroup tile
   constexpr int APL = BMT * BK;                     // f16 elements of one A plane tile
@@ -167,7 +167,33 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 1 || WM * WN > 8) ? 4 : 2)
   };
 
   if (NSTAGE == 1 && kt0 >= nk) __syncthreads();  // (an empty K range: the scales are still read by other threads below)
-  if (NSTAGE == 2) {
+  if (NSTAGE >= 3) {
+    // Ring of NSTAGE stages, NSTAGE - 1 K tiles of DMA in flight under the MFMAs: the kernel is bound by (bytes in flight per CU) /
+    // (L2 latency under load), and one tile ahead -- the two-stage form -- is a quarter of that latency.  A wave waits for ITS
+    // pieces of tile kt with a counted vmcnt (loads return in order; the pieces of the tiles behind kt stay in flight), the
+    // barrier then publishes every wave's pieces; the stage tile kt - 1 sat in is free from that barrier on (every wave is past
+    // its MFMAs) and receives tile kt + NSTAGE - 1.  One barrier per K tile, no drain.
+    constexpr int RS = NSTAGE;
+#pragma unroll
+    for (int st = 0; st < RS - 1; ++st)
+      if (kt0 + st < nk) dma_tile(st, kt0 + st);
+    int cur = 0;
+    for (int kt = kt0; kt < nk; ++kt) {
+      const int ahead = min(RS - 2, nk - 1 - kt);  // tiles this wave has issued beyond kt
+      if (RS >= 4 && ahead >= 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+      else if (ahead >= 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int nxt = cur == 0 ? RS - 1 : cur - 1;
+      if (kt + RS - 1 < nk) dma_tile(nxt, kt + RS - 1);
+      mfma_tile(cur);
+      cur = cur + 1 == RS ? 0 : cur + 1;
+    }
+  } else if (NSTAGE == 2) {
     // tile kt sits in stage kt & 1 once the barrier at the top of its iteration is passed (__syncthreads drains the issuing
     // waves' DMAs: an LDS-DMA is a pending LDS write on the VM counter); the DMA of tile kt + 1 is issued right behind that
     // barrier -- every wave has then finished reading that stage (tile kt - 1) -- and is in flight under tile kt's MFMAs
@@ -344,10 +370,15 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
       if (stages == 1) launch_stage<1, 1, 2, 2>(g, grid, stream); else launch_stage<2, 1, 2, 2>(g, grid, stream);
       break;
     case 128:
-      if (stages == 1) launch_stage<1, 2, 2, 2>(g, grid, stream); else launch_stage<2, 2, 2, 2>(g, grid, stream);
+      if (stages == 1) launch_stage<1, 2, 2, 2>(g, grid, stream);
+      else if (stages == 2) launch_stage<2, 2, 2, 2>(g, grid, stream);
+      else if (stages == 3) launch_stage<3, 2, 2, 2>(g, grid, stream);
+      else launch_stage<4, 2, 2, 2>(g, grid, stream);
       break;
-    case 256:  // 48 KB per stage: one stage = up to three workgroups per CU by LDS (two by registers), two stages = one
-      if (stages == 1) launch_stage<1, 2, 4, 2>(g, grid, stream); else launch_stage<2, 2, 4, 2>(g, grid, stream);
+    case 256:  // 48 KB per stage: one stage = up to three workgroups per CU by LDS (two by registers), two / three stages = one
+      if (stages == 1) launch_stage<1, 2, 4, 2>(g, grid, stream);
+      else if (stages == 2) launch_stage<2, 2, 4, 2>(g, grid, stream);
+      else launch_stage<3, 2, 4, 2>(g, grid, stream);
       break;
     default:   // 256 x 256: 64 KB per stage, 16 waves
       if (stages == 1) launch_stage<1, 2, 4, 4>(g, grid, stream); else launch_stage<2, 2, 4, 4>(g, grid, stream);

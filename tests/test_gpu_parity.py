@@ -166,8 +166,8 @@ def test_gemm_f16x2_presplit_operands_are_bit_identical(hip_lib, m, n, k):
     assert torch.equal(want2, got2)
 
 
-@pytest.mark.parametrize("tile", [64, 128, 256, 512])
-@pytest.mark.parametrize("stages", [1, 2])
+@pytest.mark.parametrize("tile,stages", [(64, 1), (64, 2), (128, 1), (128, 2), (128, 3), (128, 4), (256, 1), (256, 2), (256, 3),
+                                         (512, 1), (512, 2)])
 def test_gemm_f16x2_presplit_every_tile_is_bit_identical(hip_lib, monkeypatch, tile, stages):
     """The pre-split kernel's four workgroup tiles (64 x 128, 128 x 128, and round 5's 256 x 128 on 8 waves and 256 x 256 on
     16) in their one- and two-stage forms: every wave runs the same K-ordered product sequence whatever the tile, so each
