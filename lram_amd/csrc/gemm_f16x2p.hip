@@ -40,11 +40,16 @@ constexpr int BK = 32;
 //   TI 2, 2 x 2 waves: 128 x 128  (rounds 3-4: 32 KB per K tile for 96 MFMAs = 341 B of operand delivery per MFMA -- the
 //                                  kernel is bound by global -> LDS delivery, ~29 B / clock / CU out of L2, i.e. 11.8 clocks per
 //                                  MFMA against the 8 the four SIMDs need: profiles/EXPERIMENTS.md "Projection GEMM ...")
-//   TI 2, 4 x 2 waves: 256 x 128  (round 5: 48 KB per K tile for 192 MFMAs = 256 B per MFMA; 8 waves)
-//   TI 2, 4 x 4 waves: 256 x 256  (round 5: 64 KB for 384 MFMAs = 171 B per MFMA; 16 waves, one workgroup per CU)
-// The per-wave code is the same in all four; what changes is how many waves share a staged tile.
+// Round 5 instantiated this template for 256 x 128 (4 x 2 waves, 256 B per MFMA) and 256 x 256 (4 x 4 waves, 171 B per MFMA)
+// tiles too, and added a 3 / 4 stage LDS ring with counted vmcnt waits: every form bit-identical, none faster -- within 3 % on
+// the largest launches (24576 x 2048 x 512: 158-166 us against 163; 16128 x 5120 x 1280: 629-632 against 643), 10-30 % slower
+// on everything a step launches, the rings (one or two waves per SIMD) 1.3-1.7 x slower.  What the sweep says: the kernel needs
+// four waves per SIMD to cover its LDS-read -> MFMA dependency and its barrier, and four co-resident 32 KB stages ARE the
+// bytes in flight that set the delivery rate; a taller tile trades one for the other.  profiles/r05_gemm_presplit_tile_sweep.txt,
+// r05_gemm_presplit_ring_sweep.txt, EXPERIMENTS.md "Taller tiles and deeper rings"; the code is in git history (commit "Experiment:
+// 256-row / 256x256 workgroup tiles ...").
 template <bool HAS_BIAS, bool HAS_RES, int NSTAGE, int TI, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 1 || WM * WN > 8) ? 4 : (NSTAGE >= 3 && WM * WN <= 4) ? 1 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;                       // waves per workgroup
   constexpr int BMT = 32 * TI * WM, BN = 64 * WN;   // workgroup tile
   constexpr int APL = BMT * BK;                     // f16 elements of one A plane tile
@@ -167,33 +172,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NSTAGE == 1 || WM * WN > 8) ? 4 : (N
   };
 
   if (NSTAGE == 1 && kt0 >= nk) __syncthreads();  // (an empty K range: the scales are still read by other threads below)
-  if (NSTAGE >= 3) {
-    // Ring of NSTAGE stages, NSTAGE - 1 K tiles of DMA in flight under the MFMAs: the kernel is bound by (bytes in flight per CU) /
-    // (L2 latency under load), and one tile ahead -- the two-stage form -- is a quarter of that latency.  A wave waits for ITS
-    // pieces of tile kt with a counted vmcnt (loads return in order; the pieces of the tiles behind kt stay in flight), the
-    // barrier then publishes every wave's pieces; the stage tile kt - 1 sat in is free from that barrier on (every wave is past
-    // its MFMAs) and receives tile kt + NSTAGE - 1.  One barrier per K tile, no drain.
-    constexpr int RS = NSTAGE;
-#pragma unroll
-    for (int st = 0; st < RS - 1; ++st)
-      if (kt0 + st < nk) dma_tile(st, kt0 + st);
-    int cur = 0;
-    for (int kt = kt0; kt < nk; ++kt) {
-      const int ahead = min(RS - 2, nk - 1 - kt);  // tiles this wave has issued beyond kt
-      if (RS >= 4 && ahead >= 2)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-      else if (ahead >= 1)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      const int nxt = cur == 0 ? RS - 1 : cur - 1;
-      if (kt + RS - 1 < nk) dma_tile(nxt, kt + RS - 1);
-      mfma_tile(cur);
-      cur = cur + 1 == RS ? 0 : cur + 1;
-    }
-  } else if (NSTAGE == 2) {
+  if (NSTAGE == 2) {
     // tile kt sits in stage kt & 1 once the barrier at the top of its iteration is passed (__syncthreads drains the issuing
     // waves' DMAs: an LDS-DMA is a pending LDS write on the VM counter); the DMA of tile kt + 1 is issued right behind that
     // barrier -- every wave has then finished reading that stage (tile kt - 1) -- and is in flight under tile kt's MFMAs
@@ -329,13 +308,11 @@ static void launch_stage(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 // Workgroup tile of a launch.  64 x 128 where 128-row tiles would leave CUs without a workgroup AND K is short (16M at 1024
 // slots: proj_up's 1536 x 1024 x 512 halves are 96 tiles of 128 x 128 -- 26.0 us -- or 192 of 64 x 128 -- 17.8 us); long-K
 // launches keep 128 rows (inside the two-slice pipeline the small tile's 1.5 x operand traffic per flop costs Mamba-48M 2.3 %
-// and the 206M stack 1.5 %: profiles/r04_ab_tile_height.txt).  256-row tiles (round 5) where they still give every CU work:
-// the kernel is bound by operand delivery, and a tile twice as high moves 3/4 (256 x 128) or 1/2 (256 x 256) of the bytes per
-// MFMA.  LRAM_GEMM_TILE (measurement knob): 64, 128, 256 (= 256 x 128), 512 (= 256 x 256) force one.
+// and the 206M stack 1.5 %: profiles/r04_ab_tile_height.txt).  LRAM_GEMM_TILE (measurement knob): 64 / 128 force one.
 int gemm_f16x2p_tile(const GemmArgs& g, int S) {
   const char* fv = std::getenv("LRAM_GEMM_TILE");  // (read per launch: the bit-identity test walks through the tiles)
   const int force = fv ? std::atoi(fv) : 0;
-  if (force == 64 || force == 128 || force == 256 || force == 512) return force;
+  if (force == 64 || force == 128) return force;
   const long tiles128 = (long)((g.m + 127) / 128) * ((g.n + 127) / 128);
   if (g.m > 64 && ((tiles128 * S < 256 && g.k <= 768) || tiles128 * S < 128)) return 64;
   return 128;
@@ -343,8 +320,8 @@ int gemm_f16x2p_tile(const GemmArgs& g, int S) {
 
 void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
   GemmArgs g = g_in;
-  // LRAM_F16P_STAGES (measurement knob): 1 = one LDS stage, two barriers per K tile, several workgroups per CU;
-  // 2 = two stages, the next tile's DMA under the current tile's MFMAs, one barrier per K tile
+  // LRAM_F16P_STAGES (measurement knob): 1 = one LDS stage, two barriers per K tile, up to four workgroups per CU;
+  // 2 = two stages, the next tile's DMA under the current tile's MFMAs, one barrier per K tile, two workgroups per CU
   // default 0 = by grid size (same box, standalone: 16M proj_up 768 tiles 55 us with one stage / 65 with two; Mamba in_proj 576
   // tiles 67 / 80; 16M proj_down 192 tiles 50 / 40; Mamba out_proj 144 tiles 65 / 51 -- profiles/r04_gemm_f16x2p_durations.txt)
   const char* sv = std::getenv("LRAM_F16P_STAGES");
@@ -359,30 +336,15 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
     S = gemm_choose_split_k(g);
   // (the split-K chooser counts K tiles of its own BK: an empty split would read past the operand planes)
   LRAM_REQUIRE(S == 1 || (int64_t)(S - 1) * g.k_tiles_per_split < g.k / BK, "gemm f16x2 (pre-split operands): empty K split");
-  const int tile = gemm_f16x2p_tile(g, S);
-  const int bm = tile == 64 ? 64 : (tile == 128 ? 128 : 256), bn = tile == 512 ? 256 : 128;
+  const int bm = gemm_f16x2p_tile(g, S), bn = 128;
   const int tiles = ((g.m + bm - 1) / bm) * ((g.n + bn - 1) / bn);
   dim3 grid(tiles, 1, S);
   gemm_choose_xcd_split(g, bm, bn, 4);
-  const int stages = stages_env > 0 ? stages_env : ((long)tiles * S >= 384 ? 1 : 2);
-  switch (tile) {
-    case 64:
-      if (stages == 1) launch_stage<1, 1, 2, 2>(g, grid, stream); else launch_stage<2, 1, 2, 2>(g, grid, stream);
-      break;
-    case 128:
-      if (stages == 1) launch_stage<1, 2, 2, 2>(g, grid, stream);
-      else if (stages == 2) launch_stage<2, 2, 2, 2>(g, grid, stream);
-      else if (stages == 3) launch_stage<3, 2, 2, 2>(g, grid, stream);
-      else launch_stage<4, 2, 2, 2>(g, grid, stream);
-      break;
-    case 256:  // 48 KB per stage: one stage = up to three workgroups per CU by LDS (two by registers), two / three stages = one
-      if (stages == 1) launch_stage<1, 2, 4, 2>(g, grid, stream);
-      else if (stages == 2) launch_stage<2, 2, 4, 2>(g, grid, stream);
-      else launch_stage<3, 2, 4, 2>(g, grid, stream);
-      break;
-    default:   // 256 x 256: 64 KB per stage, 16 waves
-      if (stages == 1) launch_stage<1, 2, 4, 4>(g, grid, stream); else launch_stage<2, 2, 4, 4>(g, grid, stream);
-      break;
+  const int stages = stages_env == 1 || stages_env == 2 ? stages_env : ((long)tiles * S >= 384 ? 1 : 2);
+  if (bm == 64) {
+    if (stages == 1) launch_stage<1, 1, 2, 2>(g, grid, stream); else launch_stage<2, 1, 2, 2>(g, grid, stream);
+  } else {
+    if (stages == 1) launch_stage<1, 2, 2, 2>(g, grid, stream); else launch_stage<2, 2, 2, 2>(g, grid, stream);
   }
   LRAM_HIP_CHECK(hipGetLastError());
   if (S > 1) launch_splitk_reduce(g, stream);
