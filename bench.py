@@ -178,6 +178,8 @@ def parse_args(argv=None):
     ap.add_argument("--host-io-steps", type=int, default=48, help="steps of the host-inclusive leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timing-every", type=int, default=4,
+                    help="live HIP-event timing of the dominant kernel on every n-th step of the timed region (1 = every step)")
     ap.add_argument("--kernel-timing", action="store_true", help="keep the live state-pass timing below 256 env slots")
     ap.add_argument("--no-stream-ceilings", action="store_true")
     ap.add_argument("--engine-factory", default="",
@@ -402,9 +404,14 @@ def main(argv=None, engine_factory=None, device=None):
     # live kernel timing = HIP events around every state-pass launch: free beside 0.5 ms kernels, 12 % of a launch-bound
     # single-env step (0.422 vs 0.377 ms), so small batches run without it unless asked (--kernel-timing)
     timing = not args.no_kernel_timing and not args.graph and not stub and (B >= 256 or args.kernel_timing)
+    # ... and at 21 state-pass launches per step two event packets per launch cost the 4096-slot step 1.3-1.8 % when every step
+    # carries them (profiles/r05_ab_kernel_timing.txt): every `--timing-every`-th step of the timed region is timed (default 4:
+    # 16 of 64 steps, 336 launches), the rest run as a caller's steps do
+    every = max(1, args.timing_every)
+    steps_timed = len(range(0, K, every))
     if timing:
         sync()
-        eng.profile_begin()
+        eng.profile_begin_sampled(every)
     if not stub:
         eng.gemm_counts(reset=True)
     wall, last = timed_region(one_step, W, K, sync, ldist, dev)
@@ -434,6 +441,11 @@ def main(argv=None, engine_factory=None, device=None):
                                       "one state advance per env-step, full reset"},
         "inputs": "resident in HBM before the timed region (obs ring, per-step rtg and reset masks)",
     }
+    if not stub:   # which library ran: sha256 over its sources + headers + flags, compiled in (lram_amd/build.py)
+        from lram_amd import build as _build
+        from lram_amd.engine import load_library
+        out["build_id"] = load_library().lram_build_id().decode()
+        out["build_id_matches_sources"] = out["build_id"] == _build.source_hash()
     if world > 1:   # (every rank takes part; rank 0 logs it and carries it on the line)
         out["collective"] = ldist.collective_report(torch.zeros(B, last.shape[-1], dtype=last.dtype, device=last.device),
                                                     args.global_batch if args.global_batch > 0 else None)
@@ -482,6 +494,10 @@ def main(argv=None, engine_factory=None, device=None):
                           "note": "SURVEY 8d's host-inclusive step: obs / rtg / reset mask in pinned host memory -> H2D -> "
                                   "lram_step -> D2H of the actions -> host synchronisation after every step; measured after "
                                   "the timed region of `value`, same engine and schedule (started at step %d)" % t_base}
+        # SURVEY 8d defines the metric host-inclusive; the bench contract defines `value` with inputs resident in HBM (a
+        # PCIe-inclusive rate is never `value`).  Both are on the line, side by side, under names that say which is which.
+        out["value_host_inclusive"] = out["host_io"]["value"]
+        out["value_inputs_in_hbm"] = value
 
     # ---- roofline of the dominant kernel -----------------------------------------------------------
     n_rec_blocks = (spec.n_blocks - len(spec.slstm_at)) if spec.backbone == "xlstm" else spec.n_blocks
@@ -518,8 +534,11 @@ def main(argv=None, engine_factory=None, device=None):
         return r
 
     if kern_n > 0:
-        fill(roofline, kern_ms, kern_n, fold_ms, fold_n, K, B)
-        roofline["kernel_share_of_step"] = (kern_ms + fold_ms) / (wall * 1e3)
+        fill(roofline, kern_ms, kern_n, fold_ms, fold_n, steps_timed, B)
+        roofline["steps_timed"] = steps_timed
+        roofline["timing"] = ("HIP events around every launch of the dominant kernel on the stream it runs on, on every %s step "
+                              "of the timed region (%d of %d steps)" % ("" if every == 1 else "%d-th" % every, steps_timed, K))
+        roofline["kernel_share_of_step"] = (kern_ms + fold_ms) / steps_timed / (wall / K * 1e3)
     if lazy and roofline.get("avg_launch_ms"):
         r2 = cell_bytes_lazy(spec, T, r2_model=True)
         roofline["frac_round2_byte_model"] = r2 * roofline["envs_per_launch"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
@@ -546,7 +565,7 @@ def main(argv=None, engine_factory=None, device=None):
         eng.set_micro_batches(args.micro)
     # HBM bytes per launch come from a separate rocprofv3 --pmc pass (scripts/pmc_pass.sh -> profiles/): a constant
     # read from a committed file, labelled as such
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tag = "" if args.config == "xlstm_16m" else "_" + args.config   # (scripts/parse_pmc.py names the other configs' files)
         pmc_file = os.path.join(ROOT, "profiles", "%s_cell_kernel_hbm_traffic%s%s.json" % (rnd, tag, "_lazy" if lazy else ""))
         if not os.path.exists(pmc_file):
@@ -567,6 +586,7 @@ def main(argv=None, engine_factory=None, device=None):
         except Exception:
             pass
     out["roofline"] = roofline
+    out["_copy_ceiling_pending"] = True
     if spec.backbone == "mamba":
         # C3 is projection-bound (report the matrix cores beside the HBM state term).  Issued MFMA work of one
         # env-step = 2 M N K per projection x the piece products of the split scheme, over the measured step time: a
@@ -584,7 +604,7 @@ def main(argv=None, engine_factory=None, device=None):
              "peak": MFMA_PEAK_PFLOPS, "unit": "PFLOP/s", "frac_over_step": issued / (wall / K) / 1e15 / MFMA_PEAK_PFLOPS,
              "note": "matrix-core work of the projections averaged over the WHOLE env-step (state update, conv, norms "
                      "included in the time); f32 kind: peak is 0.157 PFLOP/s, frac not comparable"}
-        for rnd in ("r04", "r03"):
+        for rnd in ("r05", "r04", "r03"):
             pmc = os.path.join(ROOT, "profiles", "%s_gemm_mfma_busy.json" % rnd)
             if not os.path.exists(pmc):
                 continue
@@ -619,6 +639,8 @@ def main(argv=None, engine_factory=None, device=None):
             return 5 * 2 * n_copy * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
         out["hbm_copy_measured_GBps"] = rate(lambda: stream_copy(dst, src))
+        if roofline.get("achieved"):   # the same achieved rate against what a copy kernel moves on THIS box (not the roofline peak)
+            roofline["frac_of_measured_copy"] = roofline["achieved"] / out["hbm_copy_measured_GBps"]
         # the same bytes as an in-place read-modify-write with the cell kernel's access pattern (no arithmetic)
         out["hbm_rmw_measured_GBps"] = rate(lambda: stream_rmw(src))
         # half those bytes as a read-only stream with the lazy read pass's access shape (no arithmetic)
@@ -635,6 +657,7 @@ def main(argv=None, engine_factory=None, device=None):
             del big
         except RuntimeError:
             pass
+    out.pop("_copy_ceiling_pending", None)
     out["algorithmic_bytes_per_env_step"] = 2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim
     out["whole_step_8d_GBps"] = out["algorithmic_bytes_per_env_step"] * value / world / 1e9
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -220,6 +220,10 @@ int32_t lram_get_compat_mode(const lram_engine* e, int32_t* mamba_repeat, int32_
  * around the mLSTM cell-update launches (xLSTM) or the selective-state-update launches (Mamba).
  * lram_profile_end synchronises and returns total milliseconds and number of launches timed. */
 int32_t lram_profile_begin(lram_engine* e);
+/* The same, timing only every n-th lram_step (the first one after this call included): each timed launch is bracketed by two
+ * event packets on the state-pass queue, and at 21 launches per step that bookkeeping costs the headline 1.3-1.8 % when every
+ * step carries it (profiles/r05_ab_kernel_timing.txt).  lram_profile_end* report the sampled launches only. */
+int32_t lram_profile_begin_sampled(lram_engine* e, int32_t every_n_steps);
 int32_t lram_profile_end(lram_engine* e, double* total_ms, int64_t* n_launches);
 /* The same, with the lazy mode's fold launches (timed on their own stream) reported apart from the state-pass
  * launches, so that each figure can be held against the per-kernel averages of a rocprofv3 --kernel-trace run. */

@@ -192,6 +192,9 @@ struct lram_engine {
   size_t sync_used = 0;
   // profiling of the dominant recurrent kernel
   bool prof_on = false;
+  int prof_every = 1;       // lram_profile_begin_sampled: every n-th lram_step is timed (its launches carry the event pairs)
+  int64_t prof_calls = 0;   // lram_step calls since profiling was armed
+  bool prof_live = true;    // the call under way is one of the timed ones
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   std::vector<uint8_t> prof_aux;  // 1: the pair times a fold launch (adds to the total, is not a state-pass launch)
   size_t prof_used = 0;
@@ -833,7 +836,7 @@ void make_split(lram_engine* e, const float* w, size_t n) {
 }
 
 void prof_record(lram_engine* e, hipStream_t s, bool start, bool aux = false) {
-  if (!e->prof_on) return;
+  if (!e->prof_on || !e->prof_live) return;
   if (start) {
     if (e->prof_used == e->prof_events.size()) {
       hipEvent_t a, b;
@@ -1734,6 +1737,7 @@ int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding
     LRAM_HIP_CHECK(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     compat_prepare(e, discrete);  // (workspace of the shared repeated forwards: outside any capture)
+    e->prof_live = !e->prof_on || (e->prof_calls++ % e->prof_every) == 0;
     if (e->graph_mode && !e->prof_on) {
       GraphKey key{};
       key.obs = dev_obs, key.rtg = dev_rtg, key.rew = dev_reward, key.mask = dev_reset_mask, key.act = dev_actions;
@@ -1942,11 +1946,16 @@ int32_t lram_get_compat_mode(const lram_engine* e, int32_t* mamba_repeat, int32_
   return 0;
 }
 
-int32_t lram_profile_begin(lram_engine* e) {
+int32_t lram_profile_begin(lram_engine* e) { return lram_profile_begin_sampled(e, 1); }
+
+int32_t lram_profile_begin_sampled(lram_engine* e, int32_t every_n_steps) {
   return guarded([&] {
-    LRAM_REQUIRE(e != nullptr, "lram_profile_begin: null engine");
+    LRAM_REQUIRE(e != nullptr && every_n_steps >= 1, "lram_profile_begin_sampled: null engine / every_n_steps < 1");
     e->prof_on = true;
     e->prof_used = 0;
+    e->prof_every = every_n_steps;
+    e->prof_calls = 0;
+    e->prof_live = true;
   });
 }
 
@@ -1965,6 +1974,7 @@ int32_t lram_profile_end(lram_engine* e, double* total_ms, int64_t* n_launches) 
     *total_ms = tot;
     *n_launches = (int64_t)(e->prof_used - n_aux);
     e->prof_on = false;
+    e->prof_live = true;
     e->prof_used = 0;
   });
 }
@@ -1988,6 +1998,7 @@ int32_t lram_profile_end_split(lram_engine* e, double* main_ms, int64_t* n_main,
     }
     *main_ms = tm, *n_main = nm, *aux_ms = ta, *n_aux = na;
     e->prof_on = false;
+    e->prof_live = true;
     e->prof_used = 0;
   });
 }

@@ -62,6 +62,7 @@ _SYMBOLS = {
     "lram_set_compat_mode": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32]),
     "lram_get_compat_mode": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "lram_profile_begin": (ctypes.c_int32, [_VP]),
+    "lram_profile_begin_sampled": (ctypes.c_int32, [_VP, ctypes.c_int32]),
     "lram_profile_end": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "lram_profile_end_split": (ctypes.c_int32, [_VP, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
@@ -403,6 +404,10 @@ class Engine:
         r, st = ctypes.c_int32(1), ctypes.c_int32(0)
         self.lib.lram_get_compat_mode(self._h, ctypes.byref(r), ctypes.byref(st))
         return {"mamba_repeat": int(r.value), "stale_state": bool(st.value)}
+
+    def profile_begin_sampled(self, every_n_steps: int):
+        """Time every n-th step only (lram_profile_begin_sampled): 1/n of the event bookkeeping on the state-pass queue."""
+        _check(self.lib, self.lib.lram_profile_begin_sampled(self._h, int(every_n_steps)))
 
     def profile_begin(self):
         _check(self.lib, self.lib.lram_profile_begin(self._h))

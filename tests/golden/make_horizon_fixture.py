@@ -11,7 +11,8 @@ OraclePolicy.step -- for
 
   xlstm  xLSTM[7:1] 16M, 8 envs, DMControl-shaped inputs (17 native dims, rtg falling by r/scale = 0.01 per step as
          evaluation.py:165 does), 1000 env-steps without a reset, a reset of envs 0..3 at the 1001st, 60 more;
-  mamba  Mamba 48M, 8 envs, Meta-World-shaped inputs (39 native dims), 200 env-steps, reset of envs 0..3, 20 more,
+  mamba  Mamba 48M, 8 envs, Meta-World-shaped inputs (39 native dims), 200 env-steps, reset of envs 0..3, 20 more;
+  xlstm206m  xLSTM[7:1] 206M (20 blocks, head dim 640), 4 envs, 200 env-steps, reset of envs 0..1, 20 more,
 
 far too slow to repeat inside the GPU test run, so the outputs are committed as fixtures: inputs are regenerated from
 the seed by `horizon_inputs`, weights by init_state_dict(seed) (checksum stored and asserted); expected values =
@@ -37,12 +38,21 @@ CASES = {
                   marks=(1, 10, 100, 250, 500, 750, 1000, 1001, 1060), blocks=(0, 7), slstm=1, file="horizon_xlstm16m"),
     "mamba": dict(preset="mamba_48m", native=39, episode=200, tail=20, rtg0=6.50346, drtg=0.02,
                   marks=(1, 10, 50, 100, 150, 200, 201, 220), blocks=(0, 11), slstm=None, file="horizon_mamba48m"),
+    # the 206M geometry (head dim 640: score kernel + several column slices per head + per-env front end, none of which the
+    # 16M case touches) over a Meta-World-length episode; 4 envs (the oracle takes ~1 s per step at this size)
+    "xlstm206m": dict(preset="xlstm_206m", native=39, episode=200, tail=20, rtg0=6.50346, drtg=0.02, envs=4,
+                      marks=(1, 10, 50, 100, 150, 200, 201, 220), blocks=(0, 19), slstm=3, file="horizon_xlstm206m"),
 }
+
+
+def case_envs(case):
+    return CASES[case].get("envs", B)
 
 
 def horizon_inputs(spec, case):
     """obs [steps, B, state_dim] (native dims U(-1,1), rest zero as after pad_inputs), rtg [steps, B], mask [steps, B]."""
     c = CASES[case]
+    B = case_envs(case)
     n = c["episode"] + c["tail"]
     g = torch.Generator().manual_seed(INPUT_SEED)
     obs = torch.zeros(n, B, spec.state_dim)
@@ -99,7 +109,7 @@ def main(case, fp64=False):
     else:
         ora = OraclePolicy(spec, sd)
         step = ora.step
-    zero = torch.zeros(B)
+    zero = torch.zeros(case_envs(case))
     out = {"weight_checksum": np.float64(weight_checksum(sd))}
     m_lo, m_hi = {i: float("inf") for i in c["blocks"]}, {i: float("-inf") for i in c["blocks"]}
     t0 = time.time()
@@ -115,7 +125,7 @@ def main(case, fp64=False):
                 m_lo[i], m_hi[i] = min(m_lo[i], float(m.min())), max(m_hi[i], float(m.max()))
         if t + 1 == c["episode"]:
             store_state(out, "ep", ora, c, fp64)
-        if t % 100 == 0:
+        if t % 20 == 0:
             print(f"{case} step {t} ({time.time() - t0:.0f} s)", flush=True)
     store_state(out, "end", ora, c, fp64)
     if c["preset"].startswith("xlstm"):

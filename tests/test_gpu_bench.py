@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 def test_bench_line_contract_and_physical_roofline(hip_lib, capsys):
     import bench
     out = bench.main(["--config", "xlstm_16m", "--batch", "512", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
-                      "--no-stream-ceilings", "--host-io-steps", "3"])
+                      "--no-stream-ceilings", "--host-io-steps", "3", "--timing-every", "2"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in out, key
@@ -26,12 +26,19 @@ def test_bench_line_contract_and_physical_roofline(hip_lib, capsys):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert 0.0 < r["standalone"]["frac"] <= 1.0
-    assert r["launches_per_step"] == 14 and r["fold_launches_timed"] == 7 * 4      # 7 mLSTM blocks x 2 slices; 7 folds
+    # 7 mLSTM blocks x 2 slices; 7 folds; every 2nd of the 4 timed steps carries the event pairs (lram_profile_begin_sampled)
+    assert r["launches_per_step"] == 14 and r["steps_timed"] == 2 and r["fold_launches_timed"] == 7 * 2 and r["launches_timed"] == 28
     assert r["effective_8d_GBps"] > r["achieved"]                                   # the 8d figure prices more bytes
     assert (r["traffic"] is None) == (r["traffic_source"] is None)                  # a replayed constant is labelled
     if r["traffic"] is not None:                                                    # ... and agrees with the byte model
         assert 0.95 <= r["traffic"] / r["algorithmic_bytes_per_launch"] <= 1.10
     h = out["host_io"]
     assert h["steps"] == 3 and h["value"] > 0 and h["bytes_h2d_per_step"] == 512 * (204 * 4 + 4 + 1)
-    assert "cpu_baseline" not in out
+    # both definitions of the metric on the line, under names that say which is which: `value` = inputs resident in HBM
+    # (the bench contract), `value_host_inclusive` = SURVEY 8d's H2D + step + D2H + host sync
+    assert out["value_inputs_in_hbm"] == out["value"] and out["value_host_inclusive"] == h["value"]
+    # the library that ran is the one the checked-out sources build (sha256 over sources + headers + flags, compiled in)
+    from lram_amd import build
+    assert out["build_id"] == build.source_hash() and out["build_id_matches_sources"] is True
+    assert "cpu_baseline" not in out and "_copy_ceiling_pending" not in out
     capsys.readouterr()

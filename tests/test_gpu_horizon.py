@@ -18,8 +18,7 @@ import pytest
 import torch
 
 from lram_amd import init_state_dict, preset
-from tests.golden.make_horizon_fixture import B as FB
-from tests.golden.make_horizon_fixture import CASES, SSM_ENVS, WEIGHT_SEED, horizon_inputs, probe, weight_checksum
+from tests.golden.make_horizon_fixture import CASES, SSM_ENVS, WEIGHT_SEED, case_envs, horizon_inputs, probe, weight_checksum
 from tests.helpers import (assert_actions_match, assert_close_or_as_close_as_fp32_oracle, rel_err, relaxed_rows_fraction,
                            relaxed_rows_reset)
 
@@ -55,16 +54,17 @@ def _write_report():
         print("[report] horizon:", json.dumps(REPORT, sort_keys=True))
 
 
-def _run_xlstm(mode, slots, where):
-    """Drive lram_step over the 1060-step fixture trajectory.  `where`: slot index of each fixture env."""
+def _run_xlstm(mode, slots, where, case="xlstm"):
+    """Drive lram_step over the fixture trajectory of `case`.  `where`: slot index of each fixture env."""
     from lram_amd.engine import Engine
-    c, fx, fx64 = _fixtures("xlstm")
+    c, fx, fx64 = _fixtures(case)
+    FB = case_envs(case)
     close = _closer(fx, fx64)
     spec = preset(c["preset"])
     sd = init_state_dict(spec, seed=WEIGHT_SEED)
     assert abs(weight_checksum(sd) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"]), \
         "seeded weights differ from the ones the fixture was computed with"
-    obs, rtg, mask = horizon_inputs(spec, "xlstm")
+    obs, rtg, mask = horizon_inputs(spec, case)
     n_steps = obs.shape[0]
     eng = Engine(spec, sd, slots, device="cuda:0")
     if mode is not None:
@@ -75,18 +75,18 @@ def _run_xlstm(mode, slots, where):
     d_obs_all, d_rtg_all, d_mask_all = obs.cuda(), rtg.cuda(), mask.cuda()
     g = torch.Generator(device="cuda").manual_seed(11)
     d_obs = torch.zeros(slots, spec.state_dim, device="cuda")
-    d_rtg = torch.full((slots,), 4.5, device="cuda")
+    d_rtg = torch.full((slots,), c["rtg0"], device="cuda")
     d_rew = torch.zeros(slots, device="cuda")
     d_mask = torch.zeros(slots, dtype=torch.uint8, device="cuda")
     relaxed_rows_reset()
     ties = 0
     g_lo, m_lo, m_hi, pend_hi = float("inf"), float("inf"), float("-inf"), 0
-    name = f"xlstm16m_{mode or 'auto'}_{slots}"
+    name = f"{c['preset']}_{mode or 'auto'}_{slots}"
     for t in range(n_steps):
         if slots > FB:   # background traffic: random observations, restarts about every 300 steps, own rtg schedule
-            d_obs[:, :17] = torch.rand(slots, 17, generator=g, device="cuda") * 2 - 1
+            d_obs[:, :c["native"]] = torch.rand(slots, c["native"], generator=g, device="cuda") * 2 - 1
             d_mask.copy_((torch.rand(slots, generator=g, device="cuda") < (1.0 if t == 0 else 0.0033)).to(torch.uint8))
-            d_rtg.copy_(torch.where(d_mask.bool(), torch.full_like(d_rtg, 4.5), d_rtg - 0.01))
+            d_rtg.copy_(torch.where(d_mask.bool(), torch.full_like(d_rtg, c["rtg0"]), d_rtg - c["drtg"]))
         d_obs[where] = d_obs_all[t]
         d_rtg[where] = d_rtg_all[t]
         d_mask[where] = d_mask_all[t]
@@ -135,13 +135,21 @@ def _run_xlstm(mode, slots, where):
 
 @pytest.mark.parametrize("mode", ["lazy", "eager"])
 def test_xlstm_16m_1000_step_episode_vs_oracle_fixture(hip_lib, mode):
-    _run_xlstm(mode, FB, list(range(FB)))
+    _run_xlstm(mode, case_envs("xlstm"), list(range(case_envs("xlstm"))))
 
 
 def test_xlstm_16m_1000_step_episode_inside_the_headline_batch(hip_lib):
     """4096 slots, default modes (lazy, two slices, multi-env front end, fused group norm, pre-split projections): the
     fixture's envs sit at both ends of both slices and in the middle; their fold phases (slot % 13) differ."""
     _run_xlstm(None, 4096, [0, 1, 2047, 2048, 2049, 3000, 4094, 4095])
+
+
+@pytest.mark.parametrize("slots,where", [(4, [0, 1, 2, 3]), (512, [0, 255, 256, 511])])
+def test_xlstm_206m_200_step_episode_vs_oracle_fixture(hip_lib, slots, where):
+    """The 206M geometry (20 blocks, head dim 640: per-env front end, score kernel, several column slices per head in the read
+    pass, sLSTM head dim 320) over a Meta-World-length episode: lazy at 4 slots, and the C4 per-GPU batch -- 512 slots, two
+    slices -- with the fixture's envs at both ends of both slices."""
+    _run_xlstm("lazy" if slots == 4 else None, slots, where, case="xlstm206m")
 
 
 def test_mamba_48m_200_step_episode_vs_oracle_fixture(hip_lib):
@@ -152,6 +160,7 @@ def test_mamba_48m_200_step_episode_vs_oracle_fixture(hip_lib):
     sd = init_state_dict(spec, seed=WEIGHT_SEED)
     assert abs(weight_checksum(sd) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"])
     obs, rtg, mask = horizon_inputs(spec, "mamba")
+    FB = case_envs("mamba")
     for slots, where in ((FB, list(range(FB))), (2048, [0, 1, 1023, 1024, 1025, 1500, 2046, 2047])):
         eng = Engine(spec, sd, slots, device="cuda:0")
         idx = torch.as_tensor(where, device="cuda")

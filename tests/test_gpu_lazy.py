@@ -22,7 +22,7 @@ def _run(eng, seq):
     return torch.stack(acts)
 
 
-@pytest.mark.parametrize("period", [13, 1, 5, 14])
+@pytest.mark.parametrize("period", [13, 1, 14])   # (periods 5 and 13 over 1000 steps: tests/test_gpu_horizon.py / the soak script)
 def test_lazy_steps_match_oracle_and_eager(hip_lib, period):
     """45 steps with random per-env resets: several staggered folds per env; actions follow the oracle, the exported
     state equals the eager engine's."""
