@@ -47,7 +47,9 @@ constexpr int BK = 32;
 // four waves per SIMD to cover its LDS-read -> MFMA dependency and its barrier, and four co-resident 32 KB stages ARE the
 // bytes in flight that set the delivery rate; a taller tile trades one for the other.  profiles/r05_gemm_presplit_tile_sweep.txt,
 // r05_gemm_presplit_ring_sweep.txt, EXPERIMENTS.md "Taller tiles and deeper rings"; the code is in git history (commit "Experiment:
-// 256-row / 256x256 workgroup tiles ...").
+// 256-row / 256x256 workgroup tiles ...").  So was a loader / consumer form (two or four extra waves per workgroup that only issue
+// the LDS-DMA, the MFMA waves never touching global memory in the K loop, two stages, one barrier per K tile): bit-identical,
+// 1.3-1.5 x slower (r05_gemm_presplit_loader_consumer_sweep.txt; commit "Experiment: loader / consumer ...").
 template <bool HAS_BIAS, bool HAS_RES, int NSTAGE, int TI, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;                       // waves per workgroup
@@ -241,167 +243,6 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Loader / consumer form (round 5).  What the sweeps of this round showed about the kernel above: its time IS the sum of its
-// two halves -- tile delivery alone (scripts/tile_delivery.cpp: 73 us for 24576 x 2048 x 512 at the ~36 B / clock / CU L2 -> LDS
-// ceiling, the same with two or four workgroups per CU, so a bandwidth and not a bytes-in-flight limit) plus the MFMA work alone
-// (89 us at the 1.64 GHz the chip holds under it) = 162 us against 163-168 measured.  The co-resident workgroups fall into
-// lockstep (all wait on the same delivery queue, then all compute), and in the two-stage form the wave that issues a tile's DMA
-// sits in VMEM issue for as long as the delivery takes (back-pressure of the saturated memory pipe) with its MFMAs behind it.
-// Here the DMA is issued by NL extra waves that do nothing else; the WM x WN consumer waves never touch global memory inside the
-// K loop.  Two LDS stages; per K tile ONE workgroup barrier: the loaders arrive after `s_waitcnt vmcnt(0)` on tile kt + 1, the
-// consumers after their MFMAs on tile kt.  Same pieces, same products, same order: bit-identical to the forms above.
-template <bool HAS_BIAS, bool HAS_RES, int TI, int WM, int WN, int NL>
-__global__ __launch_bounds__(64 * (WM * WN + NL), 3) void gemm_f16x2p_ws_kernel(GemmArgs g) {
-  constexpr int NW = WM * WN;                       // consumer waves
-  constexpr int BMT = 32 * TI * WM, BN = 64 * WN;   // workgroup tile
-  constexpr int APL = BMT * BK, PLANE = BN * BK;
-  constexpr int STG = 2 * APL + 2 * PLANE;          // one LDS stage: A hi, A lo, W hi, W lo
-  constexpr int NPA = 2 * (BMT / 16);
-  constexpr int NPIECE = NPA + 2 * (BN / 16), PPL = NPIECE / NL;  // 1 KiB DMA pieces per stage / per loader wave
-  static_assert(NPA % NL == 0 && NPIECE % NL == 0, "a loader round of pieces belongs to one operand");
-  __shared__ __attribute__((aligned(1024))) _Float16 lds[2 * STG];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_n = (g.n + BN - 1) / BN;
-  const int tiles_m = (g.m + BMT - 1) / BMT;
-  int tm_idx, tn_idx;
-  gemm_tile_of(g, blockIdx.x, tiles_m, tiles_n, tm_idx, tn_idx);
-  const int m0 = tm_idx * BMT, n0 = tn_idx * BN;
-  const int nk_all = g.k / BK;
-  const int kt0 = g.split_k > 1 ? blockIdx.z * g.k_tiles_per_split : 0;
-  const int nk = g.split_k > 1 ? min(nk_all, kt0 + g.k_tiles_per_split) : nk_all;
-
-  if (wave >= NW) {  // ---- loader waves -------------------------------------------------------------------------------------
-    const int lw = wave - NW;
-    const _Float16* A2 = reinterpret_cast<const _Float16*>(g.a2);
-    const _Float16* W2 = reinterpret_cast<const _Float16*>(g.w2);
-    const _Float16* src[PPL];
-#pragma unroll
-    for (int i = 0; i < PPL; ++i) {
-      const int p = lw + NL * i;
-      const bool is_a = p < NPA;
-      const int q = is_a ? p : p - NPA;
-      const int rbs = is_a ? BMT / 16 : BN / 16;
-      const int plane = q / rbs, rb = q % rbs;
-      const int row = 16 * rb + (lane >> 2);
-      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-      if (is_a)
-        src[i] = A2 + (int64_t)plane * g.a2_plane + (int64_t)min(m0 + row, g.m - 1) * 32 + 8 * chunk;
-      else
-        src[i] = W2 + (int64_t)plane * g.w2_plane + (int64_t)min(n0 + row, g.n - 1) * 32 + 8 * chunk;
-    }
-    auto dma_tile = [&](int stage, int kt) {
-#pragma unroll
-      for (int i = 0; i < PPL; ++i) {
-        const int p = lw + NL * i;
-        const int64_t k0 = (int64_t)kt * (NL * i < NPA ? g.a2_kt : g.w2_kt);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
-                                         (__attribute__((address_space(3))) void*)(lds + stage * STG + p * 512), 16, 0, 0);
-      }
-    };
-    if (kt0 < nk) dma_tile(0, kt0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int kt = kt0; kt < nk; ++kt) {
-      if (kt + 1 < nk) dma_tile((kt + 1 - kt0) & 1, kt + 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    return;
-  }
-
-  // ---- consumer waves ---------------------------------------------------------------------------------------------------
-  const int wm = wave / WN, wn = wave % WN;
-  const int li = lane & 31, lh = lane >> 5;
-  const int sw = (li >> 2) & 3;
-  f32x16 acc[TI][2];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float ainv_r[TI][16], winv_r[2];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      ainv_r[i][r] = g.a2_inv[min(m0 + 32 * TI * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh, g.m - 1)];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) winv_r[j] = g.w_inv[min(n0 + 64 * wn + 32 * j + li, g.n - 1)];
-  const _Float16* a_base = lds + (32 * TI * wm + li) * BK;
-  const _Float16* b_base = lds + 2 * APL + (64 * wn + li) * BK;
-  __builtin_amdgcn_s_setprio(1);
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  for (int kt = kt0; kt < nk; ++kt) {
-    const int stage = (kt - kt0) & 1;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int ko = ((2 * ks + lh) ^ sw) << 3;
-      f16x8 af[TI][2], bf[2][2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          if (t < TI) af[t][p] = *reinterpret_cast<const f16x8*>(a_base + stage * STG + p * APL + 32 * t * BK + ko);
-          bf[t][p] = *reinterpret_cast<const f16x8*>(b_base + stage * STG + p * PLANE + 32 * t * BK + ko);
-        }
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);  // lo * hi
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);  // hi * lo
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);  // hi * hi
-        }
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  __builtin_amdgcn_s_setprio(0);
-
-  float* C = g.c;
-  float* S = g.split_k > 1 ? g.splitk_ws + (int64_t)blockIdx.z * g.m * g.n : nullptr;
-#pragma unroll
-  for (int i = 0; i < TI; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + 64 * wn + 32 * j + li;
-      if (col >= g.n) continue;
-      const float wi = winv_r[j];
-      const float bv = HAS_BIAS ? g.bias[col] : 0.f;
-      const int row0 = m0 + 32 * TI * wm + 32 * i + 4 * lh;
-      const bool act = g.act_silu_from >= 0 && col >= g.act_silu_from;
-      const bool rows_in = row0 + 27 < g.m;
-      if (S != nullptr) {
-        float* sp = S + (int64_t)row0 * g.n + col;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ro = (r & 3) + 8 * (r >> 2);
-          if (rows_in || row0 + ro < g.m) sp[(int64_t)ro * g.n] = acc[i][j][r] * (wi * ainv_r[i][r]);
-        }
-        continue;
-      }
-      float* cp = C + (int64_t)row0 * g.ldc + col;
-      const float* rp = HAS_RES ? g.residual + (int64_t)row0 * g.ldc + col : nullptr;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ro = (r & 3) + 8 * (r >> 2);
-        if (rows_in || row0 + ro < g.m) {
-          float v = acc[i][j][r] * (wi * ainv_r[i][r]) + bv;
-          if (HAS_RES) v += rp[(int64_t)ro * g.ldc];
-          if (act) v = silu_hw(v);
-          cp[(int64_t)ro * g.ldc] = v;
-        }
-      }
-    }
-  }
-}
-
 // One wave per row (K <= 3072): planes[0] = hi, planes[1] = lo of scale * a[r][k] (* gate[r][k]), K-tile-major ((r, k) at
 // (k / 32) * kt + r * 32 + k % 32); inv[r] = 1 / scale (exact power of two).  The stand-alone form of what the norm kernels
 // do in their epilogue.
@@ -466,20 +307,6 @@ static void launch_stage(const GemmArgs& g, dim3 grid, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_f16x2p_kernel<false, false, NSTAGE, TI, WM, WN>), grid, block, 0, stream, g);
 }
 
-template <int TI, int WM, int WN, int NL>
-static void launch_ws(const GemmArgs& g, dim3 grid, hipStream_t stream) {
-  const bool hb = g.bias != nullptr, hr = g.residual != nullptr;
-  dim3 block(64 * (WM * WN + NL));
-  if (hb && hr)
-    hipLaunchKernelGGL((gemm_f16x2p_ws_kernel<true, true, TI, WM, WN, NL>), grid, block, 0, stream, g);
-  else if (hb)
-    hipLaunchKernelGGL((gemm_f16x2p_ws_kernel<true, false, TI, WM, WN, NL>), grid, block, 0, stream, g);
-  else if (hr)
-    hipLaunchKernelGGL((gemm_f16x2p_ws_kernel<false, true, TI, WM, WN, NL>), grid, block, 0, stream, g);
-  else
-    hipLaunchKernelGGL((gemm_f16x2p_ws_kernel<false, false, TI, WM, WN, NL>), grid, block, 0, stream, g);
-}
-
 // Workgroup tile of a launch.  64 x 128 where 128-row tiles would leave CUs without a workgroup AND K is short (16M at 1024
 // slots: proj_up's 1536 x 1024 x 512 halves are 96 tiles of 128 x 128 -- 26.0 us -- or 192 of 64 x 128 -- 17.8 us); long-K
 // launches keep 128 rows (inside the two-slice pipeline the small tile's 1.5 x operand traffic per flop costs Mamba-48M 2.3 %
@@ -511,22 +338,6 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
     S = gemm_choose_split_k(g);
   // (the split-K chooser counts K tiles of its own BK: an empty split would read past the operand planes)
   LRAM_REQUIRE(S == 1 || (int64_t)(S - 1) * g.k_tiles_per_split < g.k / BK, "gemm f16x2 (pre-split operands): empty K split");
-  // LRAM_F16P_WS (experiment): loader / consumer form -- 1: 128 x 128 + 2 loader waves, 2: 256 x 128 + 4, 3: 128 x 128 + 1, 4: 256 x 128 + 2
-  const char* wv = std::getenv("LRAM_F16P_WS");
-  const int ws = wv ? std::atoi(wv) : 0;
-  if (ws >= 1 && ws <= 4) {
-    const int bm_ws = (ws == 2 || ws == 4) ? 256 : 128;
-    const int tiles_ws = ((g.m + bm_ws - 1) / bm_ws) * ((g.n + 127) / 128);
-    dim3 grid_ws(tiles_ws, 1, S);
-    gemm_choose_xcd_split(g, bm_ws, 128, 4);
-    if (ws == 1) launch_ws<2, 2, 2, 2>(g, grid_ws, stream);
-    else if (ws == 2) launch_ws<2, 4, 2, 4>(g, grid_ws, stream);
-    else if (ws == 3) launch_ws<2, 2, 2, 1>(g, grid_ws, stream);
-    else launch_ws<2, 4, 2, 2>(g, grid_ws, stream);
-    LRAM_HIP_CHECK(hipGetLastError());
-    if (S > 1) launch_splitk_reduce(g, stream);
-    return;
-  }
   const int bm = gemm_f16x2p_tile(g, S), bn = 128;
   const int tiles = ((g.m + bm - 1) / bm) * ((g.n + bn - 1) / bn);
   dim3 grid(tiles, 1, S);
