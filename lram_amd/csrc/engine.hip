@@ -188,8 +188,9 @@ struct lram_engine {
   static constexpr int cell_unroll = 16;  // C rows in flight per thread of the materialised cell kernel
   std::vector<hipStream_t> micro_streams;
   hipStream_t hbm_stream = nullptr;
-  std::vector<hipEvent_t> sync_events;
-  size_t sync_used = 0;
+  std::vector<hipEvent_t> sync_events, edge_events;   // engine-internal edges (device-scope fence) / fork + join with the caller's stream
+  size_t sync_used = 0, edge_used = 0;
+  bool event_device_scope = true;   // LRAM_EVENT_SCOPE=system: default (system-scope) events for the internal edges too
   // profiling of the dominant recurrent kernel
   bool prof_on = false;
   int prof_every = 1;       // lram_profile_begin_sampled: every n-th lram_step is timed (its launches carry the event pairs)
@@ -205,6 +206,7 @@ struct lram_engine {
     if (hbm_stream) (void)hipStreamDestroy(hbm_stream);
     for (hipStream_t ms : micro_streams) (void)hipStreamDestroy(ms);
     for (hipEvent_t ev : sync_events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : edge_events) (void)hipEventDestroy(ev);
     for (auto& e : prof_events) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
@@ -840,8 +842,10 @@ void prof_record(lram_engine* e, hipStream_t s, bool start, bool aux = false) {
   if (start) {
     if (e->prof_used == e->prof_events.size()) {
       hipEvent_t a, b;
-      LRAM_HIP_CHECK(hipEventCreate(&a));
-      LRAM_HIP_CHECK(hipEventCreate(&b));
+      // (timing only: no system-scope fence -- the header's own advice for events that measure)
+      const unsigned flags = e->event_device_scope ? hipEventDisableSystemFence : hipEventDefault;
+      LRAM_HIP_CHECK(hipEventCreateWithFlags(&a, flags));
+      LRAM_HIP_CHECK(hipEventCreateWithFlags(&b, flags));
       e->prof_events.emplace_back(a, b);
       e->prof_aux.push_back(0);
     }
@@ -862,32 +866,28 @@ struct Slice {
 
 // `dst` waits for everything enqueued so far on `src` (event from the engine's pool; also legal under
 // stream capture, where it becomes a graph edge).
-void stream_after(lram_engine* e, hipStream_t dst, hipStream_t src) {
+// boundary = false: both streams are the engine's own (slice streams, state-pass stream).  Those events are created with
+// hipEventDisableSystemFence: a default event performs a SYSTEM-scope release / acquire when it is recorded -- cache write-back
+// and invalidation for the host's and other devices' benefit -- ~150 times per env-step, between kernels of one device whose
+// launches already order their memory at device scope.  boundary = true (fork from / join into the caller's stream): default
+// events, the caller may hand the results to a copy engine or the host next.
+void stream_after(lram_engine* e, hipStream_t dst, hipStream_t src, bool boundary = false) {
   if (dst == src) return;
   // ring of events: a wait captures the record that precedes it at call time, so re-recording an event later
   // (next timestep / next call) cannot disturb waits that are already enqueued
   constexpr size_t kRing = 512;
-  if (e->sync_events.size() < kRing && e->sync_used >= e->sync_events.size()) {
+  std::vector<hipEvent_t>& pool = boundary ? e->edge_events : e->sync_events;
+  size_t& used = boundary ? e->edge_used : e->sync_used;
+  if (pool.size() < kRing && used >= pool.size()) {
     hipEvent_t nev;
-    LRAM_HIP_CHECK(hipEventCreateWithFlags(&nev, hipEventDisableTiming));
-    e->sync_events.push_back(nev);
+    unsigned flags = hipEventDisableTiming;
+    if (!boundary && e->event_device_scope) flags |= hipEventDisableSystemFence;
+    LRAM_HIP_CHECK(hipEventCreateWithFlags(&nev, flags));
+    pool.push_back(nev);
   }
-  hipEvent_t ev = e->sync_events[e->sync_used++ % e->sync_events.size()];
+  hipEvent_t ev = pool[used++ % pool.size()];
   LRAM_HIP_CHECK(hipEventRecord(ev, src));
   LRAM_HIP_CHECK(hipStreamWaitEvent(dst, ev, 0));
-}
-
-// Split form of stream_after: record now, let another stream wait later (same event ring).
-hipEvent_t record_on(lram_engine* e, hipStream_t src) {
-  constexpr size_t kRing = 512;
-  if (e->sync_events.size() < kRing && e->sync_used >= e->sync_events.size()) {
-    hipEvent_t nev;
-    LRAM_HIP_CHECK(hipEventCreateWithFlags(&nev, hipEventDisableTiming));
-    e->sync_events.push_back(nev);
-  }
-  hipEvent_t ev = e->sync_events[e->sync_used++ % e->sync_events.size()];
-  LRAM_HIP_CHECK(hipEventRecord(ev, src));
-  return ev;
 }
 
 // Slices for this call.  One slice on the caller's stream unless micro-batching is on: then n_micro slices on
@@ -919,12 +919,12 @@ std::vector<Slice> make_slices(lram_engine* e, hipStream_t s, hipStream_t* hbm) 
 }
 
 void fork_slices(lram_engine* e, const std::vector<Slice>& sl, hipStream_t hbm, hipStream_t s) {
-  for (const Slice& x : sl) stream_after(e, x.s, s);
-  stream_after(e, hbm, s);
+  for (const Slice& x : sl) stream_after(e, x.s, s, true);
+  stream_after(e, hbm, s, true);
 }
 void join_slices(lram_engine* e, const std::vector<Slice>& sl, hipStream_t hbm, hipStream_t s) {
-  for (const Slice& x : sl) stream_after(e, s, x.s);
-  stream_after(e, s, hbm);
+  for (const Slice& x : sl) stream_after(e, s, x.s, true);
+  stream_after(e, s, hbm, true);
 }
 
 // ---- mLSTM block, split at the cell kernel -----------------------------------------------------------
@@ -1470,7 +1470,7 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   const lram_config& c = e->cfg;
   const int D = c.d_model, T = c.tokens_per_step;
   const int64_t obs_w = emb ? D : c.state_dim;
-  e->sync_used = 0;
+  e->sync_used = 0, e->edge_used = 0;
   // Stored context is consumed in chunks: every block then reads and writes its recurrent state once per chunk
   // instead of once per timestep.  Up to 4 timesteps (12 tokens) per chunk through the token-sequential kernels,
   // up to 21 (63 tokens) through the chunkwise matrix-core kernels (mlstm_chunk.hip).
@@ -1646,6 +1646,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_MIN")) e->gemm_skinny_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_FRONT_MULTI")) e->front_multi = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_FRONT_MIN_ENVS")) e->front_min_envs = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("LRAM_EVENT_SCOPE")) e->event_device_scope = std::string(v) != "system";
     *out = e.release();
   });
 }
@@ -1804,7 +1805,7 @@ int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_
     const size_t bytes = sizeof(float) * (size_t)e->B * tokens * e->cfg.d_model;
     if (!lazy_active(e, tokens)) lazy_materialize(e, s);
     LRAM_HIP_CHECK(hipMemcpyAsync(e->X.p, dev_inputs_embeds, bytes, hipMemcpyDeviceToDevice, s));
-    e->sync_used = 0;
+    e->sync_used = 0, e->edge_used = 0;
     hipStream_t hbm;
     const std::vector<Slice> sl = make_slices(e, s, &hbm);
     if (sl.size() > 1) fork_slices(e, sl, hbm, s);

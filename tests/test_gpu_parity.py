@@ -539,11 +539,12 @@ def test_errors_are_loud(hip_lib):
     eng.close()
 
 
-@pytest.mark.parametrize("name,B", [("xlstm_16m", 400), ("mamba_48m", 352)])
+@pytest.mark.parametrize("name,B", [("xlstm_16m", 400), ("mamba_48m", 352), ("xlstm_206m", 176)])
 def test_presplit_projection_operands_change_nothing(hip_lib, name, B, monkeypatch):
     """LRAM_GEMM_PRESPLIT (default on): the norms ahead of proj_up / in_proj write the f16x2 GEMM's operand planes instead of
     fp32 rows + row maxima and the projection runs on gemm_f16x2p.hip.  Same pieces, same products, same order: the engine's
-    actions, hidden states and recurrent state are BIT-identical with the knob off (>= 1024 operand rows per launch)."""
+    actions, hidden states and recurrent state are BIT-identical with the knob off (>= 1024 operand rows per launch; the 206M
+    stack's wide weights take the f16x2 kernels from 512 rows -- the other clause of the shared predicate `f16x2_rows`)."""
     from lram_amd.engine import Engine
     spec = preset(name)
     sd = init_state_dict(spec, seed=91)
