@@ -317,6 +317,9 @@ def main(argv=None, engine_factory=None, device=None):
             build.build(force=False, verbose=False)
     ldist.barrier()
     on_gpu = dev.type == "cuda"
+    # the N > 1 code path (all-gather per step, collective report) -- also with ONE rank under LRAM_DIST_SINGLE_RANK=1, which is
+    # how a one-GPU box puts RCCL through it (tests/test_gpu_dist_single_rank.py)
+    dist_on = world > 1 or ldist._single_rank_collectives()
 
     def sync():
         if on_gpu:
@@ -385,7 +388,7 @@ def main(argv=None, engine_factory=None, device=None):
             a, _ = eng.step(emb, rtgs[t], reward_tok, masks[t], discrete=True, obs_is_embedding=True)
         else:
             a, _ = eng.step(obs_ring[t % n_ring], rtgs[t], reward_tok, masks[t])
-        if world > 1:
+        if dist_on:
             a = ldist.all_gather_actions(a, args.global_batch if args.global_batch > 0 else None)
         return a
 
@@ -446,7 +449,7 @@ def main(argv=None, engine_factory=None, device=None):
         from lram_amd.engine import load_library
         out["build_id"] = load_library().lram_build_id().decode()
         out["build_id_matches_sources"] = out["build_id"] == _build.source_hash()
-    if world > 1:   # (every rank takes part; rank 0 logs it and carries it on the line)
+    if dist_on:   # (every rank takes part; rank 0 logs it and carries it on the line)
         out["collective"] = ldist.collective_report(torch.zeros(B, last.shape[-1], dtype=last.dtype, device=last.device),
                                                     args.global_batch if args.global_batch > 0 else None)
         if rank == 0:
@@ -458,7 +461,7 @@ def main(argv=None, engine_factory=None, device=None):
         if cli_stub and rank == 0:
             print(json.dumps(dict(out, last_actions=last.tolist())), flush=True)
         out["last_actions"] = last
-        if world > 1:
+        if dist_on:
             torch.distributed.destroy_process_group()
         return out
 
@@ -479,7 +482,7 @@ def main(argv=None, engine_factory=None, device=None):
             d_rtg.copy_(h_rtg[t], non_blocking=True)
             d_mask.copy_(h_mask[t], non_blocking=True)
             a, _ = eng.step(d_obs, d_rtg, reward_tok, d_mask)
-            if world > 1:
+            if dist_on:
                 a = ldist.all_gather_actions(a, args.global_batch if args.global_batch > 0 else None)
             h_act.copy_(a, non_blocking=True)
             torch.cuda.current_stream(dev).synchronize()   # the caller needs the actions before it can step its envs
@@ -666,7 +669,7 @@ def main(argv=None, engine_factory=None, device=None):
         out["cpu_baseline"] = cpu_baseline(spec, sd)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
     return out
 

@@ -21,10 +21,22 @@ def dist_env() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def _single_rank_collectives() -> bool:
+    """LRAM_DIST_SINGLE_RANK=1: a WORLD_SIZE == 1 job still creates its process group and issues every collective (each
+    is the identity then).  Not a speed option: it is how a one-GPU box puts RCCL through this module's code --
+    communicator creation bound to the device, all_gather_into_tensor, all_reduce, barrier -- before the first N-GPU run
+    (tests/test_gpu_dist_single_rank.py)."""
+    return os.environ.get("LRAM_DIST_SINGLE_RANK", "0") == "1"
+
+
+def _active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _single_rank_collectives())
+
+
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from the torchrun environment (no-op for WORLD_SIZE == 1)."""
     rank, world, local_rank = dist_env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _single_rank_collectives()) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -46,7 +58,7 @@ def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 def all_gather_actions(local_actions: torch.Tensor, total: Optional[int] = None) -> torch.Tensor:
     """Concatenate every rank's [B_r, A] action slice in rank order -> [B, A] on every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return local_actions
     world = dist.get_world_size()
     local_actions = local_actions.contiguous()
@@ -66,7 +78,7 @@ def all_gather_actions(local_actions: torch.Tensor, total: Optional[int] = None)
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
@@ -80,7 +92,7 @@ def count_ranks(device) -> int:
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -92,7 +104,7 @@ def collective_report(sample: torch.Tensor, total: Optional[int] = None, iters: 
     library version (RCCL reports through torch.cuda.nccl.version()), the all-gather of one action tensor timed over
     `iters` back-to-back calls between device synchronisations (latency-bound: 128 KB per rank at 4096 env slots).  Every rank
     must call it; {} without a process group."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return {}
     import time
     backend = dist.get_backend()
