@@ -39,9 +39,10 @@ def test_c4_206m_full_depth_continuous_head(hip_lib, model_206m):
     from tests.test_gpu_parity import _run_parity
     spec, sd = model_206m
     sd = {k: v for k, v in sd.items() if not k.startswith("embed_image.")}
-    # all 20 blocks, 2 env-steps incl. the embed_ln token tap and the WHOLE final state (a 200-step episode of this stack against a
+    # all 20 blocks, 5 env-steps incl. the embed_ln token tap and the WHOLE final state (fewer steps leave so few compared rows
+    # that the handful of ill-conditioned ones exceed the 5 % cap on the float64 rule) (a 200-step episode of this stack against a
     # committed oracle fixture: tests/test_gpu_horizon.py; the live oracle takes 1-3 s per 206M step on the GPU boxes' hosts), random resets: tokens, hidden states, actions (1e-4, no ties) and the whole final state
-    assert _run_parity("xlstm_206m", B=3, steps=2, spec=spec, sd=sd, cond_aware=True) == 0
+    assert _run_parity("xlstm_206m", B=3, steps=5, spec=spec, sd=sd, cond_aware=True) == 0
 
 
 def test_c4_206m_atari_frames_discrete_head(hip_lib, model_206m):
