@@ -152,6 +152,34 @@ def test_bench_starts_its_own_ranks_from_a_plain_process(tmp_path):
     assert out["n_gpus"] == 2 == out["ranks_seen"]
 
 
+def test_bench_single_rank_collectives_mode_on_gloo():
+    """LRAM_DIST_SINGLE_RANK=1 (how a one-GPU box puts RCCL through the N > 1 path: tests/test_gpu_dist_single_rank.py): a
+    WORLD_SIZE == 1 job creates its process group and issues every collective; here the CPU twin over gloo with the stand-in engine."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, LRAM_DIST_SINGLE_RANK="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config", "xlstm_tiny",
+           "--batch", "6", "--engine-factory", os.path.join(root, "tests", "stub_engine.py") + ":factory"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1
+    assert line["collective"]["backend"] == "gloo" and line["collective"]["world_size"] == 1
+    assert torch.tensor(line["last_actions"]).shape == (6, 4)
+    # without the switch a single rank creates no process group and reports no collective
+    env.pop("LRAM_DIST_SINGLE_RANK")
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "collective" not in json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     import subprocess
     import sys

@@ -202,3 +202,30 @@ def test_lazy_fused_group_norm_variant(hip_lib, monkeypatch):
     for blk in (0, 2, 7):
         assert rel_err(fused.export_state_tensor(blk, 0), base.export_state_tensor(blk, 0)) < 2e-4
     base.close(), fused.close()
+
+
+def test_lazy_peek_looks_without_folding(hip_lib):
+    """lram_lazy_peek (evidence hook of the long-horizon tests): g, m and the pending-token counts of the lazy representation
+    without the fold an export triggers; refused in materialised mode and for sLSTM blocks."""
+    from lram_amd.engine import Engine, LramError
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=59)
+    B = 6
+    eng = Engine(spec, sd, B, device="cuda:0")
+    eng.set_state_mode("lazy", 13)
+    seq = make_inputs(spec, B, 5, seed=29, reset_prob=0.0)
+    _run(eng, seq)
+    pend = eng.lazy_peek(0, "pending")
+    # 5 steps x 3 tokens, minus what an env folded when its phase came up ((step + env) % 13 == 0 within these steps)
+    assert pend.shape == (B,) and float(pend.max()) == 15.0 and float(pend.min()) >= 3.0
+    g, m = eng.lazy_peek(0, "g"), eng.lazy_peek(0, "m")
+    assert g.shape == (B, spec.n_heads) and bool((g > 0).all()) and bool((g <= 1).all()) and bool(torch.isfinite(m).all())
+    assert torch.equal(eng.lazy_peek(0, "pending"), pend)            # looking twice changes nothing
+    assert torch.equal(m.view(-1), eng.export_state_tensor(0, 2).view(-1))   # (the export folds: afterwards nothing is pending)
+    assert float(eng.lazy_peek(0, "pending").max()) == 0.0
+    with pytest.raises(LramError):
+        eng.lazy_peek(spec.slstm_at[0], "g")
+    eng.set_state_mode("eager")
+    with pytest.raises(LramError):
+        eng.lazy_peek(0, "g")
+    eng.close()
