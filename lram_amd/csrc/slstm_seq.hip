@@ -1,4 +1,4 @@
-// sLSTM recurrence of a whole env-step (T tokens) as ONE launch for large env slices (head dim 128) on gfx950.
+// sLSTM recurrence of a whole env-step (T tokens) as ONE launch for large env slices (head dims 128 / 192 / 256 / 320 / 384) on gfx950.
 //
 // The generic path runs, per token, a batched per-head GEMM  ry = R_g h_{t-1}  (bf16x3 tile kernel, [envs, 4 gates, H]
 // through HBM) and the pointwise cell kernel after it: 2 T = 6 dependent launches of 25-90 us each beside a read pass,
@@ -16,8 +16,11 @@
 //     ([3P] slstm_pointwise: per-element n == 0 first-step rule) is lane-local: no exchange of gate sums at all;
 //   * the cell state (c, n, m) of a lane's 16 (env, channel) pairs lives in registers across the T tokens and is written
 //     back once; h_t goes to LDS (next token's A operand) and to the output rows.
-// The k index of an MFMA step is split over the lane halves as k = 64 (lane >> 5) + j (j = 0 .. 63): each lane reads its A
+// The k index of an MFMA step is split over the lane halves as k = (SDH / 2) (lane >> 5) + j (j = 0 .. SDH / 2 - 1): each lane reads its A
 // operands as float4 runs of its env's h row in LDS.
+// Round 5: templated on the head dim (SDH / 32 waves per workgroup: 4 at 128 -- the 16M model --, 10 at 320 -- the 206M model's
+// sLSTM blocks --; from nine waves the kernel is built for three waves per SIMD, 168 registers); 448 (xlstm_huge_half) would need
+// fourteen waves at 128 registers and keeps the per-token path.
 //
 // Arithmetic: products and sums in fp32 exactly as an fma chain per lane half, the two halves added inside the matrix
 // instruction; the gate pre-activations differ from the GEMM path's (bf16x3, different summation order) by fp32 rounding.
@@ -30,7 +33,7 @@ namespace lram {
 typedef float sq_f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
-constexpr int kEnv = 32, kSDH = 128, kPitch = kSDH + 4;
+constexpr int kEnv = 32;
 
 // rt2[((head * SDH + k) * SDH + ch) * 4 + g] = rt[((head * 4 + g) * SDH + ch) * SDH + k]     (rt: [NH, 4, out, in])
 __global__ __launch_bounds__(256) void slstm_pack_rt_kernel(const float* rt, float* rt2, int NH, int SDH) {
@@ -44,8 +47,10 @@ __global__ __launch_bounds__(256) void slstm_pack_rt_kernel(const float* rt, flo
   rt2[i] = rt[(((int64_t)head * 4 + g) * SDH + ch) * SDH + k];
 }
 
-template <int T>
-__global__ __launch_bounds__(256, 2) void slstm_seq_kernel(SlstmSeqArgs a) {
+template <int T, int kSDH>
+__global__ __launch_bounds__(2 * kSDH, kSDH <= 256 ? 2 : 3) void slstm_seq_kernel(SlstmSeqArgs a) {
+  constexpr int kPitch = kSDH + 4, kHalf = kSDH / 2;   // K per lane half
+  static_assert(kSDH % 32 == 0 && kHalf % 8 == 0, "head dim: a multiple of 32 whose half is a multiple of the 8-deep product round");
   __shared__ __attribute__((aligned(16))) float hs[2][kEnv][kPitch];
   const int H = a.H;
   const int head = blockIdx.x % a.NH, b0 = (blockIdx.x / a.NH) * kEnv;
@@ -53,15 +58,11 @@ __global__ __launch_bounds__(256, 2) void slstm_seq_kernel(SlstmSeqArgs a) {
   const int ch = head * kSDH + 32 * w + li;  // this lane's channel (column of H)
   const int64_t BH = (int64_t)a.state_B * H;
 
-  // ---- h_{-1} of the workgroup's envs and head -> LDS (256 threads: 32 envs x 32 float4) ----
-  {
-    const int e = tid >> 3, q = tid & 7;
+  // ---- h_{-1} of the workgroup's envs and head -> LDS (32 envs x SDH / 4 float4) ----
+  for (int idx = tid; idx < kEnv * (kSDH / 4); idx += 2 * kSDH) {
+    const int e = idx / (kSDH / 4), c4 = 4 * (idx % (kSDH / 4));
     const int b = min(b0 + e, a.B - 1);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c4 = 4 * (q + 8 * i);
-      *reinterpret_cast<float4*>(&hs[0][e][c4]) = *reinterpret_cast<const float4*>(a.state + (int64_t)b * H + head * kSDH + c4);
-    }
+    *reinterpret_cast<float4*>(&hs[0][e][c4]) = *reinterpret_cast<const float4*>(a.state + (int64_t)b * H + head * kSDH + c4);
   }
   // ---- this lane's cells: envs e_r = (r & 3) + 8 (r >> 2) + 4 lh, r = 0 .. 15 (the accumulator rows it holds) ----
   float cs[16], ns[16], ms[16];
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void slstm_seq_kernel(SlstmSeqArgs a) {
     cs[r] = st[BH], ns[r] = st[2 * BH], ms[r] = st[3 * BH];
   }
   const float bi = a.bias[ch], bf = a.bias[H + ch], bz = a.bias[2 * H + ch], bo = a.bias[3 * H + ch];
-  const float* bp = a.rt2 + (((int64_t)head * kSDH + 64 * lh) * kSDH + 32 * w + li) * 4;  // k = 64 lh + j: + j * SDH * 4
+  const float* bp = a.rt2 + (((int64_t)head * kSDH + kHalf * lh) * kSDH + 32 * w + li) * 4;  // k = kHalf lh + j: + j * SDH * 4
   __syncthreads();
 
   // (the token loop stays a loop and the kernel is built for two waves per SIMD -- 256 registers, accumulators included: fully
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void slstm_seq_kernel(SlstmSeqArgs a) {
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-    const float* ap = &hs[cur][li][64 * lh];
+    const float* ap = &hs[cur][li][kHalf * lh];
     // B operands: 4 k steps (4 float4) in flight ahead of the products that consume them, two register sets, the loop
     // NOT unrolled further (unrolled, hipcc hoists all 64 float4 of the token above the first product: 256 registers)
     constexpr int PF = 4;
@@ -108,10 +109,10 @@ __global__ __launch_bounds__(256, 2) void slstm_seq_kernel(SlstmSeqArgs a) {
     };
     load_b(bq0, 0);
 #pragma unroll 1
-    for (int j0 = 0; j0 < 64; j0 += 2 * PF) {
+    for (int j0 = 0; j0 < kHalf; j0 += 2 * PF) {
       load_b(bq1, j0 + PF);
       products(bq0, j0);
-      load_b(bq0, min(j0 + 2 * PF, 64 - PF));   // (unconditional: past the end it re-requests the last set and drops it)
+      load_b(bq0, min(j0 + 2 * PF, kHalf - PF));   // (unconditional: past the end it re-requests the last set and drops it)
       products(bq1, j0 + PF);
     }
     // pointwise cell ([3P] slstm_pointwise), lane-local: accumulator row r of tile g = gate g of (env e_r, this channel);
@@ -163,7 +164,11 @@ __global__ __launch_bounds__(256, 2) void slstm_seq_kernel(SlstmSeqArgs a) {
 }
 }  // namespace
 
-bool slstm_seq_supported(int H, int NH, int T) { return NH > 0 && H == NH * kSDH && T >= 1 && T <= 4; }
+bool slstm_seq_supported(int H, int NH, int T) {
+  if (NH <= 0 || H % NH != 0 || T < 1 || T > 4) return false;
+  const int sdh = H / NH;
+  return sdh == 128 || sdh == 192 || sdh == 256 || sdh == 320 || sdh == 384;
+}
 
 void launch_slstm_pack_rt(const float* rt, float* rt2, int NH, int SDH, hipStream_t stream) {
   const int64_t n = (int64_t)NH * 4 * SDH * SDH;
@@ -171,17 +176,28 @@ void launch_slstm_pack_rt(const float* rt, float* rt2, int NH, int SDH, hipStrea
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
+template <int SDH>
+static void launch_seq_sdh(const SlstmSeqArgs& a, hipStream_t stream) {
+  const dim3 grid((unsigned)(a.NH * ((a.B + kEnv - 1) / kEnv))), block(2 * SDH);
+  switch (a.T) {
+    case 1: hipLaunchKernelGGL((slstm_seq_kernel<1, SDH>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((slstm_seq_kernel<2, SDH>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((slstm_seq_kernel<3, SDH>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((slstm_seq_kernel<4, SDH>), grid, block, 0, stream, a); break;
+  }
+}
+
 void launch_slstm_seq(const SlstmSeqArgs& a, hipStream_t stream) {
-  LRAM_REQUIRE(slstm_seq_supported(a.H, a.NH, a.T) && a.rt2 != nullptr, "sLSTM step kernel: head dim 128, 1..4 tokens");
+  LRAM_REQUIRE(slstm_seq_supported(a.H, a.NH, a.T) && a.rt2 != nullptr, "sLSTM step kernel: head dim 128 / 192 / 256 / 320 / 384, 1..4 tokens");
   // (the kernel's row offsets into gates / yout / state are 32-bit: slices beyond ~700k envs at H = 512 would wrap)
   LRAM_REQUIRE((int64_t)a.B * a.T * 4 * a.H < (1ll << 32) && (int64_t)a.state_B * a.H < (1ll << 30),
                "sLSTM step kernel: slice too large for its 32-bit row offsets");
-  const dim3 grid((unsigned)(a.NH * ((a.B + kEnv - 1) / kEnv))), block(256);
-  switch (a.T) {
-    case 1: hipLaunchKernelGGL(slstm_seq_kernel<1>, grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(slstm_seq_kernel<2>, grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(slstm_seq_kernel<3>, grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL(slstm_seq_kernel<4>, grid, block, 0, stream, a); break;
+  switch (a.H / a.NH) {
+    case 128: launch_seq_sdh<128>(a, stream); break;
+    case 192: launch_seq_sdh<192>(a, stream); break;
+    case 256: launch_seq_sdh<256>(a, stream); break;
+    case 320: launch_seq_sdh<320>(a, stream); break;
+    default: launch_seq_sdh<384>(a, stream); break;
   }
   LRAM_HIP_CHECK(hipGetLastError());
 }

@@ -65,6 +65,30 @@ def test_slstm_step_kernel_matches_oracle_and_the_gemm_path(hip_lib, B, micro):
     new.close(), old.close()
 
 
+@pytest.mark.parametrize("d_model,B", [(768, 37), (1024, 33), (1280, 40), (1536, 34)])
+def test_slstm_step_kernel_other_head_dims(hip_lib, d_model, B):
+    """Round 5: the kernel is templated on the sLSTM head dim -- 192 (xlstm_mediumplus), 256 (xlstm_large), 320 (the 206M stack's
+    sLSTM blocks, ten waves per workgroup), 384 (xlstm_hugeplus) beside the 16M model's 128: ragged env counts, restarts, 6 steps
+    against the oracle and the per-token GEMM path, state planes included."""
+    from lram_amd.config import ModelSpec
+    spec = ModelSpec(backbone="xlstm", d_model=d_model, n_blocks=2, slstm_at=[1])
+    sd = init_state_dict(spec, seed=83)
+    seq = make_inputs(spec, B, 6, seed=43, reset_prob=0.15)
+    new, old = _engine(spec, sd, B, True), _engine(spec, sd, B, False)
+    a_new, a_old = _run(new, seq), _run(old, seq)
+    ora = dt_ref.OraclePolicy(spec, sd)
+    ties = 0
+    for t, (obs, rtg, rew, mask) in enumerate(seq):
+        ref, dbg = ora.step(obs, rtg, rew, mask, return_debug=True)
+        ties += assert_actions_match(a_new[t], ref, dbg["logits"], spec, what=f"sLSTM step kernel, head dim {d_model // 4}, step {t}")
+    assert ties == 0
+    assert float((a_new - a_old).abs().max()) <= 1e-4
+    s_new, s_old = new.export_state_tensor(1, 0), old.export_state_tensor(1, 0)
+    assert rel_err(s_new, s_old) < 2e-5, rel_err(s_new, s_old)
+    assert rel_err(s_new, ora.state["block_1"]["slstm_state"]) < 2e-4
+    new.close(), old.close()
+
+
 def test_slstm_step_kernel_single_token_calls(hip_lib):
     """T = 1 encoder calls (lram_encoder_step, one token at a time) through the same kernel equal three-token calls."""
     spec = preset("xlstm_16m")
