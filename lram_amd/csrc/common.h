@@ -321,7 +321,7 @@ struct GroupNormArgs {
   const float* skip;   // mode 0
   const float* xa;     // mode 0 [rows, NH*DH]
   const float* u;      // mode 0 [rows, 2*NH*DH]
-  float* out;          // mode 0: g [rows, NH*DH] (may be null when planes are given); mode 1: x [rows, NH*DH] (+=)
+  float* out;          // mode 0: g [rows, NH*DH]; mode 1: x [rows, NH*DH] (+=)
   int rows, NH, DH, mode;
   float eps;
 };

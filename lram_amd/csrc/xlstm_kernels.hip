@@ -569,7 +569,7 @@ __global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
       o.z += bb.z;
       o.w += bb.w;
     }
-    float* dst = a.out != nullptr ? a.out + (int64_t)row * D + hd : nullptr;
+    float* dst = a.out + (int64_t)row * D + hd;
     if (a.mode == 0) {
       const float4 sk = *reinterpret_cast<const float4*>(a.skip + hd);
       const float4 xa = *reinterpret_cast<const float4*>(a.xa + (int64_t)row * D + hd);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
       o.y = (o.y + sk.y * xa.y) * silu_f(z.y);
       o.z = (o.z + sk.z * xa.z) * silu_f(z.z);
       o.w = (o.w + sk.w * xa.w) * silu_f(z.w);
-      if (a.out != nullptr) *reinterpret_cast<float4*>(dst) = o;
+      *reinterpret_cast<float4*>(dst) = o;
     } else {
       float4 x = *reinterpret_cast<const float4*>(dst);
       x.x += o.x;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B runs of the headline bench on ONE box, two rounds.  Each argument is one configuration:
 #   "VAR=val VAR2=val2 -- --bench-flag x"   (environment before " -- ", extra bench.py flags after it; either may be empty)
-# usage: bash scripts/gpu_ab.sh "LRAM_LAZY_UNROLL=4" "LRAM_LAZY_UNROLL=8 -- --micro 3"
+# usage: bash scripts/gpu_ab.sh "LRAM_GN_FUSE=0" "LRAM_GN_FUSE=1 -- --micro 3"
 mkdir -p gpurun_out
 out=gpurun_out/ab.txt
 : > $out
