@@ -763,7 +763,10 @@ bool f16x2_weight(const lram_engine* e, const float* w, int ldw, GemmArgs* g) {
 // validate_config).
 bool presplit_for(const lram_engine* e, const float* w, int rows, int n, int k) {
   if (!e->gemm_presplit || (k & 31) != 0 || e->XN2.p == nullptr || !f16x2_rows(e, rows, n, k)) return false;
-  return f16x2_weight(e, w, k, nullptr);
+  // (the kernel's LDS-DMA addresses an operand's two planes with 32-bit byte offsets: gemm_f16x2p_supported)
+  GemmArgs probe;
+  if ((int64_t)e->XN2.n * 4 >= (1ll << 31) || !f16x2_weight(e, w, k, &probe)) return false;
+  return 4 * probe.w2_plane < (1ll << 31);
 }
 
 int stream_slot(const lram_engine* e, hipStream_t s) {  // split-K slab / row-maximum region of the stream a GEMM runs on

@@ -88,9 +88,18 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p
   // wave.  Wave w takes pieces w, w + NW, ...  Lane l fills linear position (row = 16 rb + l / 4,
   // chunk position l & 3) and fetches logical chunk (l & 3) ^ ((row >> 2) & 3) of that row.  Rows beyond M / N are clamped
   // (their products land in rows / columns the epilogue drops).
-  const _Float16* A2 = reinterpret_cast<const _Float16*>(g.a2);
-  const _Float16* W2 = reinterpret_cast<const _Float16*>(g.w2);
-  const _Float16* src[PPW];
+  // BUFFER form of the LDS-DMA (round 5): one buffer resource per operand, based at the workgroup's first row; the per-lane byte
+  // offsets are loop-invariant 32-bit registers, the K tile's offset rides in the instruction's SCALAR offset.  The global form
+  // (`global_load_lds_dwordx4` on a 64-bit per-lane address + k0) cost the issuing wave ~220 ticks per instruction -- as long as the
+  // arithmetic it feeds; this form costs half (scripts/gemm_phases.cpp, profiles/r05_gemm_presplit_phase_profile.txt: 24576 x
+  // 2048 x 512 160 -> 140 us, Mamba in_proj 102 -> 87).  Offsets stay below 2^31: launch_gemm_f16x2p checks the plane sizes.
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(g.a2) + (int64_t)m0 * 32, 0, 0xffffffffu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(g.w2) + (int64_t)n0 * 32, 0, 0xffffffffu, 0x00020000);
+#endif
+  unsigned voff[PPW];
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int p = wave + NW * i;
@@ -100,23 +109,21 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p
     const int plane = q / rbs, rb = q % rbs;
     const int row = 16 * rb + (lane >> 2);
     const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    if (is_a) {
-      const int gm = min(m0 + row, g.m - 1);
-      src[i] = A2 + (int64_t)plane * g.a2_plane + (int64_t)gm * 32 + 8 * chunk;
-    } else {
-      const int gn = min(n0 + row, g.n - 1);
-      src[i] = W2 + (int64_t)plane * g.w2_plane + (int64_t)gn * 32 + 8 * chunk;
-    }
+    const int lrow = is_a ? min(m0 + row, g.m - 1) - m0 : min(n0 + row, g.n - 1) - n0;   // row relative to the resource's base
+    voff[i] = (unsigned)(((int64_t)plane * (is_a ? g.a2_plane : g.w2_plane) + (int64_t)lrow * 32 + 8 * chunk) * 2);
   }
+  const unsigned kt_bytes_a = (unsigned)(g.a2_kt * 2), kt_bytes_w = (unsigned)(g.w2_kt * 2);
   auto dma_tile = [&](int stage, int kt) {  // (K-tile-major planes: the tile's rows of a plane are one contiguous run)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int p = wave + NW * i;
-      const int64_t k0 = (int64_t)kt * (NW * i < NPA ? g.a2_kt : g.w2_kt);  // (pieces NW i .. NW i + NW - 1 belong to one operand)
+      const bool is_a = NW * i < NPA;   // (pieces NW i .. NW i + NW - 1 belong to one operand)
       // (LDS destination: wave-uniform base of the piece -- pieces lie in the stage in piece order: A hi, A lo, W hi, W lo;
       // the hardware adds lane * 16)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + k0),
-                                       (__attribute__((address_space(3))) void*)(lds + stage * STG + p * 512), 16, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? rsrc_a : rsrc_w, (__attribute__((address_space(3))) void*)(lds + stage * STG + p * 512), 16,
+                                               voff[i], (unsigned)kt * (is_a ? kt_bytes_a : kt_bytes_w), 0, 0);
+#endif
     }
   };
 
@@ -277,6 +284,8 @@ __global__ __launch_bounds__(256) void row_split_f16x2_kernel(const float* a, in
 }  // namespace
 
 bool gemm_f16x2p_supported(const GemmArgs& g) {
+  // (byte offsets of the buffer-form LDS-DMA are 32-bit: both planes of an operand within 2 GiB of its first row)
+  if (2 * g.a2_plane * 2 >= (1ll << 31) || 2 * g.w2_plane * 2 >= (1ll << 31)) return false;
   return g.a2 != nullptr && g.a2_inv != nullptr && g.w2 != nullptr && g.w_inv != nullptr && g.nb1 * g.nb2 == 1 &&
          (g.k % BK) == 0 && g.w2_kt >= 32 * (int64_t)g.n && g.a2_kt >= 32 * (int64_t)g.m && (g.w2_plane & 7) == 0 && (g.a2_plane & 7) == 0 &&
          (g.w2_kt & 7) == 0 && (g.a2_kt & 7) == 0 &&

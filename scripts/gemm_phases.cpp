@@ -105,7 +105,7 @@ template <int WM, int WN, int NSTAGE, int WPE>
 __global__ __launch_bounds__(64 * WM * WN, WPE) void skelg(const _Float16* A2, const _Float16* W2, int M, int N, int K, float* C, unsigned* phases) {
   constexpr int NW = WM * WN, BMT = 64 * WM, BNT = 64 * WN, APL = BMT * 32, PLANE = BNT * 32, STG = 2 * APL + 2 * PLANE;
   constexpr int NPA = 2 * (BMT / 16), NPIECE = NPA + 2 * (BNT / 16), PPW = NPIECE / NW;
-  __shared__ __attribute__((aligned(1024))) _Float16 lds[(NSTAGE >= 3 ? 2 : NSTAGE) * STG];
+  __shared__ __attribute__((aligned(1024))) _Float16 lds[(NSTAGE == 5 ? 1 : NSTAGE >= 3 ? 2 : NSTAGE) * STG];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = N / BNT;
@@ -118,7 +118,36 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void skelg(const _Float16* A2, c
   const _Float16* a_base = lds + (64 * wm + li) * 32;
   const _Float16* b_base = lds + 2 * APL + (64 * wn + li) * 32;
   unsigned p_dma = 0, p_wait = 0, p_mfma = 0, p_bar = 0;
+  // buffer form of the LDS-DMA: one resource per operand, per-lane byte offsets loop-invariant in 32-bit VGPRs, the K tile's offset
+  // in the scalar operand -- no per-instruction 64-bit vector address arithmetic
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A2, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W2, 0, 0x7fffffff, 0x00020000);
+#endif
+  unsigned voff[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int p = wave + NW * i;
+    const bool is_a = p < NPA;
+    const int q = is_a ? p : p - NPA, rbs = is_a ? BMT / 16 : BNT / 16;
+    const int plane = q / rbs, rb = q % rbs;
+    const int row = 16 * rb + (lane >> 2);
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    voff[i] = (unsigned)(((is_a ? plane * a_plane + (int64_t)(m0 + row) * 32 : plane * w_plane + (int64_t)(n0 + row) * 32) + 8 * chunk) * 2);
+  }
+  auto dmab = [&](int stage, int kt) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = wave + NW * i;
+      const bool is_a = NW * i < NPA;
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? ra : rw, (__attribute__((address_space(3))) void*)(lds + stage * STG + p * 512), 16, voff[i],
+                                               (unsigned)kt * (unsigned)(is_a ? M : N) * 64u, 0, 0);
+#endif
+    }
+  };
   auto dma = [&](int stage, int kt) {
+    if (NSTAGE >= 5) { dmab(stage, kt); return; }
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
       const int p = wave + NW * i;
@@ -238,7 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void skelg(const _Float16* A2, c
       const unsigned long long t3 = __builtin_amdgcn_s_memtime();
       p_wait += (unsigned)(t1 - t0), p_mfma += (unsigned)(t3 - t1);
     }
-  } else if (NSTAGE == 2) {
+  } else if (NSTAGE == 2 || NSTAGE == 6) {
     dma(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
       const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -343,9 +372,10 @@ int main() {
     CK(hipFree(ph)); CK(hipMalloc(&ph, (size_t)wgs * 16 * 8 * 4));
     rung("128 x 128, one stage (4 WG/CU)", skelg<2, 2, 1, 4>, 128, 128, 4);
     rung("128 x 128, two stages (2 WG/CU)", skelg<2, 2, 2, 2>, 128, 128, 4);
-    rung("128 x 128, two stages, REGISTER staged", skelg<2, 2, 4, 2>, 128, 128, 4);
-    rung("256 x 128, two stages, REGISTER staged", skelg<4, 2, 4, 2>, 256, 128, 8);
-    rung("256 x 256, two stages, REGISTER staged", skelg<4, 4, 4, 4>, 256, 256, 16);
+    rung("128 x 128, one stage, BUFFER lds loads", skelg<2, 2, 5, 4>, 128, 128, 4);
+    rung("128 x 128, two stages, BUFFER lds loads", skelg<2, 2, 6, 2>, 128, 128, 4);
+    rung("256 x 128, one stage, BUFFER lds loads", skelg<4, 2, 5, 4>, 256, 128, 8);
+    rung("256 x 256, two stages, BUFFER lds loads", skelg<4, 4, 6, 4>, 256, 256, 16);
     rung("128 x 128, two stages, DMA interleaved", skelg<2, 2, 3, 2>, 128, 128, 4);
     rung("256 x 128, two stages, DMA interleaved", skelg<4, 2, 3, 2>, 256, 128, 8);
     rung("256 x 256, two stages, DMA interleaved", skelg<4, 4, 3, 4>, 256, 256, 16);
