@@ -99,6 +99,9 @@ struct GemmArgs {
   // set by the launcher (gemm_choose_xcd_split): the 8 XCDs (each with its own 4 MB L2) take an xcd_gm x xcd_gn grid of
   // output blocks, xcd_gm * xcd_gn == 8; 0 = the one-dimensional map (each XCD a contiguous run of tiles, M-major)
   int xcd_gm = 0, xcd_gn = 0;
+  // ... or (panel_w > 0) the panel order: the tile grid is cut into column panels of panel_w tiles, walked row by row (odd
+  // panels bottom-up), and every XCD takes one contiguous eighth of that walk
+  int panel_w = 0;
   int mfma_prio = 0;      // set by the launcher: raise the wave's issue priority around the MFMA block
   int split_k = 1;        // set by the launcher
   int k_tiles_per_split = 0;
@@ -112,6 +115,17 @@ void gemm_choose_xcd_split(GemmArgs& g, int bm, int bn, int bytes_per_elem);
 // the tile a workgroup id maps to under that split (device side)
 __device__ __forceinline__ void gemm_tile_of(const GemmArgs& g, int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
   const int nwg = tiles_m * tiles_n;
+  if (g.panel_w > 0) {
+    const int x = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int pos = x * q + min(x, r) + (bid >> 3);           // XCD x owns walk positions [x q + min(x, r), ...)
+    const int per_panel = tiles_m * g.panel_w;
+    const int p = pos / per_panel, rem = pos - p * per_panel;
+    const int w = min(g.panel_w, tiles_n - p * g.panel_w);
+    const int row = rem / w;
+    tm = (p & 1) ? tiles_m - 1 - row : row;
+    tn = p * g.panel_w + rem - row * w;
+    return;
+  }
   if (g.xcd_gm > 0) {
     const int x = bid & 7, idx = bid >> 3;                    // XCD, position in that XCD's stream of workgroups
     const int bm_t = tiles_m / g.xcd_gm, bn_t = tiles_n / g.xcd_gn;   // tiles per band

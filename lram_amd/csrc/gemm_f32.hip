@@ -451,8 +451,17 @@ void gemm_choose_xcd_split(GemmArgs& g, int bm, int bn, int bytes_per_elem) {
     return v ? std::atoi(v) : 1;
   }();
   g.xcd_gm = g.xcd_gn = 0;
+  g.panel_w = 0;
   if (!on || g.nb1 * g.nb2 != 1) return;
   const int tiles_m = (g.m + bm - 1) / bm, tiles_n = (g.n + bn - 1) / bn;
+  // LRAM_GEMM_PANEL (measurement knob, read per launch: the bit-identity test walks through the orders): > 0 forces the panel
+  // order with that width
+  const char* pv = std::getenv("LRAM_GEMM_PANEL");
+  const int pw = pv ? std::atoi(pv) : 0;
+  if (pw > 0) {
+    g.panel_w = std::min(pw, tiles_n);
+    return;
+  }
   double best = 0.0;
   for (int gm = 8; gm >= 1; gm >>= 1) {
     const int gn = 8 / gm;
@@ -462,6 +471,12 @@ void gemm_choose_xcd_split(GemmArgs& g, int bm, int bn, int bytes_per_elem) {
     const double cost = (double)g.m * gn + (double)g.n * gm;
     if (g.xcd_gm == 0 || cost < best) best = cost, g.xcd_gm = gm, g.xcd_gn = gn;
   }
+  // No such split (the 206M stack's projections: no W band fits an L2; tile grids that 8 does not divide): column panels of 6
+  // tiles, each XCD a contiguous eighth of the walk.  Round 5, standalone launches, beyond-L2 reads / operand bytes: 206M
+  // proj_up 6.5 -> 2.8, proj_down 4.2 -> 3.2, its 16128-row prefill launches 30.6 -> 11.1 and 9.2 -> 3.6 (widths 6 / 8 / 10 within
+  // 10 % of each other; profiles/r05_gemm_tile_order.txt).  The launches themselves get 0 - 3 % shorter and no step time moves
+  // (the re-reads were served by the 256 MB memory-side cache, not by HBM), so this is traffic hygiene, not speed.
+  if (g.xcd_gm == 0) g.panel_w = std::min(6, tiles_n);
 }
 
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream) {

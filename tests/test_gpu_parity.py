@@ -191,6 +191,31 @@ def test_gemm_f16x2_presplit_every_tile_is_bit_identical(hip_lib, monkeypatch, t
         assert torch.equal(want2, got2), (m, n, k)
 
 
+@pytest.mark.parametrize("panel", [1, 5, 6, 99])
+def test_gemm_tile_order_is_a_bijection_on_the_device(hip_lib, monkeypatch, panel):
+    """The workgroup id -> output tile map (XCD-aware: a 2-D split of the tile grid over the 8 L2s where one fits, else column
+    panels; csrc/common.h gemm_tile_of) only renames workgroups: every order gives the same bits as every other, on tile grids
+    8 divides and on ones it does not, with a ragged last panel, for both f16x2 kernels."""
+    from lram_amd.engine import gemm_f32
+    outs = {}
+    for order in (None, panel):
+        if order is None:
+            monkeypatch.delenv("LRAM_GEMM_PANEL", raising=False)
+        else:
+            monkeypatch.setenv("LRAM_GEMM_PANEL", str(order))
+        for m, n, k in [(1536, 5120, 1280), (700, 900, 64), (3072, 3072, 768), (130, 1000, 96)]:
+            g = torch.Generator().manual_seed(m + n)
+            a = torch.randn(m, k, generator=g).cuda()
+            w = (torch.randn(n, k, generator=g) * 0.05).cuda()
+            for kern in ("f16x2", "f16x2p"):
+                outs[(order, m, n, kern)] = gemm_f32(a, w, kernel=kern)
+    torch.cuda.synchronize()
+    for (order, m, n, kern), got in outs.items():
+        if order is not None:
+            assert torch.equal(got, outs[(None, m, n, kern)]), (order, m, n, kern)
+            assert torch.equal(got, outs[(None, m, n, "f16x2")]), (order, m, n, kern)
+
+
 def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=2e-4, state_tol=2e-4, spec=None,
                 sd=None, cond_aware=False):
     """cond_aware: where the engine is further than the tolerance from the fp32 oracle, accept it if it is as close to
