@@ -50,6 +50,9 @@ constexpr int BK = 32;
 // 256-row / 256x256 workgroup tiles ...").  So was a loader / consumer form (two or four extra waves per workgroup that only issue
 // the LDS-DMA, the MFMA waves never touching global memory in the K loop, two stages, one barrier per K tile): bit-identical,
 // 1.3-1.5 x slower (r05_gemm_presplit_loader_consumer_sweep.txt; commit "Experiment: loader / consumer ...").
+// And the per-WAVE tile: waves of 128 x 64 (TI = 4: 512 B of LDS fragment reads per MFMA instead of 683) as 128 x 128 tiles of two
+// waves or 256 x 128 of four: bit-identical, 10-50 % slower on every shape a step launches, equal on the largest launch
+// (r05_gemm_presplit_wave_tile_sweep.txt).
 template <bool HAS_BIAS, bool HAS_RES, int NSTAGE, int TI, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p_kernel(GemmArgs g) {
   constexpr int NW = WM * WN;                       // waves per workgroup

@@ -65,10 +65,10 @@ def test_chunkwise_reset_mask(hip_lib):
     eng.close()
 
 
-@pytest.mark.parametrize("L", [44, 21, 5])
+@pytest.mark.parametrize("L", [32, 50, 44, 21, 5])
 def test_chunkwise_prefill_equals_sequential_steps(hip_lib, monkeypatch, L):
     """lram_prefill on the 16M geometry (4 heads x 256): chunkwise kernels == token-sequential prefill == L lram_step
-    calls == the CPU oracle.  L = 44 -> 15 + 15 + 14 timesteps, 21 -> one 63-token chunk, 5 -> 15 tokens."""
+    calls == the CPU oracle.  L = 32 -> 2 x 16 timesteps, 50 -> 17 + 17 + 16, 44 -> 15 + 15 + 14, 21 -> one 63-token chunk, 5 -> 15 tokens."""
     from lram_amd.engine import Engine
     spec = preset("xlstm_16m")
     sd = init_state_dict(spec, seed=41)

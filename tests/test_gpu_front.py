@@ -43,7 +43,7 @@ def _run(eng, seq):
     return torch.stack(acts).cpu()
 
 
-@pytest.mark.parametrize("B,micro", [(7, 1), (19, 2)])
+@pytest.mark.parametrize("B,micro", [(7, 1), (19, 2), (37, 2)])
 def test_multi_env_front_end_matches_oracle_and_the_per_env_kernel(hip_lib, B, micro):
     """Ragged env counts (the last workgroup of a slice holds fewer envs than the others), random restarts, 30 steps
     (every env folds at least twice): actions follow the oracle; conv / n / m / C states equal the per-env kernel's."""

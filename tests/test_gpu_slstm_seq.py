@@ -41,7 +41,7 @@ def _run(eng, seq):
     return torch.stack(acts).cpu()
 
 
-@pytest.mark.parametrize("B,micro", [(5, 1), (37, 1), (41, 2)])
+@pytest.mark.parametrize("B,micro", [(5, 1), (37, 1), (41, 2), (70, 2)])
 def test_slstm_step_kernel_matches_oracle_and_the_gemm_path(hip_lib, B, micro):
     """Ragged env counts (workgroups of 32 envs), random restarts (the per-element n == 0 first-step rule after a reset),
     12 steps: actions follow the oracle, the sLSTM state planes (h, c, n, m) equal the GEMM path's and the oracle's."""
