@@ -383,6 +383,8 @@ void launch_slstm_token(const SlstmTokenArgs& a, hipStream_t stream);
 struct SlstmSeqArgs {
   const float* gates = nullptr;  // [B*T, 4, H] input pre-activations (Wx)
   const float* rt2 = nullptr;    // [NH, SDH (k), SDH (channel), 4 (gate)] recurrent weights re-packed by launch_slstm_pack_rt
+  const uint16_t* rt2h = nullptr;  // != nullptr: the f16x2 form -- two f16 planes of the row-scaled weights (launch_slstm_pack_rt16)
+  const float* rinv = nullptr;     // ... and [NH, 4, SDH] inverse scales
   const float* bias = nullptr;   // [4, H]
   float* state = nullptr;        // [4, state_B, H] in/out (h, c, n, m planes)
   float* yout = nullptr;         // [B*T, H]
@@ -391,6 +393,7 @@ struct SlstmSeqArgs {
 bool slstm_seq_supported(int H, int NH, int T);
 void launch_slstm_seq(const SlstmSeqArgs& a, hipStream_t stream);
 void launch_slstm_pack_rt(const float* rt, float* rt2, int NH, int SDH, hipStream_t stream);  // rt: [NH, 4, out, in]
+void launch_slstm_pack_rt16(const float* rt, uint16_t* rt2h, float* rinv, int NH, int SDH, hipStream_t stream);
 
 // a[r, f] = gelu(p[r, f]) * p[r, F + f]      p: [rows, 2F]
 void launch_gelu_gate(const float* p, float* a, int rows, int F, hipStream_t stream);

@@ -106,7 +106,10 @@ struct lram_engine {
   bool gemm_presplit = true;   // LRAM_GEMM_PRESPLIT=0: the norms ahead of proj_up / in_proj write fp32 + row maxima (round 3) instead of
                                // the f16x2 GEMM's operand planes (gemm_f16x2p.hip)
   double gemm_counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // launches / fp32-equivalent FLOPs per dispatcher family (lram_gemm_counts)
-  std::vector<DevBuf> slstm_rt2;  // sLSTM: recurrent weights re-packed [head][k][channel][gate] per block (slstm_seq.hip), head dim 128
+  std::vector<DevBuf> slstm_rt2;  // sLSTM: recurrent weights re-packed per block for slstm_seq.hip: fp32 [head][k][channel][gate], or
+                                  // (f16x2 projections, the default) two f16 planes in the same bytes + slstm_rinv, the inverse row scales
+  std::vector<DevBuf> slstm_rinv;
+  bool slstm_seq_f32 = false;     // LRAM_SLSTM_SEQ=2: its exact-fp32 form even where the projections run as f16x2
   bool slstm_seq = true;          // LRAM_SLSTM_SEQ=0: per-token recurrent GEMM + pointwise launches for slices beyond the token kernel's
   std::vector<DevBuf> gate_coef;  // mLSTM: folded i / f gate coefficients per block (mlstm_front.hip), geometries it covers
   bool front_multi = true;     // LRAM_FRONT_MULTI=0: keep the one-workgroup-per-env front end for large launches too
@@ -226,6 +229,8 @@ struct lram_engine {
     gate_coef.clear();
     for (DevBuf& b : slstm_rt2) b.release();
     slstm_rt2.clear();
+    for (DevBuf& b : slstm_rinv) b.release();
+    slstm_rinv.clear();
   }
   void drop_graph() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -478,12 +483,18 @@ void finalize(lram_engine* e) {
     LRAM_HIP_CHECK(hipDeviceSynchronize());
   }
   e->slstm_rt2.assign(e->bw.size(), DevBuf());
+  e->slstm_rinv.assign(e->bw.size(), DevBuf());
   if (c.backbone == LRAM_BACKBONE_XLSTM && slstm_seq_supported(c.d_model, c.n_heads, c.tokens_per_step)) {
     for (size_t i = 0; i < e->bw.size(); ++i) {
       if (!c.block_is_slstm[i]) continue;
       const size_t sdh = (size_t)c.d_model / c.n_heads;
       e->slstm_rt2[i].alloc((size_t)c.n_heads * 4 * sdh * sdh);
-      launch_slstm_pack_rt(e->bw[i].rt, e->slstm_rt2[i].p, c.n_heads, (int)sdh, nullptr);
+      if (e->use_f16x2 && !e->slstm_seq_f32) {  // (two f16 planes: the bytes of the fp32 copy)
+        e->slstm_rinv[i].alloc((size_t)c.n_heads * 4 * sdh);
+        launch_slstm_pack_rt16(e->bw[i].rt, reinterpret_cast<uint16_t*>(e->slstm_rt2[i].p), e->slstm_rinv[i].p, c.n_heads, (int)sdh, nullptr);
+      } else {
+        launch_slstm_pack_rt(e->bw[i].rt, e->slstm_rt2[i].p, c.n_heads, (int)sdh, nullptr);
+      }
     }
     LRAM_HIP_CHECK(hipDeviceSynchronize());
   }
@@ -1147,7 +1158,11 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
   const bool seq = !tok_fused && e->slstm_seq && e->slstm_rt2[i].p != nullptr && slstm_seq_supported(Hs, NH, T);
   if (seq) {
     SlstmSeqArgs qa;
-    qa.gates = gates, qa.rt2 = e->slstm_rt2[i].p, qa.bias = w.rbias, qa.state = state, qa.yout = Y;
+    qa.gates = gates, qa.bias = w.rbias, qa.state = state, qa.yout = Y;
+    if (e->slstm_rinv[i].p != nullptr)
+      qa.rt2h = reinterpret_cast<const uint16_t*>(e->slstm_rt2[i].p), qa.rinv = e->slstm_rinv[i].p;
+    else
+      qa.rt2 = e->slstm_rt2[i].p;
     qa.B = sl.nb, qa.T = T, qa.H = Hs, qa.NH = NH, qa.state_B = e->B;
     launch_slstm_seq(qa, s);
   }
@@ -1644,7 +1659,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_MAMBA_DT_FUSE")) e->mamba_dt_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
-    if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0, e->slstm_seq_f32 = std::atoi(v) == 2;
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_ROWS")) e->gemm_skinny_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_MIN")) e->gemm_skinny_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_FRONT_MULTI")) e->front_multi = std::atoi(v) != 0;

@@ -64,7 +64,8 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p
   constexpr int NPIECE = NPA + 2 * (BN / 16), PPW = NPIECE / NW;  // ... of a stage, per wave
   static_assert(NPA % NW == 0 && NPIECE % NW == 0, "a wave's DMA pieces of one round belong to one operand");
   static_assert(NSTAGE != 1 || BMT + BN <= 64 * NW, "scale staging: one thread per row / column of the tile");
-  __shared__ __attribute__((aligned(1024))) _Float16 lds[NSTAGE * STG];
+  constexpr int SCL = NSTAGE == 1 ? 0 : 2 * ((BMT + BN + 63) / 64 * 64);  // (two-stage form: the scale table, f16 units)
+  __shared__ __attribute__((aligned(1024))) _Float16 lds[NSTAGE * STG + SCL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
 
@@ -140,15 +141,25 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p
 
   const int li = lane & 31, lh = lane >> 5;
   const int sw = (li >> 2) & 3;  // chunk swizzle of this lane's rows (tile row offsets are multiples of 32)
-  float ainv_r[NSTAGE == 1 ? 1 : TI][NSTAGE == 1 ? 1 : 16], winv_r[2];
+  // Two-stage instances: the tile's BMT + BN inverse scales go into LDS by DMA too (4 bytes per lane, behind the tile stages
+  // of the same array; the first barrier of the K loop publishes them), read by the epilogue.  Round 5: they used to sit in
+  // 32 + 2 registers through the K loop (181 VGPRs) -- one register too many for a workgroup to start beside two read-pass
+  // workgroups of the 206M geometry (2 x 177), so the projection of one env slice WAITED for the other slice's read pass to
+  // retire workgroups instead of running under it.
+  const float* sclf = reinterpret_cast<const float*>(lds + NSTAGE * STG);
   if (NSTAGE != 1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rsrc_ai = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a2_inv), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_wi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w_inv), 0, 0xffffffffu, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        ainv_r[i][r] = g.a2_inv[min(m0 + 32 * TI * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh, g.m - 1)];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) winv_r[j] = g.w_inv[min(n0 + 64 * wn + 32 * j + li, g.n - 1)];
+    for (int c = wave; c < (BMT + BN + 63) / 64; c += NW) {  // chunk c: table entries 64 c .. 64 c + 63 (BMT is a multiple of 64)
+      const bool is_a = 64 * c < BMT;
+      const int e = 64 * c + lane - (is_a ? 0 : BMT);
+      const unsigned off = 4u * (unsigned)(is_a ? min(m0 + e, g.m - 1) : min(n0 + e, g.n - 1));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? rsrc_ai : rsrc_wi,
+                                               (__attribute__((address_space(3))) void*)(lds + NSTAGE * STG + 128 * c), 4, off, 0, 0, 0);
+    }
+#endif
   }
   const _Float16* a_base = lds + (32 * TI * wm + li) * BK;
   const _Float16* b_base = lds + 2 * APL + (64 * wn + li) * BK;
@@ -214,13 +225,13 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + 32 * TI * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      ainv[r] = NSTAGE == 1 ? scl[row - m0] : ainv_r[NSTAGE == 1 ? 0 : i][NSTAGE == 1 ? 0 : r];
+      ainv[r] = NSTAGE == 1 ? scl[row - m0] : sclf[row - m0];
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + 64 * wn + 32 * j + li;
       if (col >= g.n) continue;
-      const float wi = NSTAGE == 1 ? scl[BMT + col - n0] : winv_r[j];
+      const float wi = NSTAGE == 1 ? scl[BMT + col - n0] : sclf[BMT + col - n0];
       const float bv = HAS_BIAS ? g.bias[col] : 0.f;
       // (per (i, j) one base pointer; the 16 rows of the accumulator tile are compile-time multiples of the row pitch from it --
       // the per-element 64-bit row * pitch products, bounds checks and libm SiLU of the first form were ~60 instructions per

@@ -397,6 +397,11 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   constexpr int kRowsPerWave = (WP + T + 3) / 4;
   constexpr int CW = 4 * LPR;
   constexpr int RP = 256 / LPR;
+  // WV (scores from the score kernel, i.e. known before the pass): the window's v rows as one float4 per lane and row too -- row
+  // group rg keeps rows rg, rg + RP, ... at its own four columns, multiplies the scores on after the pass and adds the sums to its
+  // partial of the pass, as W4 does (the per-column form: WP four-byte requests per lane, half the workgroup idle)
+  constexpr bool WV = KPL < 0;
+  constexpr int kVRows = (WP + RP - 1) / RP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int DH = a.DH;
   float* qs = smem;                 // [T][DH]
@@ -485,10 +490,20 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   }
   // window V column of this thread (threads >= CW idle here): in flight during the pass over C_base
   const float* wvb = a.wv + (base * DH) + slice * CW + (tid < CW ? tid : 0);
-  float vw[W4 ? 1 : WP];
-  if (!W4) {
+  float vw[W4 || WV ? 1 : WP];
+  if (!W4 && !WV) {
 #pragma unroll
-    for (int j = 0; j < WP; ++j) vw[W4 ? 0 : j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
+    for (int j = 0; j < WP; ++j) vw[W4 || WV ? 0 : j] = (tid < CW && j < n) ? wvb[(int64_t)j * DH] : 0.f;
+  }
+  v4f v4r[WV ? kVRows : 1];
+  (void)v4r;
+  if (WV) {
+    const float* wvs = a.wv + base * DH + slice * CW + 4 * cl;
+#pragma unroll
+    for (int i = 0; i < kVRows; ++i) {
+      const int j = rg + RP * i;
+      v4r[WV ? i : 0] = (j < n && j < WP) ? *reinterpret_cast<const v4f*>(wvs + (int64_t)j * DH) : (v4f)(0.f);
+    }
   }
   // window khat rows of this wave (rows wave, wave + 4, ...), KPL values per lane and row
   const float* wkb = a.wk + base * DH;
@@ -538,9 +553,9 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
     }
     return c;
   };
-  v4f accw[W4 ? T : 1];  // W4: this wave's rows of sum_j p[t][j] v_j, columns 4 lane .. 4 lane + 3
+  v4f accw[W4 || WV ? T : 1];  // W4 / WV: this wave's (row group's) rows of sum_j p[t][j] v_j at its four columns
 #pragma unroll
-  for (int t = 0; t < (W4 ? T : 1); ++t) accw[t] = (v4f)(0.f);
+  for (int t = 0; t < (W4 || WV ? T : 1); ++t) accw[t] = (v4f)(0.f);
   auto window_scores = [&]() {
   if (KPL < 0) {
   } else if (W4) {
@@ -631,9 +646,19 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       }
     }
   }
+  if (WV) {  // (pw: the score kernel's rows, in LDS since the barrier above; zero v rows beyond the pending window)
+#pragma unroll
+    for (int i = 0; i < kVRows; ++i) {
+      const int j = rg + RP * i;
+      if (j < WP) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) accw[W4 || WV ? t : 0] += pw[t * WT + j] * v4r[WV ? i : 0];
+      }
+    }
+  }
 #pragma unroll
   for (int t = 0; t < T; ++t)
-    *reinterpret_cast<v4f*>(red + ((rg * T + t) * CW) + 4 * cl) = W4 ? G[t] * acc[t] + accw[W4 ? t : 0] : acc[t];
+    *reinterpret_cast<v4f*>(red + ((rg * T + t) * CW) + 4 * cl) = (W4 || WV) ? G[t] * acc[t] + accw[W4 || WV ? t : 0] : acc[t];
 
   if (!SF) window_scores();
   __syncthreads();
@@ -649,13 +674,13 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       float y = 0.f;
 #pragma unroll
       for (int g = 0; g < RP; ++g) y += red[(g * T + t) * CW + c];
-      hn[t] = W4 ? y : G[t] * y;  // (W4: the row groups' sums hold G y + the window rows' part already)
+      hn[t] = (W4 || WV) ? y : G[t] * y;  // (W4 / WV: the row groups' sums hold G y + the window rows' part already)
     }
-    if (!W4) {
+    if (!W4 && !WV) {
 #pragma unroll
       for (int j = 0; j < WP; ++j) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) hn[t] += pw[t * WT + j] * vw[W4 ? 0 : j];  // vw == 0 beyond the window, pw zero-filled
+        for (int t = 0; t < T; ++t) hn[t] += pw[t * WT + j] * vw[W4 || WV ? 0 : j];  // vw == 0 beyond the window, pw zero-filled
       }
     }
     if (WP < W) {
@@ -779,6 +804,9 @@ void launch_cell_t(const MlstmLazyArgs& a, hipStream_t s) {
   // flight (174 VGPRs; 206M at 512 env slots 27.7k env-steps/s; 48-row prefetch 27.5k; 8 rows in flight -- 113 VGPRs, the pass
   // itself 0.41 -> 0.31 ms -- 27.1k: the projections of that model are the longer side of the pipeline and lose what the pass gains)
   LRAM_REQUIRE(a.pw != nullptr, "lazy mLSTM: missing score buffer");
+  // (round 5, 206M at 512 slots: the window's v rows as float4 per lane and row -- WV in the kernel, 177 -> 162 VGPRs, the pass
+  // 0.36 -> 0.32 ms -- 32.1k -> 32.4k env-steps/s; 8 / 12 rows in flight: 29.2-31.7k / 30.8k, with an LDS cap of three workgroups per
+  // CU 32.3-32.6k / 31.5k: profiles/r05_ab_206m_chain.txt)
   if (a.DH % 256 == 0) return launch_cell_tluk<T, 64, 16, -1, 36>(a, s);
   launch_cell_tluk<T, 32, 16, -1, 36>(a, s);
 }

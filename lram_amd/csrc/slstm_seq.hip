@@ -162,6 +162,193 @@ __global__ __launch_bounds__(2 * kSDH, kSDH <= 256 ? 2 : 3) void slstm_seq_kerne
     }
   }
 }
+
+// =============================================================================================
+// f16x2 form (round 5): R_g h as hi * hi + hi * lo + lo * hi on v_mfma_f32_16x16x32_f16, like the projection GEMMs.
+//
+// The fp32 form above spends 64 cycles per 32 x 32 x 2 product round -- 128 us of matrix-pipe time per workgroup at the 206M
+// model's 320-wide heads -- and, with 32 envs per workgroup, runs a 256-env slice on 32 of the 256 CUs: 480 us per launch on
+// each slice's chain, three times per step, while the state-pass queue has only folds to run.  Here:
+//   * one workgroup = 16 envs x one head (twice the workgroups), wave w owns channels 32 w .. 32 w + 31 as 2 column tiles x 4 gates
+//     of 16 x 16 accumulators (32 registers); a lane's 8 (env, channel) cells keep all four gates lane-local as before;
+//   * h_t lives in LDS as two f16 planes of 2^12 h (|h| < 1: the scale is fixed, no row maxima), R is split at upload into two
+//     f16 planes per (gate, channel) row scaled by its power of two, laid out so that a wave's B operands are ONE contiguous
+//     stream ([head][wave][k step][column tile][gate][plane][lane][8]): 12 MFMAs of 16 cycles per 8 KB -- the kernel is bound by
+//     streaming R from L2 (the same bytes as fp32), not by the matrix pipe.
+// Differences from the fp32 form are those of the f16x2 GEMMs (22-bit operands, lo * lo dropped); LRAM_GEMM=f32 keeps the fp32 form.
+// =============================================================================================
+typedef float sq_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 sq_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sq_f16x4 __attribute__((ext_vector_type(4)));
+constexpr int kEnv16 = 16;
+constexpr float kHScale = 4096.f;
+
+// rt: [NH, 4, out, in] fp32 -> rt2h planes (layout above), rinv[(head * 4 + g) * SDH + ch] = 1 / (row scale * kHScale)
+__global__ __launch_bounds__(256) void slstm_pack_rt16_kernel(const float* rt, _Float16* rt2h, float* rinv, int NH, int SDH) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // row = (head * 4 + g) * SDH + ch
+  if (row >= NH * 4 * SDH) return;
+  const int ch = row % SDH, g = (row / SDH) & 3, head = row / (4 * SDH);
+  const float* r = rt + (int64_t)row * SDH;
+  float mx = 0.f;
+  for (int k = lane; k < SDH; k += 64) mx = fmaxf(mx, fabsf(r[k]));
+  const float sc = pow2_scale(wave_max(mx));
+  const int NW = SDH / 32, KS = SDH / 32;
+  const int w = ch >> 5, ct = (ch >> 4) & 1, c = ch & 15;
+  for (int k = lane; k < SDH; k += 64) {
+    const float v = r[k] * sc;
+    const _Float16 hi = (_Float16)v;
+    const int ks = k >> 5, kg = (k >> 3) & 3, j = k & 7;
+    const int64_t at = ((((((int64_t)head * NW + w) * KS + ks) * 2 + ct) * 4 + g) * 2) * 512 + (kg * 16 + c) * 8 + j;
+    rt2h[at] = hi;
+    rt2h[at + 512] = (_Float16)(v - (float)hi);
+  }
+  if (lane == 0) rinv[row] = 1.f / (sc * kHScale);
+}
+
+template <int T, int kSDH, bool GE>
+__global__ __launch_bounds__(2 * kSDH, kSDH <= 128 ? 2 : 1) void slstm_seq16_kernel(SlstmSeqArgs a) {
+  constexpr int KS = kSDH / 32, NU = 2 * KS, kPitch = kSDH + 8;   // K steps of 32, B units (k step, column tile), LDS row pitch (f16)
+  __shared__ __attribute__((aligned(16))) _Float16 hs[2][2][kEnv16][kPitch];   // [buffer][plane][env][k]
+  const int H = a.H;
+  const int head = blockIdx.x % a.NH, b0 = (blockIdx.x / a.NH) * kEnv16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lc = lane & 15, lg = lane >> 4;
+  const int64_t BH = (int64_t)a.state_B * H;
+
+  // ---- h_{-1} of the workgroup's envs and head -> the two LDS planes ----
+  for (int idx = tid; idx < kEnv16 * (kSDH / 4); idx += 2 * kSDH) {
+    const int e = idx / (kSDH / 4), c4 = 4 * (idx % (kSDH / 4));
+    const int b = min(b0 + e, a.B - 1);
+    const float4 v = *reinterpret_cast<const float4*>(a.state + (int64_t)b * H + head * kSDH + c4);
+    const float xs[4] = {v.x * kHScale, v.y * kHScale, v.z * kHScale, v.w * kHScale};
+    sq_f16x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hi[q] = (_Float16)xs[q];
+      lo[q] = (_Float16)(xs[q] - (float)hi[q]);
+    }
+    *reinterpret_cast<sq_f16x4*>(&hs[0][0][e][c4]) = hi;
+    *reinterpret_cast<sq_f16x4*>(&hs[0][1][e][c4]) = lo;
+  }
+  // ---- this lane's cells: column tile ct, accumulator row r -> env 4 lg + r, channel 32 w + 16 ct + lc of the head ----
+  auto env_of = [&](int r) { return min(b0 + 4 * lg + r, a.B - 1); };   // (clamped: rows beyond B are dropped at the stores)
+  const int chl = 32 * w + lc;             // channel within the head of column tile 0 (+ 16 for tile 1)
+  const int ch0 = head * kSDH + chl;       // ... within H
+  float cs[2][4], ns[2][4], ms[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* st = a.state + (int64_t)env_of(r) * H + ch0 + 16 * ct;
+      cs[ct][r] = st[BH], ns[ct][r] = st[2 * BH], ms[ct][r] = st[3 * BH];
+    }
+  float bias[2][4], ri[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bias[ct][g] = a.bias[g * H + ch0 + 16 * ct];
+      ri[ct][g] = a.rinv[(head * 4 + g) * kSDH + chl + 16 * ct];
+    }
+  const _Float16* bp = reinterpret_cast<const _Float16*>(a.rt2h) + ((int64_t)(head * (kSDH / 32) + w) * KS) * (16 * 512) + lane * 8;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    sq_f32x4 acc[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[ct][g] = (sq_f32x4)(0.f);
+    // the token's input pre-activations (Wx): requested before the K loop where the register budget allows (GE), so that their
+    // round trip hides behind it
+    const unsigned grow = 4u * (unsigned)H;
+    float gin[GE ? 2 : 1][GE ? 4 : 1][GE ? 4 : 1];
+    (void)gin;
+    if (GE) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned off = ((unsigned)env_of(r) * (unsigned)T + (unsigned)t) * grow + (unsigned)(ch0 + 16 * ct);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gin[GE ? ct : 0][GE ? r : 0][GE ? g : 0] = a.gates[off + g * H];
+        }
+    }
+    // B units (k step, column tile): 8 x 1 KB (gate x plane) each, two register sets, one unit ahead
+    sq_f16x8 bq0[8], bq1[8];
+    auto load_b = [&](sq_f16x8* dst, int u) {
+      const _Float16* q = bp + (unsigned)(u * 8 * 512);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const sq_f16x8*>(q + i * 512);
+    };
+    auto products = [&](const sq_f16x8* bq, int ct, const sq_f16x8& ah, const sq_f16x8& al) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {   // smallest terms first
+        acc[ct][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bq[2 * g], acc[ct][g], 0, 0, 0);      // lo * hi
+        acc[ct][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[2 * g + 1], acc[ct][g], 0, 0, 0);  // hi * lo
+        acc[ct][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bq[2 * g], acc[ct][g], 0, 0, 0);      // hi * hi
+      }
+    };
+    load_b(bq0, 0);
+#pragma unroll 1
+    for (int ks = 0; ks < KS; ++ks) {
+      load_b(bq1, 2 * ks + 1);
+      const sq_f16x8 ah = *reinterpret_cast<const sq_f16x8*>(&hs[cur][0][lc][32 * ks + 8 * lg]);
+      const sq_f16x8 al = *reinterpret_cast<const sq_f16x8*>(&hs[cur][1][lc][32 * ks + 8 * lg]);
+      products(bq0, 0, ah, al);
+      load_b(bq0, min(2 * ks + 2, NU - 2));   // (unconditional: past the end it re-requests a unit and drops it)
+      products(bq1, 1, ah, al);
+    }
+    // pointwise cell ([3P] slstm_pointwise), lane-local
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      if (!GE) __builtin_amdgcn_sched_barrier(0);
+      float gl[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned off = ((unsigned)env_of(r) * (unsigned)T + (unsigned)t) * grow + (unsigned)(ch0 + 16 * ct);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gl[r][g] = GE ? gin[GE ? ct : 0][GE ? r : 0][GE ? g : 0] : a.gates[off + g * H];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = 4 * lg + r;
+        const float iraw = gl[r][0] + acc[ct][0][r] * ri[ct][0] + bias[ct][0], fraw = gl[r][1] + acc[ct][1][r] * ri[ct][1] + bias[ct][1];
+        const float zraw = gl[r][2] + acc[ct][2][r] * ri[ct][2] + bias[ct][2], oraw = gl[r][3] + acc[ct][3][r] * ri[ct][3] + bias[ct][3];
+        const float logfplusm = ms[ct][r] + log_sigmoid(fraw);
+        const float mnew = (ns[ct][r] == 0.f) ? iraw : fmaxf(iraw, logfplusm);
+        const float ogate = sigmoid_f(oraw);
+        const float igate = fminf(expf(iraw - mnew), 1.f);
+        const float fgate = fminf(expf(logfplusm - mnew), 1.f);
+        const float cnew = fgate * cs[ct][r] + igate * tanhf(zraw);
+        const float nnew = fgate * ns[ct][r] + igate;
+        const float ynew = ogate * cnew / nnew;
+        cs[ct][r] = cnew, ns[ct][r] = nnew, ms[ct][r] = mnew;
+        const float ysc = ynew * kHScale;
+        const _Float16 yh = (_Float16)ysc;
+        hs[cur ^ 1][0][e][chl + 16 * ct] = yh;
+        hs[cur ^ 1][1][e][chl + 16 * ct] = (_Float16)(ysc - (float)yh);
+        if (b0 + e < a.B) {
+          const unsigned ycol = (unsigned)(ch0 + 16 * ct);
+          a.yout[((unsigned)(b0 + e) * (unsigned)T + (unsigned)t) * (unsigned)H + ycol] = ynew;
+          if (t == T - 1) a.state[(unsigned)(b0 + e) * (unsigned)H + ycol] = ynew;   // the state's h plane: the step's last h
+        }
+      }
+    }
+    __syncthreads();  // h_t complete in hs[cur ^ 1]; every wave is done reading hs[cur]
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = 4 * lg + r;
+      if (b0 + e < a.B) {
+        float* st = a.state + (int64_t)(b0 + e) * H + ch0 + 16 * ct;
+        st[BH] = cs[ct][r], st[2 * BH] = ns[ct][r], st[3 * BH] = ms[ct][r];
+      }
+    }
+}
 }  // namespace
 
 bool slstm_seq_supported(int H, int NH, int T) {
@@ -176,8 +363,25 @@ void launch_slstm_pack_rt(const float* rt, float* rt2, int NH, int SDH, hipStrea
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
+void launch_slstm_pack_rt16(const float* rt, uint16_t* rt2h, float* rinv, int NH, int SDH, hipStream_t stream) {
+  hipLaunchKernelGGL(slstm_pack_rt16_kernel, dim3((unsigned)((NH * 4 * SDH + 3) / 4)), dim3(256), 0, stream, rt,
+                     reinterpret_cast<_Float16*>(rt2h), rinv, NH, SDH);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
 template <int SDH>
 static void launch_seq_sdh(const SlstmSeqArgs& a, hipStream_t stream) {
+  if (a.rt2h != nullptr) {   // f16x2 form: 16 envs per workgroup; the gate rows requested early where 8 waves or fewer share the registers
+    constexpr bool GE = SDH <= 256;
+    const dim3 grid((unsigned)(a.NH * ((a.B + kEnv16 - 1) / kEnv16))), block(2 * SDH);
+    switch (a.T) {
+      case 1: hipLaunchKernelGGL((slstm_seq16_kernel<1, SDH, GE>), grid, block, 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((slstm_seq16_kernel<2, SDH, GE>), grid, block, 0, stream, a); break;
+      case 3: hipLaunchKernelGGL((slstm_seq16_kernel<3, SDH, GE>), grid, block, 0, stream, a); break;
+      default: hipLaunchKernelGGL((slstm_seq16_kernel<4, SDH, GE>), grid, block, 0, stream, a); break;
+    }
+    return;
+  }
   const dim3 grid((unsigned)(a.NH * ((a.B + kEnv - 1) / kEnv))), block(2 * SDH);
   switch (a.T) {
     case 1: hipLaunchKernelGGL((slstm_seq_kernel<1, SDH>), grid, block, 0, stream, a); break;
@@ -188,7 +392,8 @@ static void launch_seq_sdh(const SlstmSeqArgs& a, hipStream_t stream) {
 }
 
 void launch_slstm_seq(const SlstmSeqArgs& a, hipStream_t stream) {
-  LRAM_REQUIRE(slstm_seq_supported(a.H, a.NH, a.T) && a.rt2 != nullptr, "sLSTM step kernel: head dim 128 / 192 / 256 / 320 / 384, 1..4 tokens");
+  LRAM_REQUIRE(slstm_seq_supported(a.H, a.NH, a.T) && (a.rt2 != nullptr || (a.rt2h != nullptr && a.rinv != nullptr)),
+               "sLSTM step kernel: head dim 128 / 192 / 256 / 320 / 384, 1..4 tokens");
   // (the kernel's row offsets into gates / yout / state are 32-bit: slices beyond ~700k envs at H = 512 would wrap)
   LRAM_REQUIRE((int64_t)a.B * a.T * 4 * a.H < (1ll << 32) && (int64_t)a.state_B * a.H < (1ll << 30),
                "sLSTM step kernel: slice too large for its 32-bit row offsets");
