@@ -235,36 +235,29 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
     F[t] = Fc;
   }
   const float sqrt_dh = sqrtf((float)DH);
-  {
-    constexpr int kIt = 3;
-    float qv[kIt][T], kv[kIt][T];
+  {  // q / k of the step's tokens -> LDS: one float4 of four channels per thread (head dims up to 1024 without a loop)
+    const int r4 = min(4 * tid, DH - 4);
+    float4 qv[T], kv[T];
 #pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-      const int r = min(tid + 256 * it, DH - 1);
+    for (int t = 0; t < T; ++t) {
+      const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r4;
+      qv[t] = *reinterpret_cast<const float4*>(a.q + off);
+      kv[t] = *reinterpret_cast<const float4*>(a.k + off);
+    }
+    if (4 * tid < DH) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        *reinterpret_cast<float4*>(qs + t * DH + r4) = qv[t];
+        *reinterpret_cast<float4*>(ks + t * DH + r4) = make_float4(kv[t].x / sqrt_dh, kv[t].y / sqrt_dh, kv[t].z / sqrt_dh, kv[t].w / sqrt_dh);
+      }
+    }
+    for (int r = 4 * (tid + 256); r < DH; r += 1024) {   // (head dims beyond 1024)
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r;
-        qv[it][t] = a.q[off];
-        kv[it][t] = a.k[off];
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < kIt; ++it) {
-      const int r = tid + 256 * it;
-      if (r < DH) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          qs[t * DH + r] = qv[it][t];
-          ks[t * DH + r] = kv[it][t] / sqrt_dh;
-        }
-      }
-    }
-    for (int r = tid + 256 * kIt; r < DH; r += 256) {
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int64_t off = ((int64_t)b * T + t) * inner + (int64_t)h * DH + r;
-        qs[t * DH + r] = a.q[off];
-        ks[t * DH + r] = a.k[off] / sqrt_dh;
+        const float4 q4 = *reinterpret_cast<const float4*>(a.q + off), k4 = *reinterpret_cast<const float4*>(a.k + off);
+        *reinterpret_cast<float4*>(qs + t * DH + r) = q4;
+        *reinterpret_cast<float4*>(ks + t * DH + r) = make_float4(k4.x / sqrt_dh, k4.y / sqrt_dh, k4.z / sqrt_dh, k4.w / sqrt_dh);
       }
     }
   }
@@ -299,39 +292,47 @@ __global__ __launch_bounds__(256) void mlstm_lazy_score_kernel(MlstmLazyArgs a) 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int t = 0; t < T; ++t) p[i][t] = 0.f;
-    // all of the four rows' window values of this lane (head dims <= 768: 12 per row) are requested before the first fma
-    // (per 64 channels the loop compiled to load -> wait -> fma: DH / 64 dependent round trips per row group)
-    constexpr int kSIt = 12;
-    float kv[4][kSIt];
+    // all of the four rows' window values of this lane -- one float4 of four channels per 256 channels (head dims <= 768: three
+    // per row; round 5: they were twelve four-byte requests per row, and a wave's request costs the memory pipeline the same
+    // whether its lanes ask for 4 or 16 bytes) -- are requested before the first fma
+    constexpr int kSIt = 3;
+    float4 kv[4][kSIt];
 #pragma unroll
     for (int it = 0; it < kSIt; ++it) {
-      const int r = lane + 64 * it;
+      const int r = 4 * (lane + 64 * it);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = j0 + i;
-        kv[i][it] = (r < DH && j < n) ? wkb[(int64_t)j * DH + r] : 0.f;
+        kv[i][it] = (r < DH && j < n) ? *reinterpret_cast<const float4*>(wkb + (int64_t)j * DH + r) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
     for (int it = 0; it < kSIt; ++it) {
-      const int r = lane + 64 * it;
+      const int r = 4 * (lane + 64 * it);
       if (r < DH) {
+        float4 q4[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) q4[t] = *reinterpret_cast<const float4*>(qs + t * DH + r);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int j = j0 + i;
-          const float kx = j < n ? kv[i][it] : (j < n + T ? ks[(j - n) * DH + r] : 0.f);
+          const float4 kx = j < n ? kv[i][it] : (j < n + T ? *reinterpret_cast<const float4*>(ks + (j - n) * DH + r) : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
-          for (int t = 0; t < T; ++t) p[i][t] += qs[t * DH + r] * kx;
+          for (int t = 0; t < T; ++t) p[i][t] += q4[t].x * kx.x + q4[t].y * kx.y + q4[t].z * kx.z + q4[t].w * kx.w;
         }
       }
     }
-    for (int r = lane + 64 * kSIt; r < DH; r += 64) {  // (head dims beyond 768)
+    for (int r = 4 * (lane + 64 * kSIt); r < DH; r += 256) {  // (head dims beyond 768)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = j0 + i;
-        const float kx = j < n ? wkb[(int64_t)j * DH + r] : (j < n + T ? ks[(j - n) * DH + r] : 0.f);
+        const float4 kx = j < n ? *reinterpret_cast<const float4*>(wkb + (int64_t)j * DH + r)
+                                : (j < n + T ? *reinterpret_cast<const float4*>(ks + (j - n) * DH + r) : make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
-        for (int t = 0; t < T; ++t) p[i][t] += qs[t * DH + r] * kx;
+        for (int t = 0; t < T; ++t) {
+          const float4 q4 = *reinterpret_cast<const float4*>(qs + t * DH + r);
+          p[i][t] += q4.x * kx.x + q4.y * kx.y + q4.z * kx.z + q4.w * kx.w;
+        }
       }
     }
 #pragma unroll
