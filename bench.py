@@ -132,7 +132,7 @@ def cpu_baseline(spec, sd, seconds_budget=22.0):
     # PyTorch-eager on many small ops does not scale to every core of a big host: calibrate the thread count on one
     # timestep each (smallest first, stop when it gets slower), then time with the best.
     best_thr, best_t = None, None
-    for thr in sorted({min(avail, c) for c in (8, 32, 128)}):
+    for thr in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
         n, w = timed_steps(64, thr, 60.0, 2)    # two timesteps after one warm-up: one alone flipped between 8 and 32 threads
         w /= max(n, 1)                          # from box to box (round 3)
         if best_t is None or w < best_t:
@@ -145,7 +145,7 @@ def cpu_baseline(spec, sd, seconds_budget=22.0):
     return {"value": B * n / wall, "unit": "env-steps/s", "cores": best_thr, "kind": "port",
             "sample": f"CPU oracle (PyTorch-eager fp32 restatement of the same path), same model and weights, "
                       f"B={B} envs x {n} timesteps after 1 warm-up, {wall:.1f} s wall, {best_thr} torch threads "
-                      f"(fastest of a 8/32/128 calibration at B=64; host exposes {avail} cores); SURVEY 8d's 8+32 steps "
+                      f"(fastest of a 8/16/32/64/128 calibration at B=64; host exposes {avail} cores); SURVEY 8d's 8+32 steps "
                       f"at the config batch would take ~{(8 + 32) * 4096 / max(B * n / wall, 1e-9) / 60:.0f} min, hence "
                       f"the bounded sample",
             "b1_latency_ms": wall1 / n1 * 1e3,

@@ -32,3 +32,8 @@ cp profiles/${RND}_* $OUT/profiles_out/
 { PREFILL_MODES=chunkwise python scripts/bench_prefill.py xlstm_206m 64 512 | tail -1; PREFILL_MODES=chunkwise python scripts/bench_prefill.py xlstm_16m 1024 63 | tail -1; } > profiles/${RND}_prefill_chunkwise_bench.txt 2>/dev/null; cat profiles/${RND}_prefill_chunkwise_bench.txt
 python scripts/read_ceiling.py >> profiles/${RND}_prefill_chunkwise_bench.txt 2>/dev/null
 cp profiles/${RND}_* $OUT/profiles_out/
+bash scripts/gpu_timeline.sh x206m --config xlstm_206m --batch 512 > /dev/null 2>&1
+cp $OUT/timeline_x206m.txt profiles/${RND}_step_timeline_xlstm206m_b512.txt; cp $OUT/kernel_stats_x206m.csv profiles/${RND}_kernel_stats_xlstm206m_b512.csv
+head -12 profiles/${RND}_step_timeline_xlstm206m_b512.txt | cut -c1-160
+cp $OUT/pytest_gpu.log profiles/${RND}_gpu_suite_final.txt 2>/dev/null
+cp profiles/${RND}_* $OUT/profiles_out/
