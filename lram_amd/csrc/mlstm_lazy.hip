@@ -629,6 +629,13 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   const float* Cb = a.C + (((int64_t)b * NH + h) * DH) * DH + col0;
   const bool stream = !lv.zero;  // (after a restart C_base holds nothing until the env's next fold)
   if (SF) window_scores();
+#ifdef LRAM_LAZY_REGPAD
+  float rpad[LRAM_LAZY_REGPAD];
+  if (WV) {
+#pragma unroll
+    for (int i = 0; i < LRAM_LAZY_REGPAD; ++i) asm volatile("v_mov_b32 %0, 0" : "=v"(rpad[i]));
+  }
+#endif
   if (stream) {
     for (int r0 = rg; r0 < DH; r0 += RP * UNR) {
       v4f c[UNR];
@@ -647,6 +654,12 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       }
     }
   }
+#ifdef LRAM_LAZY_REGPAD
+  if (WV) {
+#pragma unroll
+    for (int i = 0; i < LRAM_LAZY_REGPAD; ++i) asm volatile("" ::"v"(rpad[i]));
+  }
+#endif
   if (WV) {  // (pw: the score kernel's rows, in LDS since the barrier above; zero v rows beyond the pending window)
 #pragma unroll
     for (int i = 0; i < kVRows; ++i) {
