@@ -629,13 +629,17 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
   const float* Cb = a.C + (((int64_t)b * NH + h) * DH) * DH + col0;
   const bool stream = !lv.zero;  // (after a restart C_base holds nothing until the env's next fold)
   if (SF) window_scores();
-#ifdef LRAM_LAZY_REGPAD
-  float rpad[LRAM_LAZY_REGPAD];
-  if (WV) {
+  // Occupancy cap by REGISTERS for the sliced-head instances (WV): twelve registers held across the pass put the kernel at 174
+  // VGPRs, i.e. two workgroups per CU instead of three, which leaves 164 registers and ~100 KB of LDS per SIMD lane / CU free: the
+  // other slice's projection workgroups (118 / 155 VGPRs, 48-65 KB) then START beside the read pass instead of waiting for one
+  // of its workgroups to retire.  The pass itself gets slower (0.32 -> 0.345 ms at 206M / 256-env slices), the step faster:
+  // 33,008 / 33,220 -> 33,553 / 33,377 env-steps/s (+1 %; profiles/r05_ab_206m_chain.txt).  An LDS cap cannot do this here --
+  // it takes the LDS those workgroups need -- and more rows in flight instead of idle registers (20 / 24: 186 / 211 VGPRs) lose.
+  constexpr int kRegPad = WV ? 12 : 0;
+  float rpad[kRegPad > 0 ? kRegPad : 1];
+  (void)rpad;
 #pragma unroll
-    for (int i = 0; i < LRAM_LAZY_REGPAD; ++i) asm volatile("v_mov_b32 %0, 0" : "=v"(rpad[i]));
-  }
-#endif
+  for (int i = 0; i < kRegPad; ++i) asm volatile("v_mov_b32 %0, 0" : "=v"(rpad[i]));
   if (stream) {
     for (int r0 = rg; r0 < DH; r0 += RP * UNR) {
       v4f c[UNR];
@@ -654,12 +658,8 @@ __global__ __launch_bounds__(256) void mlstm_lazy_cell_kernel(MlstmLazyArgs a) {
       }
     }
   }
-#ifdef LRAM_LAZY_REGPAD
-  if (WV) {
 #pragma unroll
-    for (int i = 0; i < LRAM_LAZY_REGPAD; ++i) asm volatile("" ::"v"(rpad[i]));
-  }
-#endif
+  for (int i = 0; i < kRegPad; ++i) asm volatile("" ::"v"(rpad[i]));   // (the pad registers' live range ends here)
   if (WV) {  // (pw: the score kernel's rows, in LDS since the barrier above; zero v rows beyond the pending window)
 #pragma unroll
     for (int i = 0; i < kVRows; ++i) {
