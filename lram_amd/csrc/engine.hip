@@ -109,6 +109,7 @@ struct lram_engine {
   std::vector<DevBuf> slstm_rt2;  // sLSTM: recurrent weights re-packed per block for slstm_seq.hip: fp32 [head][k][channel][gate], or
                                   // (f16x2 projections, the default) two f16 planes in the same bytes + slstm_rinv, the inverse row scales
   std::vector<DevBuf> slstm_rinv;
+  int lazy_cap2_envs = 896;       // LRAM_LAZY_CAP2_ENVS: largest slice whose read pass runs two workgroups per CU (0 = never)
   bool slstm_seq_f32 = false;     // LRAM_SLSTM_SEQ=2: its exact-fp32 form even where the projections run as f16x2
   bool slstm_seq = true;          // LRAM_SLSTM_SEQ=0: per-token recurrent GEMM + pointwise launches for slices beyond the token kernel's
   std::vector<DevBuf> gate_coef;  // mLSTM: folded i / f gate coefficients per block (mlstm_front.hip), geometries it covers
@@ -1284,9 +1285,12 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
         const size_t r0 = (size_t)x.b0 * T;
         la.q = e->Q.p + r0 * e->icols, la.k = e->K.p + r0 * e->icols, la.v = e->V.p + r0 * e->icols;
         la.scal = e->SCAL.p + r0 * c.n_heads * 4, la.h = e->H.p + r0 * e->icols;
-        // the read-only pass runs best with two workgroups per CU (one's prologue / epilogue under the other's
-        // stream; 362k vs 308k env-steps/s at B = 4096 against the single-workgroup cap the read-modify-write kernel likes)
-        la.min_lds_bytes = 0;
+        // the read-only pass's occupancy cap (LDS per workgroup; 0 = the launcher's default of three workgroups per CU, 41 KB,
+        // at 256-wide heads).  Slices below ~900 envs are CHAIN-bound -- the slice's projections / front end take longer than the
+        // other slice's read pass -- and two read-pass workgroups per CU (54 KB) leave room for the two-stage projection
+        // workgroups (155 VGPRs, 48 KB) to start beside them: 16M at 640 / 768 / 896 / 1024 / 1152 / 1280 / 1408 slots +1.5 / +2.6 /
+        // +4.0 / +2.5 / +4.6 / +3.8 / +1.1 %, 1536-1792 +0.3-1 %, 2048 -1.3 %, 4096 -1.3 % (profiles/r05_ab_read_pass_lds_cap.txt)
+        la.min_lds_bytes = (sl.size() >= 2 && x.nb <= e->lazy_cap2_envs && la.DH == 256) ? 54 * 1024 : 0;
         if (!mlstm_lazy_fused_scores(la.DH)) launch_mlstm_lazy_book(la, x.s);  // scores beside the front end
         if (lean_front(e, T)) {
           const BlockWeights& w = e->bw[i];
@@ -1660,6 +1664,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0, e->slstm_seq_f32 = std::atoi(v) == 2;
+    if (const char* v = std::getenv("LRAM_LAZY_CAP2_ENVS")) e->lazy_cap2_envs = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_ROWS")) e->gemm_skinny_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_GEMM_SKINNY_MIN")) e->gemm_skinny_min = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("LRAM_FRONT_MULTI")) e->front_multi = std::atoi(v) != 0;

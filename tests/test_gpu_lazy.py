@@ -229,3 +229,26 @@ def test_lazy_peek_looks_without_folding(hip_lib):
     with pytest.raises(LramError):
         eng.lazy_peek(0, "g")
     eng.close()
+
+
+def test_read_pass_occupancy_cap_changes_nothing(hip_lib, monkeypatch):
+    """Slices of at most LRAM_LAZY_CAP2_ENVS envs run their read pass two workgroups to a CU (so that the other slice's projection
+    workgroups start beside it); larger ones three.  Occupancy is not arithmetic: 1024 slots (two slices of 512) give the same
+    bits with the cap off, and so does a batch whose slices are above the threshold."""
+    from lram_amd.engine import Engine
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=57)
+    B = 1024
+    seq = make_inputs(spec, B, 5, seed=29, reset_prob=0.05)
+    outs = []
+    for cap in (None, "0", "256"):
+        if cap is None:
+            monkeypatch.delenv("LRAM_LAZY_CAP2_ENVS", raising=False)
+        else:
+            monkeypatch.setenv("LRAM_LAZY_CAP2_ENVS", cap)
+        eng = Engine(spec, sd, B, device="cuda:0")
+        assert eng.state_mode == "lazy"
+        outs.append((_run(eng, seq), eng.export_state_tensor(2, 0).clone()))
+        eng.close()
+    for a, c in outs[1:]:
+        assert torch.equal(a, outs[0][0]) and torch.equal(c, outs[0][1])
