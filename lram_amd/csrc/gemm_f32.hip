@@ -445,17 +445,12 @@ int gemm_choose_split_k(GemmArgs& g) {
 }
 
 void gemm_choose_xcd_split(GemmArgs& g, int bm, int bn, int bytes_per_elem) {
-  // LRAM_GEMM_XCD2D (measurement knob): 0 keeps the one-dimensional map
-  static const int on = [] {
-    const char* v = std::getenv("LRAM_GEMM_XCD2D");
-    return v ? std::atoi(v) : 1;
-  }();
   g.xcd_gm = g.xcd_gn = 0;
   g.panel_w = 0;
-  if (!on || g.nb1 * g.nb2 != 1) return;
+  if (g.nb1 * g.nb2 != 1) return;
   const int tiles_m = (g.m + bm - 1) / bm, tiles_n = (g.n + bn - 1) / bn;
   // LRAM_GEMM_PANEL (measurement knob, read per launch: the bit-identity test walks through the orders): > 0 forces the panel
-  // order with that width
+  // order with that width (a width >= the grid's = the one-dimensional map: each XCD a contiguous run of the row-major order)
   const char* pv = std::getenv("LRAM_GEMM_PANEL");
   const int pw = pv ? std::atoi(pv) : 0;
   if (pw > 0) {
