@@ -415,6 +415,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
     g.c[(int64_t)row * g.ldc + col] = v;
   }
 }
+
+// The same sums (slab 0 first, then 1, ...: bit-identical to the scalar form) with four columns per thread and every slab's
+// request issued before the first add: the scalar form walks S dependent round trips per element (round 5: 1536 x 512, S = 6
+// beside a read pass 20.9 us per launch, on the chain of every 16M block at 1024 slots; Mamba's x_proj 11.6 us).
+constexpr int kReduceMaxS = 16;
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(GemmArgs g) {
+  const int n4 = g.n >> 2;
+  const int64_t total4 = (int64_t)g.m * n4;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int row = (int)(i / n4), col = 4 * (int)(i - (int64_t)row * n4);
+  const float4* ws = reinterpret_cast<const float4*>(g.splitk_ws) + i;
+  float4 p[kReduceMaxS];
+#pragma unroll
+  for (int s = 0; s < kReduceMaxS; ++s)
+    if (s < g.split_k) p[s] = ws[(int64_t)s * total4];
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f), b = r;
+  if (g.residual != nullptr) r = *reinterpret_cast<const float4*>(g.residual + (int64_t)row * g.ldc + col);
+  if (g.bias != nullptr) b = *reinterpret_cast<const float4*>(g.bias + col);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < kReduceMaxS; ++s)
+    if (s < g.split_k) v.x += p[s].x, v.y += p[s].y, v.z += p[s].z, v.w += p[s].w;
+  if (g.bias != nullptr) v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+  if (g.residual != nullptr) v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+  *reinterpret_cast<float4*>(g.c + (int64_t)row * g.ldc + col) = v;
+}
 }  // namespace
 
 // Split-K when the output has too few 128x128 tiles to fill the 256 CUs and K is deep enough to split.
@@ -429,8 +456,12 @@ int gemm_choose_split_k(GemmArgs& g) {
     const char* v = std::getenv("LRAM_SPLITK_TILES");
     // (round 4: 128 -> 48.  With the faster front end the 1024-slot step is bound by its chain, whose proj_down -- 48 tiles of
     // 128 x 128 per 512-env slice -- ran as 5 K splits + a reduce launch: 313k -> 320k env-steps/s unsplit; 512 / 2048 / 4096 slots,
-    // Mamba-48M and the 206M stack within +- 0.5 %: profiles/r04_ab_splitk_threshold.txt)
-    return v ? std::atoi(v) : 48;
+    // Mamba-48M and the 206M stack within +- 0.5 %: profiles/r04_ab_splitk_threshold.txt.
+    // Round 5: 48 -> 56.  With two read-pass workgroups per CU for chain-bound slices the split launches find slots: the 48-tile
+    // proj_down / ffn_down of 1024 slots split again, +2-3 % (361.1k / 364.8k -> 374.2k / 367.3k at a threshold of 64); the 206M
+    // stack's 60-tile proj_down (K = 2560, five slabs of 3.9 MB) stays unsplit: split it loses 1.1 % (32.16k / 32.06k ->
+    // 31.74k / 31.75k); 128: -6 % at 512 slots.  profiles/r05_ab_splitk_threshold.txt)
+    return v ? std::atoi(v) : 56;
   }();
   if (tiles >= min_tiles || nk < 4) return 1;
   int S = std::min(std::min(nk / 2, 16), (256 + tiles - 1) / tiles);
@@ -476,6 +507,14 @@ void gemm_choose_xcd_split(GemmArgs& g, int bm, int bn, int bytes_per_elem) {
 
 void launch_splitk_reduce(const GemmArgs& g, hipStream_t stream) {
   const int64_t total = (int64_t)g.m * g.n;
+  const bool vec = (g.n & 3) == 0 && (g.ldc & 3) == 0 && g.split_k <= kReduceMaxS &&
+                   ((reinterpret_cast<uintptr_t>(g.c) | reinterpret_cast<uintptr_t>(g.splitk_ws) | reinterpret_cast<uintptr_t>(g.residual) |
+                     reinterpret_cast<uintptr_t>(g.bias)) & 15) == 0;
+  if (vec) {
+    hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, g);
+    LRAM_HIP_CHECK(hipGetLastError());
+    return;
+  }
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, g);
   LRAM_HIP_CHECK(hipGetLastError());
