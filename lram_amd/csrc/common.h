@@ -338,6 +338,7 @@ struct GroupNormArgs {
   float* out;          // mode 0: g [rows, NH*DH]; mode 1: x [rows, NH*DH] (+=)
   int rows, NH, DH, mode;
   float eps;
+  float* amax = nullptr;  // mode 0, optional: [rows, NH] max |out| of the (row, head) segment (partial row maxima for the f16x2 GEMM)
 };
 void launch_group_norm(const GroupNormArgs& a, hipStream_t stream);
 

@@ -529,6 +529,7 @@ void alloc_workspace(lram_engine* e, int tokens) {
   const size_t parts = c.backbone == LRAM_BACKBONE_MAMBA ? std::max<size_t>(1, c.d_inner / 64) : 0;
   e->AMX_XN.alloc(BT);
   if (parts) e->AMX_XA.alloc(BT * parts), e->AMX_H.alloc(BT * parts);
+  if (c.backbone == LRAM_BACKBONE_XLSTM && e->use_f16x2) e->AMX_H.alloc(BT * (size_t)c.n_heads);  // group norm -> proj_down: per-head maxima
   e->X.alloc(BT * D);
   e->XN.alloc(BT * D);
   if (e->gemm_presplit && e->use_f16x2) e->XN2.alloc(BT * D);
@@ -1086,10 +1087,15 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
   ga.h = e->H.p + r0 * e->icols, ga.gamma = w.on_g, ga.beta = w.on_b, ga.skip = w.skip, ga.xa = e->XA.p + r0 * e->icols;
   ga.u = e->U.p + r0 * e->ucols, ga.out = e->G.p + r0 * e->icols, ga.rows = rows, ga.NH = NH, ga.DH = DH, ga.mode = 0;
   ga.eps = c.ln_eps;
+  // the norm's waves (one per row and head) hand proj_down's operand row maxima over as NH partial maxima per row: the
+  // row_amax launch between the two (8-11 us on every block of a chain-bound slice's chain) goes
+  const bool hand_over = e->AMX_H.p != nullptr && f16x2_rows(e, rows, D, inner);
+  ga.amax = hand_over ? e->AMX_H.p + r0 * NH : nullptr;
   launch_group_norm(ga, sl.s);
   GemmArgs dn;
   dn.a = e->G.p + r0 * e->icols, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
   dn.m = rows, dn.n = D, dn.k = inner;
+  if (hand_over) dn.a_amax = ga.amax, dn.amax_parts = NH;
   gemm(e, dn, sl.s);
 }
 

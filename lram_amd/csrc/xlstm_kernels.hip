@@ -551,6 +551,7 @@ __global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
   }
   const float var = wave_sum(q) / (float)DH;
   const float rstd = 1.f / sqrtf(var + a.eps);
+  float omax = 0.f;
 #pragma unroll
   for (int j = 0; j < kGnMaxV; ++j) {
     const int i = lane + 64 * j;
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
       o.z = (o.z + sk.z * xa.z) * silu_f(z.z);
       o.w = (o.w + sk.w * xa.w) * silu_f(z.w);
       *reinterpret_cast<float4*>(dst) = o;
+      omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     } else {
       float4 x = *reinterpret_cast<const float4*>(dst);
       x.x += o.x;
@@ -587,6 +589,10 @@ __global__ __launch_bounds__(64) void group_norm_kernel(GroupNormArgs a) {
       x.w += o.w;
       *reinterpret_cast<float4*>(dst) = x;
     }
+  }
+  if (a.mode == 0 && a.amax != nullptr) {
+    const float m = wave_max(omax);
+    if (lane == 0) a.amax[(int64_t)row * a.NH + h] = m;
   }
 }
 
