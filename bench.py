@@ -157,6 +157,180 @@ def cpu_baseline(spec, sd, seconds_budget=22.0):
             "b1_sample": f"B=1, {n1} timesteps after 3 warm-up, {min(best_thr, 8)} threads"}
 
 
+
+# ---- the other BASELINE configurations, timed in the same run ---------------------------------
+PER_PRODUCT = {"f16x2": 3, "bf16x3": 6, "f32": 1, "few_row_f32": 1}   # matrix-core products issued per fp32 product
+
+
+def state_pass_roofline(spec, T, lazy, main_ms, n_main, aux_ms, n_aux, steps, envs_total):
+    """Roofline block of one configuration's dominant kernel from its live HIP-event timing (lram_profile_end_split): the
+    bytes one launch has to move over its mean duration; the lazy mode's fold launches are shared
+    out over the state-pass launches."""
+    if spec.backbone == "xlstm":
+        n_rec = spec.n_blocks - len(spec.slstm_at)
+        per_env = cell_bytes_lazy(spec, T) if lazy else cell_bytes_materialised(spec, T)
+        kname = "mlstm_lazy_cell_kernel + its share of mlstm_lazy_fold_kernel" if lazy else "mlstm_cell_kernel"
+    else:
+        n_rec, per_env, kname = spec.n_blocks, ssm_bytes(spec, T), "mamba_ssm_lane_kernel (selective state update)"
+    r = {"bound": "hbm", "kernel": kname, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
+         "traffic": None, "algorithmic_bytes_per_env_per_launch": per_env}
+    if n_main > 0:
+        launches_per_step = n_main / steps
+        envs_per_launch = envs_total * n_rec / launches_per_step
+        avg = main_ms / n_main + (aux_ms / n_main if n_aux else 0.0)
+        ab = per_env * envs_per_launch
+        r.update(algorithmic_bytes_per_launch=ab, envs_per_launch=envs_per_launch, launches_per_step=launches_per_step,
+                 avg_launch_ms=avg, launches_timed=n_main, achieved=ab / (avg * 1e-3) / 1e9)
+        r["frac"] = r["achieved"] / HBM_PEAK_GBPS
+    return r
+
+
+def mfma_block(gemm_ran, seconds):
+    """Matrix-core work of the projections (engine dispatch counters) over a measured interval."""
+    flops = sum(v["flop"] for v in gemm_ran.values())
+    issued = sum(v["flop"] * PER_PRODUCT[k] for k, v in gemm_ran.items())
+    return {"bound": "mfma", "fp32_equiv_flop": flops, "issued_flop": issued, "achieved": issued / seconds / 1e15,
+            "peak": MFMA_PEAK_PFLOPS, "unit": "PFLOP/s", "frac": issued / seconds / 1e15 / MFMA_PEAK_PFLOPS,
+            "note": "issued matrix-core FLOPs of the projections (3 f16 products per fp32 product on the f16x2 kernels) over the "
+                    "WHOLE measured interval, every other kernel's time included"}
+
+
+def _leg_inputs(spec, B, n_steps, ep_len, rtg0, drtg, native, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ring = torch.zeros(4, B, spec.state_dim, device=dev)
+    ring[:, :, :native] = torch.rand(4, B, native, generator=g, device=dev) * 2 - 1
+    age = (torch.arange(B, device=dev).view(1, -1) % ep_len + torch.arange(n_steps, device=dev).view(-1, 1)) % ep_len
+    masks = (age == 0).to(torch.uint8).contiguous()
+    masks[0] = 1
+    return ring, (rtg0 - age.float() * drtg).contiguous(), masks, g
+
+
+def step_leg(tag, cfg, B, K, W, dev, ep_len, rtg0, drtg, native, image=False, compat_act_dim=0, what=""):
+    """One BASELINE configuration as K timed lram_step calls on a fresh engine (inputs resident in HBM, the state pass
+    HIP-event timed on every 2nd step), engine destroyed afterwards."""
+    from lram_amd import init_state_dict, preset
+    from lram_amd.engine import Engine
+    spec = preset(cfg)
+    sd = init_state_dict(spec, seed=0, with_image_encoder=image)
+    eng = Engine(spec, sd, B, device=dev)
+    T = spec.tokens_per_step
+    prime = 16 if eng.state_mode == "lazy" else 2
+    ring, rtgs, masks, g = _leg_inputs(spec, B, prime + W + K, ep_len, rtg0, drtg, native, dev, 4321)
+    zero = torch.zeros(B, device=dev)
+    if image:
+        frames = torch.randint(0, 256, (2, B, 3, 64, 64), generator=g, device=dev, dtype=torch.uint8)
+        emb = torch.empty(B, spec.d_model, device=dev)
+    if compat_act_dim:
+        eng.set_compat_mode(compat_act_dim, True)
+
+    def one(t):
+        if image:
+            eng.embed_images(frames[t % 2], emb)
+            eng.step(emb, rtgs[t], zero, masks[t], discrete=True, obs_is_embedding=True)
+        else:
+            eng.step(ring[t % 4], rtgs[t], zero, masks[t])
+
+    for t in range(prime + W):
+        one(t)
+    torch.cuda.synchronize()
+    eng.profile_begin_sampled(2)
+    eng.gemm_counts(reset=True)
+    t0 = time.perf_counter()
+    for t in range(prime + W, prime + W + K):
+        one(t)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ran = eng.gemm_counts()
+    main_ms, n_main, aux_ms, n_aux = eng.profile_end_split()
+    lazy = eng.state_mode == "lazy"
+    leg = {"id": tag, "workload": what or f"{cfg}, {B} env slots", "preset": cfg, "batch": B, "steps": K, "warmup": W + prime,
+           "value": B * K / wall, "unit": "env-steps/s", "ms_per_step": wall / K * 1e3,
+           "state_mode": eng.state_mode if spec.backbone == "xlstm" else None,
+           "projections": projection_label(ran, "f16x2"),
+           # (the reference Mamba trajectory runs `compat_act_dim` forwards per env-step: that many state passes over every env)
+           "roofline": state_pass_roofline(spec, T, lazy, main_ms, n_main, aux_ms, n_aux, len(range(0, K, 2)),
+                                           B * max(1, compat_act_dim)),
+           "mfma": mfma_block(ran, wall)}
+    if spec.backbone == "xlstm":
+        leg["whole_step_8d_GBps"] = (2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim) * leg["value"] / 1e9
+    eng.close()
+    del eng, sd
+    torch.cuda.empty_cache()
+    return leg
+
+
+def prefill_leg(tag, cfg, B, L, n_decode, dev, what=""):
+    """BASELINE config 5: lram_prefill of L stored timesteps (3 L tokens; chunkwise-parallel kernels) on B envs, then n_decode
+    single steps from the prefilled state.  `value` = env-timesteps/s of the prefill; the decode steps are reported beside it."""
+    from lram_amd import init_state_dict, preset
+    from lram_amd.engine import Engine
+    spec = preset(cfg)
+    sd = init_state_dict(spec, seed=0)
+    eng = Engine(spec, sd, B, device=dev)
+    g = torch.Generator(device=dev).manual_seed(77)
+    obs = torch.zeros(B, L, spec.state_dim, device=dev)
+    obs[:, :, :168] = torch.rand(B, L, 168, generator=g, device=dev) * 2 - 1          # Mimicgen: 168-dim full state space
+    rtg = (6.0 - 0.01 * torch.arange(L, device=dev).float()).repeat(B, 1).contiguous()
+    rew = torch.zeros(B, L, device=dev)
+    ones = torch.ones(B, dtype=torch.uint8, device=dev)
+    eng.prefill(obs, rtg, rew, ones)                                                   # warm-up pass (allocations, first launches)
+    torch.cuda.synchronize()
+    eng.gemm_counts(reset=True)
+    t0 = time.perf_counter()
+    eng.prefill(obs, rtg, rew, ones)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ran = eng.gemm_counts()
+    o1, r1, z1 = obs[:, 0].contiguous(), rtg[:, -1].contiguous(), torch.zeros(B, device=dev)
+    for _ in range(2):
+        eng.step(o1, r1, z1, None)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n_decode):
+        eng.step(o1, r1, z1, None)
+    torch.cuda.synchronize()
+    wall_d = time.perf_counter() - t1
+    leg = {"id": tag, "workload": what or f"{cfg} prefill", "preset": cfg, "batch": B, "context_timesteps": L,
+           "steps": 1, "warmup": 1, "value": B * L / wall, "unit": "env-timesteps/s", "ms_per_step": wall * 1e3,
+           "projections": projection_label(ran, "f16x2"), "mfma": mfma_block(ran, wall),
+           "decode": {"steps": n_decode, "ms_per_step": wall_d / n_decode * 1e3, "value": B * n_decode / wall_d,
+                      "unit": "env-steps/s", "state_mode": eng.state_mode}}
+    eng.close()
+    del eng, sd
+    torch.cuda.empty_cache()
+    return leg
+
+
+def config_legs(dev):
+    """BASELINE.json `configs` 2-5 at their per-GPU sizes, one fresh engine each (the headline's is closed first)."""
+    legs = []
+    plan = [
+        lambda: step_leg("C2", "xlstm_16m", 1024, 48, 4, dev, 1000, 4.51274, 0.01, 17,
+                         what="xLSTM[7:1] 16M, DMControl cheetah-run-shaped obs, continuous head, 1024 env slots"),
+        lambda: step_leg("C3", "mamba_48m", 2048, 32, 4, dev, 200, 6.50346, 0.005, 39,
+                         what="Mamba 48M, Meta-World-shaped obs (39 dims), 2048 env slots, one state advance per env-step"),
+        lambda: step_leg("C3-reference-trajectory", "mamba_48m", 2048, 12, 2, dev, 200, 6.50346, 0.005, 39, compat_act_dim=4,
+                         what="Mamba 48M, 2048 env slots, the reference Mamba agent's trajectory (src/algos/decision_mamba.py:"
+                              "107-122: one forward per action dim = 4 per env-step on Meta-World, layer-0-only resets)"),
+        lambda: step_leg("C4-per-gpu-shard", "xlstm_206m", 512, 12, 2, dev, 1000, 3.0, 0.001, 0, image=True,
+                         what="xLSTM[7:1] 206M, Atari-shaped uint8 [3,64,64] frames -> IMPALA-CNN -> 18-way discrete head, "
+                              "512 env slots = one GPU's shard of BASELINE's 4096 over 8"),
+        lambda: prefill_leg("C5", "xlstm_206m", 64, 512, 16, dev,
+                            what="xLSTM 206M, Mimicgen-shaped obs: lram_prefill of 512 timesteps (1536 tokens, chunkwise-parallel) "
+                                 "on 64 envs, then 16 single-step decodes"),
+    ]
+    for fn in plan:
+        t0 = time.time()
+        try:
+            leg = fn()
+        except Exception as ex:   # a leg that cannot run says so on the line instead of taking the headline down with it
+            leg = {"id": "?", "error": f"{type(ex).__name__}: {ex}"}
+        leg["leg_wall_s"] = time.time() - t0
+        log("[bench] config leg:", json.dumps({k: leg.get(k) for k in ("id", "value", "unit", "ms_per_step", "leg_wall_s", "error")}))
+        legs.append(leg)
+    return legs
+
+
 # ---- the run ------------------------------------------------------------------------------------------------
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -182,6 +356,8 @@ def parse_args(argv=None):
     ap.add_argument("--env-act-dim", type=int, default=0, help="action dims the env uses (compat forwards per step)")
     ap.add_argument("--host-io-steps", type=int, default=48, help="steps of the host-inclusive leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` legs (BASELINE configs 2-5 at their per-GPU sizes; default-workload N = 1 runs only)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="live HIP-event timing of the dominant kernel on every n-th step of the timed region (1 = every step)")
@@ -668,8 +844,17 @@ def main(argv=None, engine_factory=None, device=None):
     out.pop("_copy_ceiling_pending", None)
     out["algorithmic_bytes_per_env_step"] = 2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim
     out["whole_step_8d_GBps"] = out["algorithmic_bytes_per_env_step"] * value / world / 1e9
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    default_workload = (args.config == "xlstm_16m" and args.obs == "state" and args.batch == 4096 and args.global_batch == 0
+                        and not args.mamba_compat and not args.graph)
+    if rank == 0 and world == 1 and not dist_on and default_workload and not args.no_configs:
+        # BASELINE.json's other configurations, each on a fresh engine after the headline's is gone
         eng.close()
+        eng = None
+        torch.cuda.empty_cache()
+        out["configs"] = config_legs(dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if eng is not None:
+            eng.close()
         torch.cuda.empty_cache()
         out["cpu_baseline"] = cpu_baseline(spec, sd)
     if rank == 0:

@@ -162,7 +162,11 @@ int32_t lram_get_taps(lram_engine* e, float* dev_tokens_embed, float* dev_hidden
  *   xLSTM mLSTM block: 0 = C [B,NH,DH,DH]  1 = n [B,NH,DH,1]  2 = m [B,NH,1,1]  3 = conv [B,K,inner]
  *   xLSTM sLSTM block: 0 = slstm_state [4,B,D] (y,c,n,m)      3 = conv [B,K,D]
  *   Mamba layer      : 0 = ssm_state [B,d_inner,d_state]      3 = conv_state [B,d_inner,d_conv]
- * lram_state_numel returns the element count (0 if the tensor does not exist for that block). */
+ * lram_state_numel returns the element count (0 if the tensor does not exist for that block).
+ * Invariant checked at import: an sLSTM hidden plane (slstm_state[0] = y) must satisfy |y| < 16 (no NaN) wherever the step runs
+ * its recurrent products on binary16 planes of 2^12 y (the default with f16x2 projections; the recurrence itself only produces
+ * |y| < 1).  lram_state_import refuses anything else (one reduction + host synchronisation on that tensor); LRAM_SLSTM_SEQ=2 or
+ * LRAM_GEMM=f32 select the exact-fp32 recurrence, which has no such limit. */
 int64_t lram_state_numel(const lram_engine* e, int32_t block, int32_t which);
 int32_t lram_state_export(lram_engine* e, int32_t block, int32_t which, float* dev_dst, void* stream);
 int32_t lram_state_import(lram_engine* e, int32_t block, int32_t which, const float* dev_src, void* stream);

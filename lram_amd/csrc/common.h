@@ -106,6 +106,18 @@ struct GemmArgs {
   int split_k = 1;        // set by the launcher
   int k_tiles_per_split = 0;
 };
+// Measurement knobs of the projection launchers (LRAM_GEMM_TILE / LRAM_F16P_STAGES / LRAM_GEMM_PANEL / LRAM_SPLITK_TILES), read
+// from the environment ONCE -- no getenv on the step path (an environ scan per launch, and a race with a concurrent setenv from
+// another host thread) -- and again only where an engine is created (lram_create, like every other knob) or a standalone test /
+// micro-benchmark entry (lram_gemm_*) starts: that is how the bit-identity tests walk through tiles, stages and tile orders.
+struct GemmKnobs {
+  int tile = 0;          // 64 / 128: force the workgroup tile height of the f16x2 kernels
+  int stages = 0;        // 1 / 2: force the LDS stage count of the pre-split kernel
+  int panel = 0;         // > 0: force the column-panel tile order with that width
+  int splitk_tiles = 56; // outputs with fewer 128 x 128 tiles than this are split along K
+};
+const GemmKnobs& gemm_knobs();
+void gemm_knobs_reload();
 int gemm_choose_split_k(GemmArgs& g);                             // fills split_k / k_tiles_per_split, returns S
 // Output-tile -> XCD map of the 128-column-tile projection kernels (bm = their tile height, bytes_per_elem = operand bytes
 // per element as staged: 4 for fp32 / two f16 planes).  Hardware hands consecutive workgroup ids to the 8 XCDs in turn, so

@@ -110,6 +110,7 @@ struct lram_engine {
                                   // (f16x2 projections, the default) two f16 planes in the same bytes + slstm_rinv, the inverse row scales
   std::vector<DevBuf> slstm_rinv;
   int lazy_cap2_envs = 896;       // LRAM_LAZY_CAP2_ENVS: largest slice whose read pass runs two workgroups per CU (0 = never)
+  bool gn_amax_handover = true;   // LRAM_GN_AMAX=0: proj_down's operand row maxima from their own launch, not from the group norm
   bool slstm_seq_f32 = false;     // LRAM_SLSTM_SEQ=2: its exact-fp32 form even where the projections run as f16x2
   bool slstm_seq = true;          // LRAM_SLSTM_SEQ=0: per-token recurrent GEMM + pointwise launches for slices beyond the token kernel's
   std::vector<DevBuf> gate_coef;  // mLSTM: folded i / f gate coefficients per block (mlstm_front.hip), geometries it covers
@@ -1089,7 +1090,9 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
   ga.eps = c.ln_eps;
   // the norm's waves (one per row and head) hand proj_down's operand row maxima over as NH partial maxima per row: the
   // row_amax launch between the two (8-11 us on every block of a chain-bound slice's chain) goes
-  const bool hand_over = e->AMX_H.p != nullptr && f16x2_rows(e, rows, D, inner);
+  // (LRAM_GN_AMAX=0, test switch: the standalone row-maximum launch instead; bit-identical by construction -- a maximum of
+  // partial maxima is exact -- and tests/test_gpu_realbatch.py holds it to that)
+  const bool hand_over = e->gn_amax_handover && e->AMX_H.p != nullptr && f16x2_rows(e, rows, D, inner);
   ga.amax = hand_over ? e->AMX_H.p + r0 * NH : nullptr;
   launch_group_norm(ga, sl.s);
   GemmArgs dn;
@@ -1657,6 +1660,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     e->cfg = *cfg;
     e->device = device;
     // Environment knobs (measurement / test switches; the table is in DESIGN.md section 5)
+    gemm_knobs_reload();   // the projection launchers' process-wide knobs: read here, never on the step path
     if (const char* v = std::getenv("LRAM_PREFILL_CHUNK")) e->chunk_prefill = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_STATE")) {
       const std::string m(v);
@@ -1668,6 +1672,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_COMPAT_SHARE")) e->compat_share = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_MAMBA_DT_FUSE")) e->mamba_dt_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
+    if (const char* v = std::getenv("LRAM_GN_AMAX")) e->gn_amax_handover = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0, e->slstm_seq_f32 = std::atoi(v) == 2;
     if (const char* v = std::getenv("LRAM_LAZY_CAP2_ENVS")) e->lazy_cap2_envs = std::max(0, std::atoi(v));
@@ -1757,6 +1762,10 @@ int32_t lram_reset(lram_engine* e, const uint8_t* dev_env_mask, void* stream) {
   });
 }
 
+// Every public entry that launches the stack counts as one call of a sampled profile (lram_profile_begin_sampled): whether ITS
+// launches are timed is decided here, not inherited from whatever call came before.
+static void prof_tick(lram_engine* e) { e->prof_live = !e->prof_on || (e->prof_calls++ % e->prof_every) == 0; }
+
 int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding, const float* dev_rtg,
                   const float* dev_reward, const uint8_t* dev_reset_mask, int32_t discrete, float* dev_actions,
                   int32_t* dev_tokens, void* stream) {
@@ -1767,8 +1776,8 @@ int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding
     LRAM_HIP_CHECK(hipSetDevice(e->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     compat_prepare(e, discrete);  // (workspace of the shared repeated forwards: outside any capture)
-    e->prof_live = !e->prof_on || (e->prof_calls++ % e->prof_every) == 0;
-    if (e->graph_mode && !e->prof_on) {
+    prof_tick(e);
+    if (e->graph_mode && !(e->prof_on && e->prof_live)) {  // (a sampled run's un-timed steps keep the graph path)
       GraphKey key{};
       key.obs = dev_obs, key.rtg = dev_rtg, key.rew = dev_reward, key.mask = dev_reset_mask, key.act = dev_actions;
       key.tok = dev_tokens, key.emb = obs_is_embedding, key.discrete = discrete, key.B = e->B, key.stream = s;
@@ -1808,6 +1817,7 @@ int32_t lram_prefill(lram_engine* e, const float* dev_obs_seq, int32_t obs_is_em
     LRAM_REQUIRE(timesteps >= 1, "lram_prefill: timesteps must be >= 1");
     LRAM_REQUIRE(e->cfg.tokens_per_step == 3, "lram_prefill: the (state, rtg, reward) front end needs tokens_per_step == 3");
     LRAM_HIP_CHECK(hipSetDevice(e->device));
+    prof_tick(e);
     timesteps_launches(e, dev_obs_seq, obs_is_embedding, dev_rtg_seq, dev_reward_seq, timesteps, dev_reset_mask, discrete,
                        dev_actions, dev_tokens, static_cast<hipStream_t>(stream));
   });
@@ -1831,6 +1841,7 @@ int32_t lram_encoder_step(lram_engine* e, const float* dev_inputs_embeds, int32_
       LRAM_HIP_CHECK(hipDeviceSynchronize());
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    prof_tick(e);
     const size_t bytes = sizeof(float) * (size_t)e->B * tokens * e->cfg.d_model;
     if (!lazy_active(e, tokens)) lazy_materialize(e, s);
     LRAM_HIP_CHECK(hipMemcpyAsync(e->X.p, dev_inputs_embeds, bytes, hipMemcpyDeviceToDevice, s));
@@ -1882,9 +1893,34 @@ int32_t lram_state_import(lram_engine* e, int32_t block, int32_t which, const fl
     LRAM_REQUIRE(e && e->B > 0 && dev_src, "lram_state_import: bad argument");
     StateView v = state_view(e, block, which);
     LRAM_REQUIRE(v.p != nullptr, "lram_state_import: no such state tensor");
-    lazy_materialize(e, static_cast<hipStream_t>(stream));
-    LRAM_HIP_CHECK(hipMemcpyAsync(v.p, dev_src, v.n * sizeof(float), hipMemcpyDeviceToDevice,
-                                  static_cast<hipStream_t>(stream)));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool slstm = e->cfg.backbone == LRAM_BACKBONE_XLSTM && e->cfg.block_is_slstm[block];
+    if (slstm && which == 0 && e->slstm_rinv[block].p != nullptr) {
+      // The f16x2 form of the sLSTM step (slstm_seq16_kernel) keeps h_t in LDS as two binary16 planes of 2^12 h: every state the
+      // recurrence itself produces has |h| < 1, a foreign one need not (|h| >= 16 overflows binary16 to inf and the next step
+      // spreads NaN).  A rare call: one row-maximum launch over the h plane [B, D] and a host synchronisation are affordable.
+      LRAM_HIP_CHECK(hipSetDevice(e->device));
+      const int B = e->B, D = e->cfg.d_model;
+      float* dmax = nullptr;
+      LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dmax), (size_t)B * sizeof(float)));
+      std::vector<float> hmax((size_t)B);
+      try {
+        launch_row_amax(dev_src, D, nullptr, 0, B, D, dmax, s);
+        LRAM_HIP_CHECK(hipMemcpyAsync(hmax.data(), dmax, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
+        LRAM_HIP_CHECK(hipStreamSynchronize(s));
+      } catch (...) {
+        (void)hipFree(dmax);
+        throw;
+      }
+      (void)hipFree(dmax);
+      for (int b = 0; b < B; ++b)
+        LRAM_REQUIRE(hmax[(size_t)b] < 15.9f,   // (a NaN row fails the comparison too)
+                     "lram_state_import: sLSTM hidden plane holds |h| >= 16 (or NaN): outside what the recurrence produces (|h| < 1) "
+                     "and outside the binary16 planes of the f16x2 step kernel; import a state the model produced, or run the "
+                     "engine with LRAM_SLSTM_SEQ=2 / LRAM_GEMM=f32 (exact fp32 recurrence, no range limit)");
+    }
+    lazy_materialize(e, s);
+    LRAM_HIP_CHECK(hipMemcpyAsync(v.p, dev_src, v.n * sizeof(float), hipMemcpyDeviceToDevice, s));
   });
 }
 
@@ -2044,6 +2080,7 @@ int32_t lram_gemm_counts(lram_engine* e, double* out8, int32_t reset) {
 int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
                       const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
   return guarded([&] {
+    gemm_knobs_reload();   // standalone test / micro-benchmark entry: the launch knobs as the environment has them NOW
     GemmArgs g;
     g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
     g.residual = accumulate ? dev_c : nullptr;
@@ -2055,6 +2092,7 @@ int32_t lram_gemm_f32(const float* dev_a, int64_t lda, const float* dev_w, int64
 int32_t lram_gemm_skinny(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
                          const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
   return guarded([&] {
+    gemm_knobs_reload();   // standalone test / micro-benchmark entry: the launch knobs as the environment has them NOW
     GemmArgs g;
     g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
     g.residual = accumulate ? dev_c : nullptr;
@@ -2066,6 +2104,7 @@ int32_t lram_gemm_skinny(const float* dev_a, int64_t lda, const float* dev_w, in
 int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
                          const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
   return guarded([&] {
+    gemm_knobs_reload();   // standalone test / micro-benchmark entry: the launch knobs as the environment has them NOW
     LRAM_REQUIRE(ldw == k, "lram_gemm_bf16x3: W must be contiguous [n, k]");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t numel = (size_t)n * k;
@@ -2090,6 +2129,7 @@ int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, in
 int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
                         const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
   return guarded([&] {
+    gemm_knobs_reload();   // standalone test / micro-benchmark entry: the launch knobs as the environment has them NOW
     LRAM_REQUIRE(ldw == k, "lram_gemm_f16x2: W must be contiguous [n, k]");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t numel = split_f16x2_plane_elems((size_t)n, (size_t)k);  // (K-tile-major planes)
@@ -2119,6 +2159,7 @@ int32_t lram_gemm_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int
 int32_t lram_gemm_f16x2_presplit(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
                                  const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
   return guarded([&] {
+    gemm_knobs_reload();   // standalone test / micro-benchmark entry: the launch knobs as the environment has them NOW
     LRAM_REQUIRE(ldw == k, "lram_gemm_f16x2_presplit: W must be contiguous [n, k]");
     LRAM_REQUIRE(k % 32 == 0 && k <= 3072, "lram_gemm_f16x2_presplit: k must be a multiple of 32, <= 3072");
     hipStream_t s = static_cast<hipStream_t>(stream);

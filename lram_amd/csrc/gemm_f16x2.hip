@@ -448,8 +448,7 @@ void launch_gemm_f16x2(const GemmArgs& g_in, hipStream_t stream) {
   // where they would leave CUs without any workgroup and K is short (1536 x 1024 x 512: 31.6 us with 96 tiles of 128 rows, 20.5
   // with 192 of 64; long-K launches: see launch_gemm_f16x2p)
   // (LRAM_GEMM_TILE = 64 / 128 forces one: the knob of launch_gemm_f16x2p)
-  const char* fv = std::getenv("LRAM_GEMM_TILE");
-  const int force_bm = fv ? std::atoi(fv) : 0;
+  const int force_bm = gemm_knobs().tile;
   constexpr int bm64_below = 256, bm64_anyk = 128;
   const bool small = force_bm == 64 || (force_bm != 128 && g.m > 64 && ((S == 1 && tiles128 < 768 && tiles_n <= 6) || ((long)tiles128 * S < bm64_below && g.k <= 768) || (long)tiles128 * S < bm64_anyk));
   const int tiles = small ? ((g.m + 63) / 64) * tiles_n : tiles128;

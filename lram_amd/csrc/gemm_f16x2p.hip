@@ -335,8 +335,7 @@ static void launch_stage(const GemmArgs& g, dim3 grid, hipStream_t stream) {
 // launches keep 128 rows (inside the two-slice pipeline the small tile's 1.5 x operand traffic per flop costs Mamba-48M 2.3 %
 // and the 206M stack 1.5 %: profiles/r04_ab_tile_height.txt).  LRAM_GEMM_TILE (measurement knob): 64 / 128 force one.
 int gemm_f16x2p_tile(const GemmArgs& g, int S) {
-  const char* fv = std::getenv("LRAM_GEMM_TILE");  // (read per launch: the bit-identity test walks through the tiles)
-  const int force = fv ? std::atoi(fv) : 0;
+  const int force = gemm_knobs().tile;  // (cached: common.h GemmKnobs)
   if (force == 64 || force == 128) return force;
   const long tiles128 = (long)((g.m + 127) / 128) * ((g.n + 127) / 128);
   if (g.m > 64 && ((tiles128 * S < 256 && g.k <= 768) || tiles128 * S < 128)) return 64;
@@ -349,8 +348,7 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
   // 2 = two stages, the next tile's DMA under the current tile's MFMAs, one barrier per K tile, two workgroups per CU
   // default 0 = by grid size (same box, standalone: 16M proj_up 768 tiles 55 us with one stage / 65 with two; Mamba in_proj 576
   // tiles 67 / 80; 16M proj_down 192 tiles 50 / 40; Mamba out_proj 144 tiles 65 / 51 -- profiles/r04_gemm_f16x2p_durations.txt)
-  const char* sv = std::getenv("LRAM_F16P_STAGES");
-  const int stages_env = sv ? std::atoi(sv) : 0;
+  const int stages_env = gemm_knobs().stages;
   g.mfma_prio = 1;
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
   LRAM_REQUIRE(gemm_f16x2p_supported(g), "gemm f16x2 (pre-split operands): unsupported operand layout");

@@ -444,6 +444,30 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(GemmArgs g) {
 }
 }  // namespace
 
+namespace {
+GemmKnobs g_knobs;
+bool g_knobs_read = false;
+int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : dflt;
+}
+}  // namespace
+
+void gemm_knobs_reload() {
+  GemmKnobs k;
+  k.tile = env_int("LRAM_GEMM_TILE", 0);
+  k.stages = env_int("LRAM_F16P_STAGES", 0);
+  k.panel = env_int("LRAM_GEMM_PANEL", 0);
+  k.splitk_tiles = env_int("LRAM_SPLITK_TILES", 56);
+  g_knobs = k;
+  g_knobs_read = true;
+}
+
+const GemmKnobs& gemm_knobs() {
+  if (!g_knobs_read) gemm_knobs_reload();
+  return g_knobs;
+}
+
 // Split-K when the output has too few 128x128 tiles to fill the 256 CUs and K is deep enough to split.
 int gemm_choose_split_k(GemmArgs& g) {
   g.split_k = 1;
@@ -452,8 +476,6 @@ int gemm_choose_split_k(GemmArgs& g) {
   const int tiles = ((g.m + BM - 1) / BM) * ((g.n + BN - 1) / BN);
   const int nk = (g.k + BK - 1) / BK;
   // LRAM_SPLITK_TILES (measurement knob): outputs with fewer 128 x 128 tiles than this are split along K
-  static const int min_tiles = [] {
-    const char* v = std::getenv("LRAM_SPLITK_TILES");
     // (round 4: 128 -> 48.  With the faster front end the 1024-slot step is bound by its chain, whose proj_down -- 48 tiles of
     // 128 x 128 per 512-env slice -- ran as 5 K splits + a reduce launch: 313k -> 320k env-steps/s unsplit; 512 / 2048 / 4096 slots,
     // Mamba-48M and the 206M stack within +- 0.5 %: profiles/r04_ab_splitk_threshold.txt.
@@ -461,8 +483,7 @@ int gemm_choose_split_k(GemmArgs& g) {
     // proj_down / ffn_down of 1024 slots split again, +2-3 % (361.1k / 364.8k -> 374.2k / 367.3k at a threshold of 64); the 206M
     // stack's 60-tile proj_down (K = 2560, five slabs of 3.9 MB) stays unsplit: split it loses 1.1 % (32.16k / 32.06k ->
     // 31.74k / 31.75k); 128: -6 % at 512 slots.  profiles/r05_ab_splitk_threshold.txt)
-    return v ? std::atoi(v) : 56;
-  }();
+  const int min_tiles = gemm_knobs().splitk_tiles;
   if (tiles >= min_tiles || nk < 4) return 1;
   int S = std::min(std::min(nk / 2, 16), (256 + tiles - 1) / tiles);
   while (S > 1 && (int64_t)S * g.m * g.n > g.splitk_ws_elems) --S;
@@ -480,10 +501,10 @@ void gemm_choose_xcd_split(GemmArgs& g, int bm, int bn, int bytes_per_elem) {
   g.panel_w = 0;
   if (g.nb1 * g.nb2 != 1) return;
   const int tiles_m = (g.m + bm - 1) / bm, tiles_n = (g.n + bn - 1) / bn;
-  // LRAM_GEMM_PANEL (measurement knob, read per launch: the bit-identity test walks through the orders): > 0 forces the panel
-  // order with that width (a width >= the grid's = the one-dimensional map: each XCD a contiguous run of the row-major order)
-  const char* pv = std::getenv("LRAM_GEMM_PANEL");
-  const int pw = pv ? std::atoi(pv) : 0;
+  // LRAM_GEMM_PANEL (measurement knob; gemm_knobs(): the bit-identity test walks through the orders via the standalone entries):
+  // > 0 forces the panel order with that width (a width >= the grid's = the one-dimensional map: each XCD a contiguous run of
+  // the row-major order)
+  const int pw = gemm_knobs().panel;
   if (pw > 0) {
     g.panel_w = std::min(pw, tiles_n);
     return;

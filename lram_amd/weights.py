@@ -18,6 +18,9 @@ import torch
 from .config import ModelSpec
 
 IMPALA_CHANNELS = (16, 32, 32)  # src/algos/models/image_encoders.py:39-43 (model_size 1)
+# scheme "trained_like": mLSTM gate weight scales in units of 1/sqrt(fan_in) (measured on the 16M stack: input-gate
+# pre-activations of standard deviation ~5, i.e. about +-15 over a trajectory; forget-gate ones ~1.3 around the 3..6 bias)
+TRAINED_LIKE_IGATE, TRAINED_LIKE_FGATE = 6.0, 1.0
 
 
 # ----------------------------------------------------------------------------------------------
@@ -122,8 +125,18 @@ def init_state_dict(spec: ModelSpec, seed: int = 0, scheme: str = "exercise", wi
     scheme "reference": follows the reference / package initialisers where they matter for the dynamics
         (HF normal(0, 0.02) for Linear, sLSTM recurrent kernel zeros and power-law forget bias, mLSTM gate
         weights zero with forget bias linspace(3, 6), Mamba A_log = log(1..N), D = 1, dt bias = softplus^-1
-        of log-uniform [1e-3, 1e-1]) -- the distribution a freshly constructed reference model has.
+        of log-uniform [1e-3, 1e-1]) -- the distribution a freshly constructed reference model has
+        (src/algos/models/decision_xlstm.py:170-171,210-213: post_init -> reset_parameters).
+    scheme "trained_like": the long-memory corner a trained checkpoint sits in
+        (src/algos/decision_transformer_sb3.py:1120-1184 loads such weights): dense weights at 1/sqrt(fan_in)
+        (O(1) activations), mLSTM forget bias linspace(3, 6) KEPT (f ~ 0.95-0.998: hundreds of steps of memory),
+        input-gate weights large enough that the pre-activation spans about +-15 (the stabiliser m leaves
+        [-8, 8]), forget-gate weights moderate, sLSTM recurrent kernel non-zero with the unscaled power-law
+        forget bias, Mamba dt_proj.bias at BOTH ends of [1e-3, 1e-1] and A_log up to log(16) + 2.
     """
+    assert scheme in ("exercise", "reference", "trained_like"), scheme
+    ex = scheme != "reference"          # tensors that are random wherever the model is not freshly initialised
+    tl = scheme == "trained_like"
     # Portable generator: PCG64 uniform floats are exact integer->float conversions, so the same seed gives
     # bit-identical weights on every host (torch.randn / exp / log go through SIMD-dependent libm paths).
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -142,24 +155,28 @@ def init_state_dict(spec: ModelSpec, seed: int = 0, scheme: str = "exercise", wi
         fan_in = shape[-1] if len(shape) >= 2 else 1
         if name.endswith("A_log"):
             t = f64(np.log(np.arange(1, shape[1] + 1, dtype=np.float64))).repeat(shape[0], 1)
-            if scheme == "exercise":
+            if tl:     # decay rates up to e^2 x the initial ones: A = -exp(A_log) down to -16 e^2
+                t = t + torch.from_numpy(rng.random(tuple(shape), dtype=np.float32) * np.float32(2.0))
+            elif ex:
                 t = t + randn(shape, 0.1)
         elif name.endswith("mixer.D"):
-            t = torch.ones(shape) + (randn(shape, 0.1) if scheme == "exercise" else 0)
+            t = torch.ones(shape) + (randn(shape, 0.1) if ex else 0)
         elif name.endswith("dt_proj.bias"):
             u = rng.random(tuple(shape), dtype=np.float32).astype(np.float64)
+            if tl:     # both ends of the initialiser's range, nothing in between
+                u = (u >= 0.5).astype(np.float64)
             dt = np.maximum(np.exp(u * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3)), 1e-4)
             t = f64(dt + np.log(-np.expm1(-dt)))
         elif name.endswith("learnable_skip"):
-            t = torch.ones(shape) + (randn(shape, 0.1) if scheme == "exercise" else 0)
+            t = torch.ones(shape) + (randn(shape, 0.1) if ex else 0)
         elif ("norm" in name and name.endswith(".weight") and "embed_ln" not in name and spec.backbone == "xlstm"
               and not spec.rms_norm) or name.endswith("outnorm.weight") or name.endswith("group_norm.weight"):
             # xlstm LayerNorm stores gamma - 1 (residual weight), default 0
-            t = randn(shape, 0.1) if scheme == "exercise" else torch.zeros(shape)
+            t = randn(shape, 0.1) if ex else torch.zeros(shape)
         elif "norm" in name and name.endswith(".weight") or name == "embed_ln.weight":
-            t = torch.ones(shape) + (randn(shape, 0.1) if scheme == "exercise" else 0)
+            t = torch.ones(shape) + (randn(shape, 0.1) if ex else 0)
         elif name.endswith("_recurrent_kernel_"):
-            t = randn(shape, 1.0 / math.sqrt(shape[1])) if scheme == "exercise" else torch.zeros(shape)
+            t = randn(shape, 1.0 / math.sqrt(shape[1])) if ex else torch.zeros(shape)
         elif name.endswith("slstm_cell._bias_"):
             NH, _, dh = shape
             t = torch.zeros(shape)
@@ -167,7 +184,9 @@ def init_state_dict(spec: ModelSpec, seed: int = 0, scheme: str = "exercise", wi
             ratio = blk / (spec.n_blocks - 1) if spec.n_blocks > 1 else 0.0
             # [3P] powerlaw_blockdependent forget-gate bias (slot 1 = "f")
             t[:, 1, :] = f64(-(-5.0 + 12.0 * (np.arange(dh, dtype=np.float64) / max(dh - 1, 1)) ** (0.3 + 1.3 * ratio)))
-            if scheme == "exercise":
+            if tl:
+                t = t + randn(shape, 0.2)
+            elif ex:
                 t = t * 0.25 + randn(shape, 0.2)
         elif name.endswith("mlstm_cell.fgate.bias"):
             t = torch.linspace(3.0, 6.0, shape[0])
@@ -176,7 +195,8 @@ def init_state_dict(spec: ModelSpec, seed: int = 0, scheme: str = "exercise", wi
         elif name.endswith("mlstm_cell.igate.bias"):
             t = randn(shape, 0.1)
         elif name.endswith("mlstm_cell.igate.weight") or name.endswith("mlstm_cell.fgate.weight"):
-            t = randn(shape, 1.0 / math.sqrt(shape[-1])) if scheme == "exercise" else torch.zeros(shape)
+            k = (TRAINED_LIKE_IGATE if "igate" in name else TRAINED_LIKE_FGATE) if tl else 1.0
+            t = randn(shape, k / math.sqrt(shape[-1])) if ex else torch.zeros(shape)
         elif name.endswith(".bias"):
             t = randn(shape, 0.02 if scheme == "reference" else 0.1)
         elif name in ("embed_return.weight", "embed_rewards.weight"):

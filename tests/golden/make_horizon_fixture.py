@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate tests/golden/horizon_{xlstm16m,mamba48m}[_fp64].npz: the step path at the reference's real episode length.
 
-    python tests/golden/make_horizon_fixture.py [--fp64] [--model xlstm|mamba]     (about 5 + 10 minutes on 8 cores)
+    python tests/golden/make_horizon_fixture.py [--fp64] [--model xlstm|mamba|xlstm206m] [--scheme exercise|reference|trained_like]
+                                                                                    (about 5 + 10 minutes on 8 cores)
 
 The reference loop runs an episode to `done` (src/callbacks/evaluation.py:130-177: DMControl episodes are 1000 steps,
 Meta-World 200) and, unless `reset_inf_cache_freq` fires, never clears the cache in between
@@ -45,11 +46,19 @@ CASES = {
 }
 
 
+SCHEMES = ("exercise", "reference", "trained_like")
+OUTLIER_CHANNEL, OUTLIER_GAIN = 3, 30.0   # scheme "trained_like": one native observation channel carries 30 x the range
+
+
 def case_envs(case):
     return CASES[case].get("envs", B)
 
 
-def horizon_inputs(spec, case):
+def fixture_name(case, scheme="exercise", fp64=False):
+    return CASES[case]["file"] + ("" if scheme == "exercise" else "_" + scheme) + ("_fp64" if fp64 else "") + ".npz"
+
+
+def horizon_inputs(spec, case, scheme="exercise"):
     """obs [steps, B, state_dim] (native dims U(-1,1), rest zero as after pad_inputs), rtg [steps, B], mask [steps, B]."""
     c = CASES[case]
     B = case_envs(case)
@@ -57,6 +66,8 @@ def horizon_inputs(spec, case):
     g = torch.Generator().manual_seed(INPUT_SEED)
     obs = torch.zeros(n, B, spec.state_dim)
     obs[:, :, : c["native"]] = torch.rand(n, B, c["native"], generator=g) * 2 - 1
+    if scheme == "trained_like":
+        obs[:, :, OUTLIER_CHANNEL] *= OUTLIER_GAIN
     mask = torch.zeros(n, B, dtype=torch.uint8)
     mask[0] = 1
     mask[c["episode"], : B // 2] = 1
@@ -94,14 +105,14 @@ def store_state(out, tag, ora, c, fp64):
         out[f"{tag}_b{c['slstm']}_slstm"] = ora.state[f"block_{c['slstm']}"]["slstm_state"].numpy().copy()
 
 
-def main(case, fp64=False):
+def main(case, fp64=False, scheme="exercise"):
     from lram_amd import init_state_dict, preset
     from oracle.dt_ref import OraclePolicy
     torch.set_num_threads(int(os.environ.get("HORIZON_THREADS", os.cpu_count() or 1)))
     c = CASES[case]
     spec = preset(c["preset"])
-    sd = init_state_dict(spec, seed=WEIGHT_SEED)
-    obs, rtg, mask = horizon_inputs(spec, case)
+    sd = init_state_dict(spec, seed=WEIGHT_SEED, scheme=scheme)
+    obs, rtg, mask = horizon_inputs(spec, case, scheme)
     if fp64:
         from tests.helpers import Fp64Oracle
         f64 = Fp64Oracle(spec, sd)
@@ -112,6 +123,7 @@ def main(case, fp64=False):
     zero = torch.zeros(case_envs(case))
     out = {"weight_checksum": np.float64(weight_checksum(sd))}
     m_lo, m_hi = {i: float("inf") for i in c["blocks"]}, {i: float("-inf") for i in c["blocks"]}
+    n_hi = {i: 0.0 for i in c["blocks"]}
     t0 = time.time()
     for t in range(c["episode"] + c["tail"]):
         act, dbg = step(obs[t], rtg[t], zero, mask[t] if mask[t].any() else None, return_debug=True)
@@ -123,6 +135,7 @@ def main(case, fp64=False):
             for i in c["blocks"]:
                 m = ora.state[f"block_{i}"]["mlstm_state"][2]
                 m_lo[i], m_hi[i] = min(m_lo[i], float(m.min())), max(m_hi[i], float(m.max()))
+                n_hi[i] = max(n_hi[i], float(ora.state[f"block_{i}"]["mlstm_state"][1].abs().max()))
         if t + 1 == c["episode"]:
             store_state(out, "ep", ora, c, fp64)
         if t % 20 == 0:
@@ -131,15 +144,18 @@ def main(case, fp64=False):
     if c["preset"].startswith("xlstm"):
         for i in c["blocks"]:
             out[f"m_range_b{i}"] = np.array([m_lo[i], m_hi[i]])
+            out[f"n_absmax_b{i}"] = np.float64(n_hi[i])
     if fp64:   # float64 RESULTS stored as float32 (6e-8 relative, against comparison bars of 2e-4): halves the fixture
         out = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and k != "weight_checksum" else v)
                for k, v in out.items()}
-    name = c["file"] + ("_fp64" if fp64 else "") + ".npz"
+    name = fixture_name(case, scheme, fp64)
     np.savez_compressed(os.path.join(HERE, name), **out)
     print("wrote", name, f"{time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
     which = [sys.argv[sys.argv.index("--model") + 1]] if "--model" in sys.argv else list(CASES)
+    scheme = sys.argv[sys.argv.index("--scheme") + 1] if "--scheme" in sys.argv else "exercise"
+    assert scheme in SCHEMES, scheme
     for w in which:
-        main(w, fp64="--fp64" in sys.argv)
+        main(w, fp64="--fp64" in sys.argv, scheme=scheme)

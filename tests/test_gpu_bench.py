@@ -42,3 +42,34 @@ def test_bench_line_contract_and_physical_roofline(hip_lib, capsys):
     assert out["build_id"] == build.source_hash() and out["build_id_matches_sources"] is True
     assert "cpu_baseline" not in out and "_copy_ceiling_pending" not in out
     capsys.readouterr()
+
+
+def test_bench_config_legs_contract(hip_lib, capsys):
+    """`configs` on the default bench line: BASELINE.json's configurations 2-5 at their per-GPU sizes, each timed on a fresh
+    engine with its own roofline / matrix-core block (bench.config_legs).  Here: the contract of every leg, fractions physical,
+    the reference Mamba trajectory slower than the one-advance-per-step one by about its 4 forwards."""
+    import bench
+    legs = bench.config_legs("cuda:0")
+    assert [l.get("id") for l in legs] == ["C2", "C3", "C3-reference-trajectory", "C4-per-gpu-shard", "C5"], legs
+    for l in legs:
+        assert "error" not in l, l
+        for key in ("workload", "preset", "batch", "steps", "value", "unit", "ms_per_step", "mfma", "leg_wall_s"):
+            assert key in l, (l["id"], key)
+        assert l["value"] > 0 and l["ms_per_step"] > 0 and l["leg_wall_s"] < 60
+        assert 0.0 < l["mfma"]["frac"] <= 1.0 and l["mfma"]["peak"] == 2.5 and l["mfma"]["unit"] == "PFLOP/s"
+        if l["id"] != "C5":
+            assert l["unit"] == "env-steps/s"
+            assert abs(l["value"] - l["batch"] * 1e3 / l["ms_per_step"]) < 1e-6 * l["value"]
+            r = l["roofline"]
+            assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0.0 < r["frac"] <= 1.0
+            assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches_timed"] > 0
+    by = {l["id"]: l for l in legs}
+    assert by["C2"]["state_mode"] == "lazy" and by["C4-per-gpu-shard"]["state_mode"] == "lazy"
+    assert by["C2"]["roofline"]["launches_per_step"] == 14 and by["C4-per-gpu-shard"]["roofline"]["launches_per_step"] == 34
+    ratio = by["C3"]["value"] / by["C3-reference-trajectory"]["value"]
+    assert 3.0 < ratio < 5.0, ratio                  # 4 forwards per env-step on the reference's Meta-World trajectory
+    c5 = by["C5"]
+    assert c5["unit"] == "env-timesteps/s" and c5["context_timesteps"] == 512 and c5["batch"] == 64
+    assert abs(c5["value"] - 64 * 512 * 1e3 / c5["ms_per_step"]) < 1e-6 * c5["value"]
+    assert c5["decode"]["steps"] == 16 and c5["decode"]["value"] > 0
+    capsys.readouterr()

@@ -18,7 +18,8 @@ import pytest
 import torch
 
 from lram_amd import init_state_dict, preset
-from tests.golden.make_horizon_fixture import CASES, SSM_ENVS, WEIGHT_SEED, case_envs, horizon_inputs, probe, weight_checksum
+from tests.golden.make_horizon_fixture import (CASES, SCHEMES, SSM_ENVS, WEIGHT_SEED, case_envs, fixture_name, horizon_inputs,
+                                               probe, weight_checksum)
 from tests.helpers import (assert_actions_match, assert_close_or_as_close_as_fp32_oracle, rel_err, relaxed_rows_fraction,
                            relaxed_rows_reset)
 
@@ -27,10 +28,10 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 REPORT = {}
 
 
-def _fixtures(case):
+def _fixtures(case, scheme="exercise"):
     c = CASES[case]
-    fx = np.load(os.path.join(GOLD, c["file"] + ".npz"))
-    fx64 = np.load(os.path.join(GOLD, c["file"] + "_fp64.npz"))
+    fx = np.load(os.path.join(GOLD, fixture_name(case, scheme)))
+    fx64 = np.load(os.path.join(GOLD, fixture_name(case, scheme, fp64=True)))
     assert abs(float(fx64["weight_checksum"]) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"])
     return c, fx, fx64
 
@@ -54,17 +55,18 @@ def _write_report():
         print("[report] horizon:", json.dumps(REPORT, sort_keys=True))
 
 
-def _run_xlstm(mode, slots, where, case="xlstm"):
-    """Drive lram_step over the fixture trajectory of `case`.  `where`: slot index of each fixture env."""
+def _run_xlstm(mode, slots, where, case="xlstm", scheme="exercise"):
+    """Drive lram_step over the fixture trajectory of `case` on the weight distribution `scheme`.  `where`: slot index of each
+    fixture env."""
     from lram_amd.engine import Engine
-    c, fx, fx64 = _fixtures(case)
+    c, fx, fx64 = _fixtures(case, scheme)
     FB = case_envs(case)
     close = _closer(fx, fx64)
     spec = preset(c["preset"])
-    sd = init_state_dict(spec, seed=WEIGHT_SEED)
+    sd = init_state_dict(spec, seed=WEIGHT_SEED, scheme=scheme)
     assert abs(weight_checksum(sd) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"]), \
         "seeded weights differ from the ones the fixture was computed with"
-    obs, rtg, mask = horizon_inputs(spec, case)
+    obs, rtg, mask = horizon_inputs(spec, case, scheme)
     n_steps = obs.shape[0]
     eng = Engine(spec, sd, slots, device="cuda:0")
     if mode is not None:
@@ -81,10 +83,13 @@ def _run_xlstm(mode, slots, where, case="xlstm"):
     relaxed_rows_reset()
     ties = 0
     g_lo, m_lo, m_hi, pend_hi = float("inf"), float("inf"), float("-inf"), 0
-    name = f"{c['preset']}_{mode or 'auto'}_{slots}"
+    name = f"{c['preset']}_{mode or 'auto'}_{slots}" + ("" if scheme == "exercise" else "_" + scheme)
+    n_hi = 0.0
     for t in range(n_steps):
         if slots > FB:   # background traffic: random observations, restarts about every 300 steps, own rtg schedule
             d_obs[:, :c["native"]] = torch.rand(slots, c["native"], generator=g, device="cuda") * 2 - 1
+            if scheme == "trained_like":   # the background traffic carries the outlier channel too
+                d_obs[:, 3] *= 30.0
             d_mask.copy_((torch.rand(slots, generator=g, device="cuda") < (1.0 if t == 0 else 0.0033)).to(torch.uint8))
             d_rtg.copy_(torch.where(d_mask.bool(), torch.full_like(d_rtg, c["rtg0"]), d_rtg - c["drtg"]))
         d_obs[where] = d_obs_all[t]
@@ -116,16 +121,20 @@ def _run_xlstm(mode, slots, where, case="xlstm"):
                 close(cm @ r, f"{tag}_b{i}_Cr", f"{name} {tag} block {i} C r")
                 close(r @ cm, f"{tag}_b{i}_rC", f"{name} {tag} block {i} r C")
                 close(cm.abs().amax(dim=(-1, -2)), f"{tag}_b{i}_Cabsmax", f"{name} {tag} block {i} max |C|")
-                close(eng.export_state_tensor(i, 1)[where].squeeze(-1), f"{tag}_b{i}_n", f"{name} {tag} block {i} n")
+                nn = eng.export_state_tensor(i, 1)[where].squeeze(-1)
+                n_hi = max(n_hi, float(nn.abs().max()))
+                close(nn, f"{tag}_b{i}_n", f"{name} {tag} block {i} n")
                 assert rel_err(eng.export_state_tensor(i, 2)[where], fx[f"{tag}_b{i}_m"]) < 1e-4, (tag, i)
                 close(eng.export_state_tensor(i, 3)[where], f"{tag}_b{i}_conv", f"{name} {tag} block {i} conv")
             close(eng.export_state_tensor(c["slstm"], 0)[:, where], f"{tag}_b{c['slstm']}_slstm", f"{name} {tag} sLSTM state")
     frac = relaxed_rows_fraction()
     REPORT[name] = {"steps": n_steps, "action_ties_below_2e-4": ties, "rows_on_the_float64_rule": round(frac, 4),
                     "oracle_m_range": {f"b{i}": [float(x) for x in fx[f"m_range_b{i}"]] for i in c["blocks"]}}
+    if f"n_absmax_b{c['blocks'][0]}" in fx.files:
+        REPORT[name]["oracle_n_absmax"] = {f"b{i}": float(fx[f"n_absmax_b{i}"]) for i in c["blocks"]}
     if lazy:
         REPORT[name].update({"engine_m_min": m_lo, "engine_m_max": m_hi, "g_min_between_folds": g_lo,
-                             "max_pending_window_tokens": pend_hi})
+                             "max_pending_window_tokens": pend_hi, "engine_n_absmax_at_the_state_marks": n_hi})
         assert g_lo > 0.0, "the scale of C_base underflowed between folds"
     _write_report()
     assert frac <= 0.05, frac
@@ -133,33 +142,41 @@ def _run_xlstm(mode, slots, where, case="xlstm"):
     torch.cuda.empty_cache()
 
 
+# The weight distributions (lram_amd/weights.py::init_state_dict): "exercise" = every term busy, forgets within tens of steps;
+# "reference" = a freshly built reference model (src/algos/models/decision_xlstm.py:170-171,210-213); "trained_like" = the
+# long-memory corner of a loaded checkpoint (src/algos/decision_transformer_sb3.py:1120-1184): f ~ 0.95-0.998, input-gate
+# pre-activations of +-15 (m far outside [-8, 8]), one observation channel 30 x the others.
+@pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("mode", ["lazy", "eager"])
-def test_xlstm_16m_1000_step_episode_vs_oracle_fixture(hip_lib, mode):
-    _run_xlstm(mode, case_envs("xlstm"), list(range(case_envs("xlstm"))))
+def test_xlstm_16m_1000_step_episode_vs_oracle_fixture(hip_lib, mode, scheme):
+    _run_xlstm(mode, case_envs("xlstm"), list(range(case_envs("xlstm"))), scheme=scheme)
 
 
-def test_xlstm_16m_1000_step_episode_inside_the_headline_batch(hip_lib):
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_xlstm_16m_1000_step_episode_inside_the_headline_batch(hip_lib, scheme):
     """4096 slots, default modes (lazy, two slices, multi-env front end, fused group norm, pre-split projections): the
     fixture's envs sit at both ends of both slices and in the middle; their fold phases (slot % 13) differ."""
-    _run_xlstm(None, 4096, [0, 1, 2047, 2048, 2049, 3000, 4094, 4095])
+    _run_xlstm(None, 4096, [0, 1, 2047, 2048, 2049, 3000, 4094, 4095], scheme=scheme)
 
 
+@pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("slots,where", [(4, [0, 1, 2, 3]), (512, [0, 255, 256, 511])])
-def test_xlstm_206m_200_step_episode_vs_oracle_fixture(hip_lib, slots, where):
+def test_xlstm_206m_200_step_episode_vs_oracle_fixture(hip_lib, slots, where, scheme):
     """The 206M geometry (20 blocks, head dim 640: per-env front end, score kernel, several column slices per head in the read
     pass, sLSTM head dim 320) over a Meta-World-length episode: lazy at 4 slots, and the C4 per-GPU batch -- 512 slots, two
     slices -- with the fixture's envs at both ends of both slices."""
-    _run_xlstm("lazy" if slots == 4 else None, slots, where, case="xlstm206m")
+    _run_xlstm("lazy" if slots == 4 else None, slots, where, case="xlstm206m", scheme=scheme)
 
 
-def test_mamba_48m_200_step_episode_vs_oracle_fixture(hip_lib):
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_mamba_48m_200_step_episode_vs_oracle_fixture(hip_lib, scheme):
     from lram_amd.engine import Engine
-    c, fx, fx64 = _fixtures("mamba")
+    c, fx, fx64 = _fixtures("mamba", scheme)
     close = _closer(fx, fx64)
     spec = preset(c["preset"])
-    sd = init_state_dict(spec, seed=WEIGHT_SEED)
+    sd = init_state_dict(spec, seed=WEIGHT_SEED, scheme=scheme)
     assert abs(weight_checksum(sd) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"])
-    obs, rtg, mask = horizon_inputs(spec, "mamba")
+    obs, rtg, mask = horizon_inputs(spec, "mamba", scheme)
     FB = case_envs("mamba")
     for slots, where in ((FB, list(range(FB))), (2048, [0, 1, 1023, 1024, 1025, 1500, 2046, 2047])):
         eng = Engine(spec, sd, slots, device="cuda:0")
@@ -171,10 +188,12 @@ def test_mamba_48m_200_step_episode_vs_oracle_fixture(hip_lib):
         d_mask = torch.zeros(slots, dtype=torch.uint8, device="cuda")
         relaxed_rows_reset()
         ties = 0
-        name = f"mamba48m_{slots}"
+        name = f"mamba48m_{slots}" + ("" if scheme == "exercise" else "_" + scheme)
         for t in range(obs.shape[0]):
             if slots > FB:
                 d_obs[:, :39] = torch.rand(slots, 39, generator=g, device="cuda") * 2 - 1
+                if scheme == "trained_like":
+                    d_obs[:, 3] *= 30.0
                 d_mask.copy_((torch.rand(slots, generator=g, device="cuda") < (1.0 if t == 0 else 0.01)).to(torch.uint8))
                 d_rtg.copy_(torch.where(d_mask.bool(), torch.full_like(d_rtg, 6.5), d_rtg - 0.02))
             d_obs[idx], d_rtg[idx], d_mask[idx] = obs[t].cuda(), rtg[t].cuda(), mask[t].cuda()

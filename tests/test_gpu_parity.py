@@ -217,12 +217,14 @@ def test_gemm_tile_order_is_a_bijection_on_the_device(hip_lib, monkeypatch, pane
 
 
 def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=2e-4, state_tol=2e-4, spec=None,
-                sd=None, cond_aware=False):
-    """cond_aware: where the engine is further than the tolerance from the fp32 oracle, accept it if it is as close to
+                sd=None, cond_aware=False, scheme="exercise", reset_prob=0.15, obs_gain=None):
+    """scheme: weight distribution (lram_amd/weights.py::init_state_dict); reset_prob: per-env, per-step restart probability;
+    obs_gain: (channel, factor) scales one observation channel (un-normalised outlier).
+    cond_aware: where the engine is further than the tolerance from the fp32 oracle, accept it if it is as close to
     the float64 evaluation as the fp32 oracle itself is (tests/helpers.py::Fp64Oracle) -- deep stacks meet inputs that
     are ill-conditioned for any fp32 evaluation."""
     spec = preset(name) if spec is None else spec
-    sd = init_state_dict(spec, seed=seed) if sd is None else sd
+    sd = init_state_dict(spec, seed=seed, scheme=scheme) if sd is None else sd
     eng = _engine(spec, sd, B)
     if graph:
         eng.set_graph_mode(True)
@@ -236,7 +238,9 @@ def _run_parity(name, B, steps, seed=0, discrete=False, graph=False, hidden_tol=
     d_rtg = torch.empty(B, device="cuda:0")
     d_rew = torch.empty(B, device="cuda:0")
     d_mask = torch.empty(B, dtype=torch.uint8, device="cuda:0")
-    for t, (obs, rtg, rew, mask) in enumerate(make_inputs(spec, B, steps, seed=1234 + seed)):
+    for t, (obs, rtg, rew, mask) in enumerate(make_inputs(spec, B, steps, seed=1234 + seed, reset_prob=reset_prob)):
+        if obs_gain is not None:
+            obs[:, obs_gain[0]] *= obs_gain[1]
         d_obs.copy_(obs), d_rtg.copy_(rtg), d_rew.copy_(rew), d_mask.copy_(mask)
         a_gpu, tok = eng.step(d_obs, d_rtg, d_rew, d_mask, discrete=discrete)
         a_ref, dbg = ora.step(obs, rtg, rew, mask, discrete=discrete, return_debug=True)
@@ -396,6 +400,20 @@ def test_mamba_48m_shapes(hip_lib):
     assert _run_parity("mamba_48m", B=6, steps=4) == 0
 
 
+@pytest.mark.parametrize("scheme", ["reference", "trained_like"])
+@pytest.mark.parametrize("name,B,steps", [("xlstm_16m", 12, 40), ("mamba_48m", 6, 24)])
+def test_weight_distributions_the_reference_actually_runs(hip_lib, scheme, name, B, steps):
+    """Live oracle parity on the two weight distributions every other test leaves out (they all use scheme="exercise", which
+    forgets within tens of steps): "reference" = what `post_init -> reset_parameters` leaves in a freshly built model
+    (src/algos/models/decision_xlstm.py:170-171,210-213: mLSTM forget bias linspace(3, 6), zero gate weights, R = 0, N(0, 0.02)
+    projections; Mamba A_log = log(1..16), dt bias from log-uniform [1e-3, 1e-1]); "trained_like" = the long-memory corner of a
+    loaded checkpoint (src/algos/decision_transformer_sb3.py:1120-1184): f ~ 0.95-0.998, input-gate pre-activations of +-15,
+    one observation channel 30 x the rest, Mamba dt bias at both ends of its range, A_log up to log 16 + 2.  Few resets, so
+    the state integrates (the 1000-step horizon on these distributions: tests/test_gpu_horizon.py)."""
+    gain = (3, 30.0) if scheme == "trained_like" else None
+    assert _run_parity(name, B=B, steps=steps, scheme=scheme, reset_prob=0.03, obs_gain=gain, cond_aware=True) == 0
+
+
 @pytest.mark.parametrize("B", [77, 130])
 def test_mamba_lane_state_update_at_ragged_env_counts(hip_lib, B):
     """From 64 env slots Mamba-48M's selective state update runs lane = channel (mamba_ssm_lane_kernel: 8 env slots per wave,
@@ -547,6 +565,80 @@ def test_state_import_export_roundtrip_and_reset(hip_lib):
             for t in (val if isinstance(val, tuple) else (val,)):
                 rows = t[:, [0, 2]] if key == "slstm_state" else t[[0, 2]]
                 assert float(rows.abs().max()) == 0.0
+    eng.close()
+
+
+def test_slstm_hidden_plane_import_is_range_checked(hip_lib, monkeypatch):
+    """The f16x2 form of the sLSTM step keeps h in LDS as binary16 planes of 2^12 h (fine for |h| < 1, which is all the
+    recurrence produces): lram_state_import refuses a foreign hidden plane with |h| >= 16 or NaN where that form is active,
+    accepts it where the exact-fp32 recurrence runs (LRAM_SLSTM_SEQ=2), and always accepts what an engine exported."""
+    from lram_amd.engine import Engine, LramError
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=0)
+    B = 1024                                   # (f16x2 projections, hence the f16x2 step form, from 1024 operand rows)
+    eng = Engine(spec, sd, B, device="cuda:0")
+    for obs, rtg, rew, mask in make_inputs(spec, B, 2):
+        eng.step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+    blk = spec.slstm_at[0]
+    good = eng.export_state_tensor(blk, 0).clone()
+    assert float(good[0].abs().max()) < 1.0
+    eng.import_state_tensor(blk, 0, good)      # what the model produced: fine
+    for poison in (20.0, float("nan")):
+        bad = good.clone()
+        bad[0, 17, 5] = poison
+        with pytest.raises(LramError, match="sLSTM hidden plane"):
+            eng.import_state_tensor(blk, 0, bad)
+    bad = good.clone()
+    bad[1, 17, 5] = 1e6                        # the c / n / m planes stay fp32 in registers: no limit on them
+    eng.import_state_tensor(blk, 0, bad)
+    eng.close()
+    monkeypatch.setenv("LRAM_SLSTM_SEQ", "2")  # exact-fp32 recurrence: no range limit, no check
+    eng = Engine(spec, sd, B, device="cuda:0")
+    bad = good.clone()
+    bad[0, 17, 5] = 20.0
+    eng.import_state_tensor(blk, 0, bad)
+    a, _ = eng.step(*[v.cuda() for v in make_inputs(spec, B, 1)[0][:3]], None)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(a).all())
+    eng.close()
+
+
+def test_sampled_profile_counts_every_entry_point(hip_lib):
+    """lram_profile_begin_sampled(n): every public entry that launches the stack (lram_step, lram_prefill, lram_encoder_step) is
+    one call of the sample, timed or not by ITS position -- not by whatever lram_step ran before it."""
+    from lram_amd.engine import Engine
+    spec = preset("xlstm_tiny")
+    sd = init_state_dict(spec, seed=0)
+    B = 8
+    eng = Engine(spec, sd, B, device="cuda:0")
+    n_rec = spec.n_blocks - len(spec.slstm_at)
+    obs, rtg, rew, _ = [v.cuda() if v is not None else None for v in make_inputs(spec, B, 1)[0]]
+    x = torch.randn(B, 1, spec.d_model, device="cuda:0")
+    seq = (obs.unsqueeze(1).repeat(1, 2, 1).contiguous(), rtg.unsqueeze(1).repeat(1, 2).contiguous(),
+           rew.unsqueeze(1).repeat(1, 2).contiguous())
+    def launches(fn):
+        eng.profile_begin()
+        fn()
+        torch.cuda.synchronize()
+        return eng.profile_end_split()[1]
+
+    n_step, n_enc, n_pre = launches(lambda: eng.step(obs, rtg, rew, None)), launches(lambda: eng.encoder_step(x)), \
+        launches(lambda: eng.prefill(*seq))
+    assert min(n_step, n_enc, n_pre) >= n_rec
+    eng.profile_begin_sampled(2)
+    eng.step(obs, rtg, rew, None)          # call 0: timed
+    eng.encoder_step(x)                    # call 1: not timed
+    eng.encoder_step(x)                    # call 2: timed
+    eng.step(obs, rtg, rew, None)          # call 3: not timed
+    eng.prefill(*seq)                      # call 4: timed
+    torch.cuda.synchronize()
+    _, n_main, _, _ = eng.profile_end_split()
+    assert n_main == n_step + n_enc + n_pre, (n_main, n_step, n_enc, n_pre)
+    eng.profile_begin_sampled(2)
+    eng.encoder_step(x)                    # call 0 of a new sample: timed, whatever the last step of the old one was
+    torch.cuda.synchronize()
+    _, n_one, _, _ = eng.profile_end_split()
+    assert n_one > 0
     eng.close()
 
 

@@ -207,3 +207,24 @@ def test_c2_16m_at_1024_slots_30_lazy_steps(hip_lib):
         for j in range(3):
             assert rel_err(base["state"][(i, j)][sample], want[j]) < 2e-4, (i, j)
     assert rel_err(base["state"][(1, 0)][:, sample], ora.state["block_1"]["slstm_state"]) < 2e-4
+
+
+@pytest.mark.parametrize("gn_fuse", ["0", None])
+def test_group_norm_row_maxima_handover_is_bit_identical(hip_lib, monkeypatch, gn_fuse):
+    """proj_down's operand row maxima come from the output group norm's waves as NH partial maxima per row (round 5) instead of a
+    row-maximum launch of their own (LRAM_GN_AMAX=0): a maximum of partial maxima is exact, so the two forms must agree bit for
+    bit -- 16M at 1024 slots (f16x2 projections, two 512-slot slices), with the group norm un-fused (LRAM_GN_FUSE=0: every block
+    takes the hand-over) and in the default form."""
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=0)
+    seq = _inputs(spec, 1024, 4, seed=77)
+    if gn_fuse is not None:
+        monkeypatch.setenv("LRAM_GN_FUSE", gn_fuse)
+    keys = [(0, 0), (6, 1)]
+    monkeypatch.delenv("LRAM_GN_AMAX", raising=False)
+    a = _run(spec, sd, seq, want_state=keys)
+    monkeypatch.setenv("LRAM_GN_AMAX", "0")
+    b = _run(spec, sd, seq, want_state=keys)
+    assert torch.equal(a["acts"], b["acts"]) and torch.equal(a["hidden"], b["hidden"]) and torch.equal(a["logits"], b["logits"])
+    for k in keys:
+        assert torch.equal(a["state"][k], b["state"][k]), k

@@ -9,21 +9,24 @@ import torch
 
 from lram_amd import init_state_dict, preset
 from oracle.dt_ref import OraclePolicy
-from tests.golden.make_horizon_fixture import CASES, SSM_ENVS, WEIGHT_SEED, case_envs, horizon_inputs, weight_checksum
+from tests.golden.make_horizon_fixture import (CASES, SCHEMES, SSM_ENVS, WEIGHT_SEED, case_envs, fixture_name, horizon_inputs,
+                                               weight_checksum)
+from tests.helpers import assert_actions_match
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+@pytest.mark.parametrize("scheme", SCHEMES)
 @pytest.mark.parametrize("case", ["xlstm", "mamba", "xlstm206m"])
-def test_horizon_fixture_is_what_the_oracle_computes(case):
+def test_horizon_fixture_is_what_the_oracle_computes(case, scheme):
     c = CASES[case]
     B = case_envs(case)
-    fx = np.load(os.path.join(GOLD, c["file"] + ".npz"))
-    fx64 = np.load(os.path.join(GOLD, c["file"] + "_fp64.npz"))
+    fx = np.load(os.path.join(GOLD, fixture_name(case, scheme)))
+    fx64 = np.load(os.path.join(GOLD, fixture_name(case, scheme, fp64=True)))
     spec = preset(c["preset"])
-    sd = init_state_dict(spec, seed=WEIGHT_SEED)
+    sd = init_state_dict(spec, seed=WEIGHT_SEED, scheme=scheme)
     assert abs(weight_checksum(sd) - float(fx["weight_checksum"])) <= 1e-9 * float(fx["weight_checksum"])
-    obs, rtg, mask = horizon_inputs(spec, case)
+    obs, rtg, mask = horizon_inputs(spec, case, scheme)
     assert obs.shape[0] == c["episode"] + c["tail"] and int(mask.sum()) == B + B // 2
     assert bool((rtg[c["episode"], : B // 2] == c["rtg0"]).all()) and bool((rtg[c["episode"], B // 2:] < rtg[0, 0]).all())
     ora = OraclePolicy(spec, sd)
@@ -32,8 +35,12 @@ def test_horizon_fixture_is_what_the_oracle_computes(case):
     for t in range(10 if case != "xlstm206m" else 1):   # (206M: ~1 s per oracle step)
         act, dbg = ora.step(obs[t], rtg[t], torch.zeros(B), mask[t] if mask[t].any() else None, return_debug=True)
         if t + 1 in (1, 10):
-            np.testing.assert_allclose(dbg["logits"].numpy(), fx[f"logits_{t + 1}"], rtol=0, atol=2e-6)
-            assert np.array_equal(act.numpy(), fx[f"actions_{t + 1}"])
+            scale = max(1.0, float(np.abs(fx[f"logits_{t + 1}"]).max()))
+            np.testing.assert_allclose(dbg["logits"].numpy(), fx[f"logits_{t + 1}"], rtol=0, atol=2e-6 * scale)
+            # (through the tie rule: a host with another core count sums its matmuls in another order, and an action whose
+            # top-2 logits sit within 2e-4 of each other may then legitimately flip)
+            assert_actions_match(act, torch.from_numpy(fx[f"actions_{t + 1}"]), torch.from_numpy(fx[f"logits_{t + 1}"]), spec,
+                                 what=f"{case} {scheme} step {t + 1}")
     for s in c["marks"]:
         for k in ("actions", "logits", "hidden"):
             assert f"{k}_{s}" in fx.files and f"{k}_{s}" in fx64.files
@@ -51,3 +58,5 @@ def test_horizon_fixture_is_what_the_oracle_computes(case):
     else:
         lo, hi = fx[f"m_range_b{c['blocks'][0]}"]
         assert np.isfinite(lo) and np.isfinite(hi) and lo < hi
+        if scheme == "trained_like":   # the regime the scheme exists for: the stabiliser leaves [-8, 8]
+            assert max(float(np.abs(fx[f"m_range_b{i}"]).max()) for i in c["blocks"]) > 8.0
