@@ -111,7 +111,7 @@ struct GemmArgs {
 // another host thread) -- and again only where an engine is created (lram_create, like every other knob) or a standalone test /
 // micro-benchmark entry (lram_gemm_*) starts: that is how the bit-identity tests walk through tiles, stages and tile orders.
 struct GemmKnobs {
-  int tile = 0;          // 64 / 128: force the workgroup tile height of the f16x2 kernels
+  int tile = 0;          // 64 / 128: force the workgroup tile height of the f16x2 kernels; 256: the 8-phase 256 x 256 kernel; -1: never it
   int stages = 0;        // 1 / 2: force the LDS stage count of the pre-split kernel
   int panel = 0;         // > 0: force the column-panel tile order with that width
   int splitk_tiles = 56; // outputs with fewer 128 x 128 tiles than this are split along K
@@ -163,6 +163,8 @@ bool gemm_f16x2_supported(const GemmArgs& g);
 void launch_gemm_f16x2(const GemmArgs& g, hipStream_t stream);    // fp32-accurate, 2 x f16 split operands, row-scaled
 bool gemm_f16x2p_supported(const GemmArgs& g);
 void launch_gemm_f16x2p(const GemmArgs& g, hipStream_t stream);   // the same with A pre-split too: DMA staging, MFMA-only loop
+bool gemm_f16x2_8p_supported(const GemmArgs& g);
+void launch_gemm_f16x2_8p(const GemmArgs& g, hipStream_t stream); // ... as 256 x 256 tiles, 8 staggered waves, counted DMA waits (gemm_f16x2_8p.hip)
 // planes[0 / 1] (K-tile-major: (r, k) at (k / 32) * kt + r * 32 + k % 32; `plane` elements apart) = hi / lo of
 // scale_r * a[r][k] (* gate[r][k]), inv[r] = 1 / scale_r
 void launch_row_split_f16x2(const float* a, int64_t lda, const float* gate, int64_t ldg, int rows, int k, uint16_t* planes,
@@ -403,6 +405,7 @@ struct SlstmSeqArgs {
   float* yout = nullptr;         // [B*T, H]
   int B = 0, T = 0, H = 0, NH = 0, state_B = 0;
 };
+void launch_slstm_h_range(const float* h, int64_t n, float limit, int* flag, hipStream_t stream);  // flag |= any element outside (-limit, limit), NaN included
 bool slstm_seq_supported(int H, int NH, int T);
 void launch_slstm_seq(const SlstmSeqArgs& a, hipStream_t stream);
 void launch_slstm_pack_rt(const float* rt, float* rt2, int NH, int SDH, hipStream_t stream);  // rt: [NH, 4, out, in]

@@ -1898,26 +1898,26 @@ int32_t lram_state_import(lram_engine* e, int32_t block, int32_t which, const fl
     if (slstm && which == 0 && e->slstm_rinv[block].p != nullptr) {
       // The f16x2 form of the sLSTM step (slstm_seq16_kernel) keeps h_t in LDS as two binary16 planes of 2^12 h: every state the
       // recurrence itself produces has |h| < 1, a foreign one need not (|h| >= 16 overflows binary16 to inf and the next step
-      // spreads NaN).  A rare call: one row-maximum launch over the h plane [B, D] and a host synchronisation are affordable.
+      // spreads NaN).  A rare call: one small reduction over the h plane [B, D] and a host synchronisation are affordable.
       LRAM_HIP_CHECK(hipSetDevice(e->device));
-      const int B = e->B, D = e->cfg.d_model;
-      float* dmax = nullptr;
-      LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dmax), (size_t)B * sizeof(float)));
-      std::vector<float> hmax((size_t)B);
+      const int64_t n = (int64_t)e->B * e->cfg.d_model;   // plane 0 of [4, B, D]
+      int* dflag = nullptr;
+      int hflag = 0;
+      LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&dflag), sizeof(int)));
       try {
-        launch_row_amax(dev_src, D, nullptr, 0, B, D, dmax, s);
-        LRAM_HIP_CHECK(hipMemcpyAsync(hmax.data(), dmax, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, s));
+        LRAM_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), s));
+        launch_slstm_h_range(dev_src, n, 15.9f, dflag, s);
+        LRAM_HIP_CHECK(hipMemcpyAsync(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost, s));
         LRAM_HIP_CHECK(hipStreamSynchronize(s));
       } catch (...) {
-        (void)hipFree(dmax);
+        (void)hipFree(dflag);
         throw;
       }
-      (void)hipFree(dmax);
-      for (int b = 0; b < B; ++b)
-        LRAM_REQUIRE(hmax[(size_t)b] < 15.9f,   // (a NaN row fails the comparison too)
-                     "lram_state_import: sLSTM hidden plane holds |h| >= 16 (or NaN): outside what the recurrence produces (|h| < 1) "
-                     "and outside the binary16 planes of the f16x2 step kernel; import a state the model produced, or run the "
-                     "engine with LRAM_SLSTM_SEQ=2 / LRAM_GEMM=f32 (exact fp32 recurrence, no range limit)");
+      (void)hipFree(dflag);
+      LRAM_REQUIRE(hflag == 0,
+                   "lram_state_import: sLSTM hidden plane holds |h| >= 16 (or NaN): outside what the recurrence produces (|h| < 1) "
+                   "and outside the binary16 planes of the f16x2 step kernel; import a state the model produced, or run the "
+                   "engine with LRAM_SLSTM_SEQ=2 / LRAM_GEMM=f32 (exact fp32 recurrence, no range limit)");
     }
     lazy_materialize(e, s);
     LRAM_HIP_CHECK(hipMemcpyAsync(v.p, dev_src, v.n * sizeof(float), hipMemcpyDeviceToDevice, s));

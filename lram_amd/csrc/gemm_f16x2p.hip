@@ -352,6 +352,19 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
   g.mfma_prio = 1;
   LRAM_REQUIRE(g.m > 0 && g.n > 0 && g.k > 0, "gemm: empty problem");
   LRAM_REQUIRE(gemm_f16x2p_supported(g), "gemm f16x2 (pre-split operands): unsupported operand layout");
+  // The 8-phase 256 x 256 kernel (gemm_f16x2_8p.hip; bit-identical results) where it is faster: launches of several rounds of
+  // 256 x 256 tiles with a deep K -- one workgroup per CU exposes its prologue and its 256 KB epilogue (2 + 10 us per round,
+  // HBM-write-bound when every CU stores at once), so it wins from ~4 rounds on: C5's proj_up 16128 x 5120 x 1280 567 -> 509 us,
+  // 24576 x 2048 x 512 155 -> 147; everything a step launches is 0.6-1.0 x (profiles/r06_gemm_8phase_durations.txt).
+  // LRAM_GEMM_TILE=256 forces it (tests, measurements), -1 keeps it off.
+  {
+    const int force = gemm_knobs().tile;
+    const long t256 = (long)((g.m + 255) / 256) * ((g.n + 255) / 256);
+    if (force == 256 || (force == 0 && t256 >= 700 && g.k >= 512 && g.n >= 1024)) {
+      launch_gemm_f16x2_8p(g_in, stream);
+      return;
+    }
+  }
   int S = 1;
   if (g.act_silu_from >= 0)
     g.split_k = 1, g.k_tiles_per_split = 0;  // output activation: K unsplit

@@ -25,6 +25,8 @@
 // Arithmetic: products and sums in fp32 exactly as an fma chain per lane half, the two halves added inside the matrix
 // instruction; the gate pre-activations differ from the GEMM path's (bf16x3, different summation order) by fp32 rounding.
 // Reference call site: xLSTMBlockStack.step -> sLSTMLayer.step (src/algos/models/decision_xlstm.py:155-166).
+#include <algorithm>
+
 #include "common.h"
 #include "device_math.h"
 
@@ -350,6 +352,19 @@ __global__ __launch_bounds__(2 * kSDH, kSDH <= 128 ? 2 : 1) void slstm_seq16_ker
     }
 }
 }  // namespace
+
+// flag != 0 when an element of h[n] is NOT inside (-limit, limit) -- NaN included (`!(|v| < limit)`; a maximum would drop NaNs)
+__global__ __launch_bounds__(256) void slstm_h_range_kernel(const float* h, int64_t n, float limit, int* flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= !(fabsf(h[i]) < limit);
+  if (bad) atomicOr(flag, 1);
+}
+
+void launch_slstm_h_range(const float* h, int64_t n, float limit, int* flag, hipStream_t stream) {
+  const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(slstm_h_range_kernel, dim3(blocks), dim3(256), 0, stream, h, n, limit, flag);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
 
 bool slstm_seq_supported(int H, int NH, int T) {
   if (NH <= 0 || H % NH != 0 || T < 1 || T > 4) return false;

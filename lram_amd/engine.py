@@ -440,6 +440,17 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
     """out[M,N] = a[M,K] @ w[N,K]^T (+ bias) (+ out) through the library's fp32-MFMA kernel (kernel="f32") or the
     bf16x3 kernel (kernel="bf16x3") the engine uses for its projections."""
     lib = load_library()
+    if kernel == "f16x2p8":   # the pre-split entry with the 8-phase 256 x 256 kernel forced (the entry re-reads the launch knobs)
+        import os
+        old = os.environ.get("LRAM_GEMM_TILE")
+        os.environ["LRAM_GEMM_TILE"] = "256"
+        try:
+            return gemm_f32(a, w, bias, out, accumulate, "f16x2p")
+        finally:
+            if old is None:
+                del os.environ["LRAM_GEMM_TILE"]
+            else:
+                os.environ["LRAM_GEMM_TILE"] = old
     fn = {"f32": lib.lram_gemm_f32, "bf16x3": lib.lram_gemm_bf16x3, 
           "f16x2": lib.lram_gemm_f16x2, "f16x2p": lib.lram_gemm_f16x2_presplit, "skinny": lib.lram_gemm_skinny}[kernel]
     M, K = a.shape

@@ -100,7 +100,7 @@ def relaxed_rows_fraction():
     return RELAXED_ROWS["relaxed"] / max(1, RELAXED_ROWS["rows"])
 
 
-def assert_close_or_as_close_as_fp32_oracle(got, ref32, ref64, tol=2e-4, factor=8.0, cap=5e-3, what=""):
+def assert_close_or_as_close_as_fp32_oracle(got, ref32, ref64, tol=2e-4, factor=8.0, cap=5e-3, what="", pooled=False):
     """|got - ref32| <= tol * scale, or -- per row of the last axis -- got is within `factor` x the fp32 oracle's own
     distance from the fp64 result AND within `cap` * scale of it in absolute terms (the escape hatch is for
     ill-conditioned rows, not for regressions: however far the fp32 oracle itself drifts, the engine may not be further
@@ -112,7 +112,8 @@ def assert_close_or_as_close_as_fp32_oracle(got, ref32, ref64, tol=2e-4, factor=
     err_oracle = (ref32 - ref64).abs().amax(dim=-1)
     direct = (got - ref32).abs().amax(dim=-1)
     strict = direct <= tol * scale
-    relaxed = (err_engine <= torch.clamp(factor * err_oracle, max=cap * scale)) & ~strict
+    floor = err_oracle.max() if pooled else err_oracle
+    relaxed = (err_engine <= torch.clamp(factor * torch.maximum(err_oracle, floor), max=cap * scale)) & ~strict
     RELAXED_ROWS["rows"] += strict.numel()
     RELAXED_ROWS["relaxed"] += int(relaxed.sum())
     ok = strict | relaxed
