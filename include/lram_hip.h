@@ -258,6 +258,14 @@ int32_t lram_gemm_bf16x3(const float* dev_a, int64_t lda, const float* dev_w, in
 int32_t lram_gemm_skinny(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                          int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                          int32_t k, void* stream);
+/* Same contract through the narrow-output kernel (gemm_narrow.hip: 16 rows x all n <= 96 columns per workgroup, exact fp32 matrix
+ * instruction, A staged coalesced through LDS, W packed in fragment order; the engine takes it for Mamba's x_proj --
+ * mamba_ssm.Mamba.x_proj, reached from src/algos/models/decision_mamba.py:130-147 -- from 256 operand rows).  W contiguous
+ * [n, k], k a multiple of 64 and >= 256, lda a multiple of 4, accumulate must be 0.  Packs W into a temporary and synchronises
+ * the stream: test / micro-benchmark entry. */
+int32_t lram_gemm_narrow(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
+                         int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
+                         int32_t k, void* stream);
 /* Same contract through the f16x2 kernel (each fp32 operand row scaled by a power of two and split into two binary16
  * pieces, three f16 MFMA products accumulated in fp32, exact un-scaling: fp32-level accuracy at half the matrix-core
  * work of bf16x3; gemm_f16x2.hip).  Splits W and computes A's row scales into temporaries, synchronises the stream:

@@ -15,7 +15,7 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["engine.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "gemm_f16x2.hip", "gemm_f16x2p.hip", "gemm_f16x2_8p.hip", "xlstm_kernels.hip",
+SOURCES = ["engine.hip", "gemm_f32.hip", "gemm_bf16x3.hip", "gemm_f16x2.hip", "gemm_f16x2p.hip", "gemm_f16x2_8p.hip", "gemm_narrow.hip", "xlstm_kernels.hip",
            "mlstm_chunk.hip", "mlstm_lazy.hip", "mlstm_front.hip", "slstm_seq.hip", "impala_cnn.hip", "misc_kernels.hip",
            "mamba_kernels.hip", "selftest.hip"]
 BUILD_ID_SOURCE = "build_id.cpp"   # carries the hash of everything else; compiled on every build (a second)

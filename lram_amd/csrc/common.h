@@ -163,6 +163,12 @@ bool gemm_f16x2_supported(const GemmArgs& g);
 void launch_gemm_f16x2(const GemmArgs& g, hipStream_t stream);    // fp32-accurate, 2 x f16 split operands, row-scaled
 bool gemm_f16x2p_supported(const GemmArgs& g);
 void launch_gemm_f16x2p(const GemmArgs& g, hipStream_t stream);   // the same with A pre-split too: DMA staging, MFMA-only loop
+// narrow-output projection (N <= 96, K a multiple of 64; gemm_narrow.hip): exact fp32 MFMA, 16 rows per workgroup, W packed at upload
+bool gemm_narrow_shape(int n, int k);
+bool gemm_narrow_supported(const GemmArgs& g);
+size_t gemm_narrow_pack_elems(int n, int k);
+void launch_gemm_narrow_pack(const float* w, int n, int k, float* packed, hipStream_t stream);
+void launch_gemm_narrow(const GemmArgs& g, const float* packed, hipStream_t stream);
 bool gemm_f16x2_8p_supported(const GemmArgs& g);
 void launch_gemm_f16x2_8p(const GemmArgs& g, hipStream_t stream); // ... as 256 x 256 tiles, 8 staggered waves, counted DMA waits (gemm_f16x2_8p.hip)
 // planes[0 / 1] (K-tile-major: (r, k) at (k / 32) * kt + r * 32 + k % 32; `plane` elements apart) = hi / lo of

@@ -110,6 +110,9 @@ struct lram_engine {
                                   // (f16x2 projections, the default) two f16 planes in the same bytes + slstm_rinv, the inverse row scales
   std::vector<DevBuf> slstm_rinv;
   int lazy_cap2_envs = 896;       // LRAM_LAZY_CAP2_ENVS: largest slice whose read pass runs two workgroups per CU (0 = never)
+  std::map<const float*, DevBuf> narrow;   // narrow-output weights (Mamba x_proj) packed for gemm_narrow.hip (built in finalize)
+  bool gemm_narrow_on = true;     // LRAM_GEMM_NARROW=0: x_proj through the tile GEMMs (split-K + reduce) as before round 6
+  int gemm_narrow_min_rows = 256;
   bool gn_amax_handover = true;   // LRAM_GN_AMAX=0: proj_down's operand row maxima from their own launch, not from the group norm
   bool slstm_seq_f32 = false;     // LRAM_SLSTM_SEQ=2: its exact-fp32 form even where the projections run as f16x2
   bool slstm_seq = true;          // LRAM_SLSTM_SEQ=0: per-token recurrent GEMM + pointwise launches for slices beyond the token kernel's
@@ -227,6 +230,8 @@ struct lram_engine {
     split16.clear();
     for (DevBuf& b : dt_wt) b.release();
     dt_wt.clear();
+    for (auto& kv : narrow) kv.second.release();
+    narrow.clear();
     for (DevBuf& b : gate_coef) b.release();
     gate_coef.clear();
     for (DevBuf& b : slstm_rt2) b.release();
@@ -500,6 +505,16 @@ void finalize(lram_engine* e) {
     }
     LRAM_HIP_CHECK(hipDeviceSynchronize());
   }
+  if (c.backbone == LRAM_BACKBONE_MAMBA && e->gemm_narrow_on && gemm_narrow_shape(c.dt_rank + 2 * c.d_state, c.d_inner)) {
+    const int nx = c.dt_rank + 2 * c.d_state;
+    for (const BlockWeights& w : e->bw) {
+      if (w.x_proj == nullptr || e->narrow.count(w.x_proj)) continue;
+      DevBuf& pk = e->narrow[w.x_proj];
+      pk.alloc(gemm_narrow_pack_elems(nx, c.d_inner));
+      launch_gemm_narrow_pack(w.x_proj, nx, c.d_inner, pk.p, nullptr);
+    }
+    LRAM_HIP_CHECK(hipDeviceSynchronize());
+  }
   e->dt_wt.assign(e->bw.size(), DevBuf());
   if (c.backbone == LRAM_BACKBONE_MAMBA && e->mamba_dt_fuse && mamba_ssm_dt_fusable(c.d_state, c.dt_rank)) {
     for (size_t i = 0; i < e->bw.size(); ++i) {
@@ -741,6 +756,12 @@ bool takes_skinny_with_norm(const lram_engine* e, const GemmArgs& g) {
   return takes_skinny(e, g) && gemm_skinny_norm_supported(g);
 }
 
+// The narrow-output kernel's share: a whole packed weight (x_proj), enough rows to fill the chip with 16-row workgroups.
+bool narrow_takes(const lram_engine* e, const GemmArgs& g) {
+  if (!e->gemm_narrow_on || g.m < e->gemm_narrow_min_rows || g.a2 != nullptr || (int)g.ldw != g.k) return false;
+  return e->narrow.count(g.w) != 0 && gemm_narrow_supported(g);
+}
+
 void count_gemm(lram_engine* e, int family, const GemmArgs& g) {
   e->gemm_counts[family] += 1.0;
   e->gemm_counts[4 + family] += 2.0 * g.m * g.n * g.k * g.nb1 * g.nb2;
@@ -801,6 +822,11 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
                  "gemm: pre-split A operand for a projection the pre-split kernel does not serve");
     launch_gemm_f16x2p(g, s);
     count_gemm(e, 0, g);
+    return;
+  }
+  if (narrow_takes(e, g)) {  // narrow outputs (Mamba x_proj): one launch, exact fp32, no split-K slabs / reduce launch
+    launch_gemm_narrow(g, e->narrow.find(g.w)->second.p, s);
+    count_gemm(e, 2, g);
     return;
   }
   if (f16x2_rows(e, g.m, g.n, g.k) && g.nb1 * g.nb2 == 1 && e->ASCALE.p != nullptr && (size_t)g.m <= e->ascale_rows) {
@@ -1379,7 +1405,9 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   } else if (stage == 1) {
     MambaConvArgs ca;
     ca.xz = U, ca.conv_state = st.conv.p + b0 * di * c.d_conv, ca.conv_w = w.conv_w, ca.conv_b = w.conv_b, ca.xc = XA;
-    ca.reset = rs, ca.B = sl.nb, ca.T = T, ca.d_inner = di, ca.K = c.d_conv, ca.amax = amx_xa;
+    // (x_proj's operand row maxima are only needed where it runs as an f16x2 tile GEMM)
+    const bool xp_narrow = e->gemm_narrow_on && rows >= e->gemm_narrow_min_rows && e->narrow.count(w.x_proj) != 0;
+    ca.reset = rs, ca.B = sl.nb, ca.T = T, ca.d_inner = di, ca.K = c.d_conv, ca.amax = xp_narrow ? nullptr : amx_xa;
     launch_mamba_conv(ca, sl.s);
   } else {
     MambaSsmArgs sa;
@@ -1673,6 +1701,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_MAMBA_DT_FUSE")) e->mamba_dt_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_GN_AMAX")) e->gn_amax_handover = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_GEMM_NARROW")) e->gemm_narrow_on = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0, e->slstm_seq_f32 = std::atoi(v) == 2;
     if (const char* v = std::getenv("LRAM_LAZY_CAP2_ENVS")) e->lazy_cap2_envs = std::max(0, std::atoi(v));
@@ -2098,6 +2127,29 @@ int32_t lram_gemm_skinny(const float* dev_a, int64_t lda, const float* dev_w, in
     g.residual = accumulate ? dev_c : nullptr;
     g.m = m, g.n = n, g.k = k;
     launch_gemm_skinny(g, static_cast<hipStream_t>(stream));
+  });
+}
+
+int32_t lram_gemm_narrow(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
+                         const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(ldw == k && accumulate == 0, "lram_gemm_narrow: W must be contiguous [n, k]; no accumulation");
+    LRAM_REQUIRE(gemm_narrow_shape(n, k), "lram_gemm_narrow: n <= 96, k a multiple of 64, >= 256");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* packed = nullptr;
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&packed), gemm_narrow_pack_elems(n, k) * sizeof(float)));
+    try {
+      launch_gemm_narrow_pack(dev_w, n, k, packed, s);
+      GemmArgs g;
+      g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
+      g.m = m, g.n = n, g.k = k;
+      launch_gemm_narrow(g, packed, s);
+      LRAM_HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      (void)hipFree(packed);
+      throw;
+    }
+    (void)hipFree(packed);
   });
 }
 

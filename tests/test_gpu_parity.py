@@ -72,6 +72,35 @@ def test_gemm_few_row_kernel_matches_fp64(hip_lib, m, n, k):
     assert float(wide_c[:, n:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("m,n,k", [(3072, 80, 1536), (300, 80, 1536), (257, 33, 256), (1000, 96, 320), (17, 5, 256), (4100, 80, 2560),
+                                   (64, 16, 64 * 9), (40, 48, 64 * 5)])
+def test_gemm_narrow_output_kernel_matches_fp64(hip_lib, m, n, k):
+    """gemm_narrow_kernel (Mamba's x_proj in the engine: N = 80, K = 1536, from 256 operand rows): exact fp32 products on the matrix
+    cores, 16 rows x all columns per workgroup, K chunks of 64 dealt to 4 waves (fewer chunks than waves, a chunk count that 4
+    does not divide), ragged last row block, column counts that are not multiples of 16, bias, a row range of a wider operand
+    and of a wider output -- the bar of the k-ordered fp32 kernel."""
+    from lram_amd.engine import gemm_f32
+    g = torch.Generator().manual_seed(m * 7 + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g)
+    bias = torch.randn(n, generator=g)
+    ref = a.double() @ w.double().t()
+    out = gemm_f32(a.cuda(), w.cuda(), None, kernel="narrow")
+    torch.cuda.synchronize()
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-6 * k ** 0.5 * 16, (m, n, k)
+    out_b = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="narrow")
+    torch.cuda.synchronize()
+    assert (out_b.cpu().double() - ref - bias.double()).abs().max().item() < 2e-6 * k ** 0.5 * 16
+    assert torch.equal(out_b, gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="narrow"))       # deterministic
+    wide_a = torch.randn(m, k + 8, generator=g)
+    wide_c = torch.zeros(m, n + 4).cuda()
+    out3 = gemm_f32(wide_a.cuda()[:, :k], w.cuda(), bias.cuda(), out=wide_c[:, :n], kernel="narrow")
+    torch.cuda.synchronize()
+    ref3 = wide_a[:, :k].double() @ w.double().t() + bias.double()
+    assert (out3.cpu().double() - ref3).abs().max().item() < 2e-6 * k ** 0.5 * 16
+    assert float(wide_c[:, n:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (96, 2192, 512), (300, 80, 1536), (1000, 1408, 512),
                                    (4096, 512, 1024), (5, 8, 8), (257, 129, 48)])
 def test_gemm_bf16x3_matches_fp64(hip_lib, m, n, k):
@@ -455,6 +484,36 @@ def test_mamba_lane_state_update_at_ragged_env_counts(hip_lib, B):
     spec = ModelSpec(backbone="mamba", kind="MDDMamba", d_model=768, n_blocks=3)  # Mamba-48M's widths (d_inner 1536, dt_rank 48)
     assert spec.d_inner == 1536 and spec.dt_rank in (0, 48)
     assert _run_parity(f"mamba_768_b{B}", B=B, steps=5, spec=spec) == 0
+
+
+def test_mamba_x_proj_narrow_kernel_against_the_tile_gemm_path(hip_lib, monkeypatch):
+    """x_proj through the narrow-output kernel (default from 256 operand rows: one launch, exact fp32) and through the f16x2 tile
+    GEMM + split-K reduce it replaced (LRAM_GEMM_NARROW=0): both meet the oracle bars at 130 envs (390 rows, ragged 16-row blocks),
+    and agree with each other to fp32 rounding."""
+    from lram_amd.engine import Engine
+    spec = preset("mamba_48m")
+    sd = init_state_dict(spec, seed=0)
+    B = 130
+    seq = make_inputs(spec, B, 3, seed=77)
+    outs = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("LRAM_GEMM_NARROW", on)
+        eng = Engine(spec, sd, B, device="cuda:0")
+        for obs, rtg, rew, mask in seq:
+            a, _ = eng.step(obs.cuda(), rtg.cuda(), rew.cuda(), mask.cuda())
+        torch.cuda.synchronize()
+        _, hidden, logits = eng.taps()
+        counts = eng.gemm_counts()
+        outs[on] = (a.clone(), hidden.clone(), counts)
+        eng.close()
+    assert outs["1"][2]["f32"]["launches"] >= 3 * spec.n_blocks > outs["0"][2]["f32"]["launches"]   # (counted with the exact-fp32 family)
+    assert rel_err(outs["1"][1], outs["0"][1]) < 1e-5
+    ora = dt_ref.OraclePolicy(spec, sd)
+    for obs, rtg, rew, mask in seq:
+        a_ref, dbg = ora.step(obs, rtg, rew, mask, return_debug=True)
+    for on in ("1", "0"):
+        assert rel_err(outs[on][1], dbg["hidden"]) < 2e-4, on
+        assert_actions_match(outs[on][0], a_ref, dbg["logits"], spec, what=f"narrow={on}")
 
 
 @pytest.mark.parametrize("name,B", [("mamba_48m", 6), ("mamba_tiny", 7)])
