@@ -266,6 +266,13 @@ int32_t lram_gemm_skinny(const float* dev_a, int64_t lda, const float* dev_w, in
 int32_t lram_gemm_narrow(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
                          int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
                          int32_t k, void* stream);
+/* The same kernel family with the products formed as in lram_gemm_f16x2 (rows scaled by a power of two, two binary16 pieces per
+ * operand, hi*hi + hi*lo + lo*hi on the f16 matrix instruction, exact un-scaling): the form the engine runs for x_proj wherever
+ * its projections run as f16x2 and the conv kernel hands the operand's row maxima over.  Same argument rules as lram_gemm_narrow;
+ * splits W and takes A's row maxima in temporaries, synchronises the stream: test / micro-benchmark entry. */
+int32_t lram_gemm_narrow_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c,
+                               int64_t ldc, const float* dev_bias, int32_t accumulate, int32_t m, int32_t n,
+                               int32_t k, void* stream);
 /* Same contract through the f16x2 kernel (each fp32 operand row scaled by a power of two and split into two binary16
  * pieces, three f16 MFMA products accumulated in fp32, exact un-scaling: fp32-level accuracy at half the matrix-core
  * work of bf16x3; gemm_f16x2.hip).  Splits W and computes A's row scales into temporaries, synchronises the stream:

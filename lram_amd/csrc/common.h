@@ -169,6 +169,9 @@ bool gemm_narrow_supported(const GemmArgs& g);
 size_t gemm_narrow_pack_elems(int n, int k);
 void launch_gemm_narrow_pack(const float* w, int n, int k, float* packed, hipStream_t stream);
 void launch_gemm_narrow(const GemmArgs& g, const float* packed, hipStream_t stream);
+// ... as f16x2 split products (g.w2 / w_inv = the K-tile-major planes of the f16x2 tile GEMMs, g.a_amax / amax_parts = A's row maxima)
+bool gemm_narrow16_supported(const GemmArgs& g);
+void launch_gemm_narrow16(const GemmArgs& g, hipStream_t stream);
 bool gemm_f16x2_8p_supported(const GemmArgs& g);
 void launch_gemm_f16x2_8p(const GemmArgs& g, hipStream_t stream); // ... as 256 x 256 tiles, 8 staggered waves, counted DMA waits (gemm_f16x2_8p.hip)
 // planes[0 / 1] (K-tile-major: (r, k) at (k / 32) * kt + r * 32 + k % 32; `plane` elements apart) = hi / lo of

@@ -113,6 +113,7 @@ struct lram_engine {
   std::map<const float*, DevBuf> narrow;   // narrow-output weights (Mamba x_proj) packed for gemm_narrow.hip (built in finalize)
   bool gemm_narrow_on = true;     // LRAM_GEMM_NARROW=0: x_proj through the tile GEMMs (split-K + reduce) as before round 6
   int gemm_narrow_min_rows = 256;
+  bool gemm_narrow_f16 = true;    // LRAM_GEMM_NARROW=2: its exact-fp32 form even where the projections run as f16x2
   bool gn_amax_handover = true;   // LRAM_GN_AMAX=0: proj_down's operand row maxima from their own launch, not from the group norm
   bool slstm_seq_f32 = false;     // LRAM_SLSTM_SEQ=2: its exact-fp32 form even where the projections run as f16x2
   bool slstm_seq = true;          // LRAM_SLSTM_SEQ=0: per-token recurrent GEMM + pointwise launches for slices beyond the token kernel's
@@ -824,8 +825,14 @@ void gemm(lram_engine* e, GemmArgs& g, hipStream_t s) {
     count_gemm(e, 0, g);
     return;
   }
-  if (narrow_takes(e, g)) {  // narrow outputs (Mamba x_proj): one launch, exact fp32, no split-K slabs / reduce launch
-    launch_gemm_narrow(g, e->narrow.find(g.w)->second.p, s);
+  if (narrow_takes(e, g)) {  // narrow outputs (Mamba x_proj): one launch, no split-K slabs / reduce launch
+    if (e->use_f16x2 && e->gemm_narrow_f16 && g.a_amax != nullptr && f16x2_weight(e, g.w, (int)g.ldw, &g) && gemm_narrow16_supported(g)) {
+      launch_gemm_narrow16(g, s);   // f16x2 split products (the operand's row maxima come from its producer)
+      count_gemm(e, 0, g);
+      return;
+    }
+    g.w2 = nullptr, g.w_inv = nullptr, g.w2_kt = 0;
+    launch_gemm_narrow(g, e->narrow.find(g.w)->second.p, s);   // exact fp32
     count_gemm(e, 2, g);
     return;
   }
@@ -1405,9 +1412,10 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
   } else if (stage == 1) {
     MambaConvArgs ca;
     ca.xz = U, ca.conv_state = st.conv.p + b0 * di * c.d_conv, ca.conv_w = w.conv_w, ca.conv_b = w.conv_b, ca.xc = XA;
-    // (x_proj's operand row maxima are only needed where it runs as an f16x2 tile GEMM)
-    const bool xp_narrow = e->gemm_narrow_on && rows >= e->gemm_narrow_min_rows && e->narrow.count(w.x_proj) != 0;
-    ca.reset = rs, ca.B = sl.nb, ca.T = T, ca.d_inner = di, ca.K = c.d_conv, ca.amax = xp_narrow ? nullptr : amx_xa;
+    // (x_proj's operand row maxima are not needed where it runs in the exact-fp32 form of the narrow-output kernel)
+    const bool xp_narrow32 = e->gemm_narrow_on && rows >= e->gemm_narrow_min_rows && e->narrow.count(w.x_proj) != 0 &&
+                             !(e->use_f16x2 && e->gemm_narrow_f16);
+    ca.reset = rs, ca.B = sl.nb, ca.T = T, ca.d_inner = di, ca.K = c.d_conv, ca.amax = xp_narrow32 ? nullptr : amx_xa;
     launch_mamba_conv(ca, sl.s);
   } else {
     MambaSsmArgs sa;
@@ -1701,7 +1709,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_MAMBA_DT_FUSE")) e->mamba_dt_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_GN_AMAX")) e->gn_amax_handover = std::atoi(v) != 0;
-    if (const char* v = std::getenv("LRAM_GEMM_NARROW")) e->gemm_narrow_on = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_GEMM_NARROW")) e->gemm_narrow_on = std::atoi(v) != 0, e->gemm_narrow_f16 = std::atoi(v) != 2;
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0, e->slstm_seq_f32 = std::atoi(v) == 2;
     if (const char* v = std::getenv("LRAM_LAZY_CAP2_ENVS")) e->lazy_cap2_envs = std::max(0, std::atoi(v));
@@ -2150,6 +2158,37 @@ int32_t lram_gemm_narrow(const float* dev_a, int64_t lda, const float* dev_w, in
       throw;
     }
     (void)hipFree(packed);
+  });
+}
+
+int32_t lram_gemm_narrow_f16x2(const float* dev_a, int64_t lda, const float* dev_w, int64_t ldw, float* dev_c, int64_t ldc,
+                               const float* dev_bias, int32_t accumulate, int32_t m, int32_t n, int32_t k, void* stream) {
+  return guarded([&] {
+    gemm_knobs_reload();
+    LRAM_REQUIRE(ldw == k && accumulate == 0, "lram_gemm_narrow_f16x2: W must be contiguous [n, k]; no accumulation");
+    LRAM_REQUIRE(gemm_narrow_shape(n, k), "lram_gemm_narrow_f16x2: n <= 96, k a multiple of 64, >= 256");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t numel = split_f16x2_plane_elems((size_t)n, (size_t)k);
+    uint16_t* planes = nullptr;
+    float* scales = nullptr;  // [n] inverse weight scales, then [m] row maxima of A
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&planes), 2 * numel * sizeof(uint16_t)));
+    LRAM_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&scales), ((size_t)n + m) * sizeof(float)));
+    try {
+      launch_split_f16x2(dev_w, n, k, planes, scales, s);
+      launch_row_amax(dev_a, lda, nullptr, 0, m, k, scales + n, s);
+      GemmArgs g;
+      g.a = dev_a, g.lda = lda, g.w = dev_w, g.ldw = ldw, g.c = dev_c, g.ldc = ldc, g.bias = dev_bias;
+      g.m = m, g.n = n, g.k = k, g.w2 = planes, g.w2_plane = (int64_t)numel, g.w2_kt = 32 * (int64_t)n, g.w_inv = scales;
+      g.a_amax = scales + n, g.amax_parts = 1;
+      launch_gemm_narrow16(g, s);
+      LRAM_HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+      (void)hipFree(planes);
+      (void)hipFree(scales);
+      throw;
+    }
+    (void)hipFree(planes);
+    (void)hipFree(scales);
   });
 }
 

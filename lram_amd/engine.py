@@ -72,6 +72,8 @@ _SYMBOLS = {
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_narrow": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
+    "lram_gemm_narrow_f16x2": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_bf16x3": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_gemm_f16x2": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
@@ -455,7 +457,7 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = No
                 os.environ["LRAM_GEMM_TILE"] = old
     fn = {"f32": lib.lram_gemm_f32, "bf16x3": lib.lram_gemm_bf16x3, 
           "f16x2": lib.lram_gemm_f16x2, "f16x2p": lib.lram_gemm_f16x2_presplit, "skinny": lib.lram_gemm_skinny,
-          "narrow": lib.lram_gemm_narrow}[kernel]
+          "narrow": lib.lram_gemm_narrow, "narrow16": lib.lram_gemm_narrow_f16x2}[kernel]
     M, K = a.shape
     N = w.shape[0]
     if out is None:

@@ -40,6 +40,8 @@ if __name__ == "__main__":
         for kern in kernels:
             if kern in ("f16x2p", "f16x2p8") and K % 32 != 0:
                 continue
+            if kern in ("narrow", "narrow16") and (N > 96 or K % 64 != 0 or K < 256):
+                continue
             for _ in range(REPS):
                 gemm_f32(a, w, kernel=kern)
             order.append({"tag": tag, "kernel": kern, "m": M, "n": N, "k": K, "reps": REPS})

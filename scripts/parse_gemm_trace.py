@@ -29,6 +29,6 @@ for o in order:
         i += 1
     us = sorted(durs)[len(durs) // 2] / 1e3
     flops = 2.0 * o["m"] * o["n"] * o["k"]
-    mult = {"bf16x3": 6, "f16x2": 3, "f16x2p": 3, "f16x2p8": 3}.get(o["kernel"], 1)
+    mult = {"bf16x3": 6, "f16x2": 3, "f16x2p": 3, "f16x2p8": 3, "narrow16": 3}.get(o["kernel"], 1)
     print(f"{o['tag']:14s} {o['kernel']:7s} M={o['m']:6d} N={o['n']:5d} K={o['k']:5d}  {us:8.1f} us  "
           f"{flops / us / 1e6:7.1f} TFLOP/s fp32-equiv  {mult * flops / us / 1e6:7.1f} TFLOP/s MFMA-issued")

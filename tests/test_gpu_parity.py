@@ -74,8 +74,10 @@ def test_gemm_few_row_kernel_matches_fp64(hip_lib, m, n, k):
 
 @pytest.mark.parametrize("m,n,k", [(3072, 80, 1536), (300, 80, 1536), (257, 33, 256), (1000, 96, 320), (17, 5, 256), (4100, 80, 2560),
                                    (64, 16, 64 * 9), (40, 48, 64 * 5)])
-def test_gemm_narrow_output_kernel_matches_fp64(hip_lib, m, n, k):
-    """gemm_narrow_kernel (Mamba's x_proj in the engine: N = 80, K = 1536, from 256 operand rows): exact fp32 products on the matrix
+@pytest.mark.parametrize("kern", ["narrow", "narrow16"])
+def test_gemm_narrow_output_kernel_matches_fp64(hip_lib, m, n, k, kern):
+    """gemm_narrow_kernel / gemm_narrow16_kernel (Mamba's x_proj in the engine: N = 80, K = 1536, from 256 operand rows): exact fp32
+    products ("narrow") or f16x2 split products ("narrow16": the engine's default beside f16x2 projections) on the matrix
     cores, 16 rows x all columns per workgroup, K chunks of 64 dealt to 4 waves (fewer chunks than waves, a chunk count that 4
     does not divide), ragged last row block, column counts that are not multiples of 16, bias, a row range of a wider operand
     and of a wider output -- the bar of the k-ordered fp32 kernel."""
@@ -84,17 +86,27 @@ def test_gemm_narrow_output_kernel_matches_fp64(hip_lib, m, n, k):
     a = torch.randn(m, k, generator=g)
     w = torch.randn(n, k, generator=g)
     bias = torch.randn(n, generator=g)
+    if kern == "narrow16":   # rows of varied scale, one all-zero row: what the power-of-two row scales are for
+        a = a * torch.exp(torch.randn(m, 1, generator=g))
+        a[m // 2] = 0.0
     ref = a.double() @ w.double().t()
-    out = gemm_f32(a.cuda(), w.cuda(), None, kernel="narrow")
+    out = gemm_f32(a.cuda(), w.cuda(), None, kernel=kern)
     torch.cuda.synchronize()
-    assert (out.cpu().double() - ref).abs().max().item() < 2e-6 * k ** 0.5 * 16, (m, n, k)
-    out_b = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="narrow")
+    scale = a.double().abs() @ w.double().abs().t() + 1e-300
+    if kern == "narrow16":   # the f16x2 bar: within 1.25 x the exact fp32 kernel's error on the same data (sum |a||w| metric)
+        e1 = ((gemm_f32(a.cuda(), w.cuda(), None, kernel="narrow").cpu().double() - ref).abs() / scale).max().item()
+        e2 = ((out.cpu().double() - ref).abs() / scale).max().item()
+        assert e2 < 1.25 * e1, (m, n, k, e2, e1)
+        assert float(out[m // 2].abs().max()) == 0.0
+    assert ((out.cpu().double() - ref).abs() / scale.clamp_min(1.0)).max().item() < 2e-6 * 16, (m, n, k)
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-6 * k ** 0.5 * 16 * max(1.0, float(a.abs().max())), (m, n, k)
+    out_b = gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel=kern)
     torch.cuda.synchronize()
-    assert (out_b.cpu().double() - ref - bias.double()).abs().max().item() < 2e-6 * k ** 0.5 * 16
-    assert torch.equal(out_b, gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel="narrow"))       # deterministic
+    assert (out_b.cpu().double() - ref - bias.double()).abs().max().item() < 2e-6 * k ** 0.5 * 16 * max(1.0, float(a.abs().max()))
+    assert torch.equal(out_b, gemm_f32(a.cuda(), w.cuda(), bias.cuda(), kernel=kern))       # deterministic
     wide_a = torch.randn(m, k + 8, generator=g)
     wide_c = torch.zeros(m, n + 4).cuda()
-    out3 = gemm_f32(wide_a.cuda()[:, :k], w.cuda(), bias.cuda(), out=wide_c[:, :n], kernel="narrow")
+    out3 = gemm_f32(wide_a.cuda()[:, :k], w.cuda(), bias.cuda(), out=wide_c[:, :n], kernel=kern)
     torch.cuda.synchronize()
     ref3 = wide_a[:, :k].double() @ w.double().t() + bias.double()
     assert (out3.cpu().double() - ref3).abs().max().item() < 2e-6 * k ** 0.5 * 16
@@ -487,16 +499,17 @@ def test_mamba_lane_state_update_at_ragged_env_counts(hip_lib, B):
 
 
 def test_mamba_x_proj_narrow_kernel_against_the_tile_gemm_path(hip_lib, monkeypatch):
-    """x_proj through the narrow-output kernel (default from 256 operand rows: one launch, exact fp32) and through the f16x2 tile
-    GEMM + split-K reduce it replaced (LRAM_GEMM_NARROW=0): both meet the oracle bars at 130 envs (390 rows, ragged 16-row blocks),
-    and agree with each other to fp32 rounding."""
+    """x_proj through the narrow-output kernel (default from 256 operand rows: one launch; f16x2 split products fed with the conv
+    kernel's row maxima, or exact fp32 with LRAM_GEMM_NARROW=2) and through the f16x2 tile GEMM + split-K reduce it replaced
+    (LRAM_GEMM_NARROW=0): all meet the oracle bars at 130 envs (390 rows, ragged 16-row blocks) and agree with each other to fp32
+    rounding."""
     from lram_amd.engine import Engine
     spec = preset("mamba_48m")
     sd = init_state_dict(spec, seed=0)
     B = 130
     seq = make_inputs(spec, B, 3, seed=77)
     outs = {}
-    for on in ("1", "0"):
+    for on in ("1", "2", "0"):
         monkeypatch.setenv("LRAM_GEMM_NARROW", on)
         eng = Engine(spec, sd, B, device="cuda:0")
         for obs, rtg, rew, mask in seq:
@@ -506,12 +519,14 @@ def test_mamba_x_proj_narrow_kernel_against_the_tile_gemm_path(hip_lib, monkeypa
         counts = eng.gemm_counts()
         outs[on] = (a.clone(), hidden.clone(), counts)
         eng.close()
-    assert outs["1"][2]["f32"]["launches"] >= 3 * spec.n_blocks > outs["0"][2]["f32"]["launches"]   # (counted with the exact-fp32 family)
-    assert rel_err(outs["1"][1], outs["0"][1]) < 1e-5
+    # (the exact-fp32 form is counted with the fp32 family, the f16x2 form with the f16x2 family)
+    assert outs["2"][2]["f32"]["launches"] >= 3 * spec.n_blocks > outs["0"][2]["f32"]["launches"]
+    assert outs["1"][2]["f32"]["launches"] == outs["0"][2]["f32"]["launches"]
+    assert rel_err(outs["1"][1], outs["0"][1]) < 1e-5 and rel_err(outs["2"][1], outs["0"][1]) < 1e-5
     ora = dt_ref.OraclePolicy(spec, sd)
     for obs, rtg, rew, mask in seq:
         a_ref, dbg = ora.step(obs, rtg, rew, mask, return_debug=True)
-    for on in ("1", "0"):
+    for on in ("1", "2", "0"):
         assert rel_err(outs[on][1], dbg["hidden"]) < 2e-4, on
         assert_actions_match(outs[on][0], a_ref, dbg["logits"], spec, what=f"narrow={on}")
 
