@@ -87,11 +87,13 @@ struct GemmArgs {
   // optional (few-row kernel, K <= 512): A is the UN-normalised input; every workgroup normalises its 32 rows in registers
   // before the products -- LayerNorm (x - mean) / sqrt(var + eps) * norm_g (+ norm_b), biased variance, two pass; RMSNorm
   // x * rsqrt(mean(x^2) + eps) * norm_g -- as row_norm_kernel does: no norm launch, no [rows, K] round trip
-  // optional (few-row kernel): the outer batch index z2 (< nb2 <= 4) picks its operands from these tables instead of
+  // optional (few-row kernel; bf16x3 kernel with w3_tab): the outer batch index z2 (< nb2 <= 4) picks its operands from these tables instead of
   // a / w / c + z2 * stride -- several projections with unrelated base pointers in one launch (the four sLSTM gates)
   const float* a_tab[4] = {nullptr, nullptr, nullptr, nullptr};
   const float* w_tab[4] = {nullptr, nullptr, nullptr, nullptr};
   float* c_tab[4] = {nullptr, nullptr, nullptr, nullptr};
+  // (bf16x3 kernel with a_tab / c_tab: the split planes of w_tab[z2], `w3_plane` elements apart like w3's)
+  const uint16_t* w3_tab[4] = {nullptr, nullptr, nullptr, nullptr};
   const float* norm_g = nullptr;
   const float* norm_b = nullptr;
   float norm_eps = 0.f;

@@ -113,6 +113,7 @@ struct lram_engine {
   std::map<const float*, DevBuf> narrow;   // narrow-output weights (Mamba x_proj) packed for gemm_narrow.hip (built in finalize)
   bool gemm_narrow_on = true;     // LRAM_GEMM_NARROW=0: x_proj through the tile GEMMs (split-K + reduce) as before round 6
   int gemm_narrow_min_rows = 256;
+  bool slstm_gates_one = true;    // LRAM_SLSTM_GATES_ONE=0: the four sLSTM gate projections of larger slices as four bf16x3 launches
   bool gemm_narrow_f16 = true;    // LRAM_GEMM_NARROW=2: its exact-fp32 form even where the projections run as f16x2
   bool gn_amax_handover = true;   // LRAM_GN_AMAX=0: proj_down's operand row maxima from their own launch, not from the group norm
   bool slstm_seq_f32 = false;     // LRAM_SLSTM_SEQ=2: its exact-fp32 form even where the projections run as f16x2
@@ -1135,6 +1136,22 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
   gemm(e, dn, sl.s);
 }
 
+// Fills g4's operand tables for the four sLSTM gate projections as one bf16x3 launch; false where that kernel cannot serve it.
+bool slstm_gates_one_bf16x3(const lram_engine* e, GemmArgs& g4, const BlockWeights& w, const float* XC, const float* XN, float* gates,
+                            int Hs) {
+  if (!e->use_bf16x3 || !e->slstm_gates_one) return false;
+  int64_t plane = -1;
+  for (int g = 0; g < 4; ++g) {
+    auto it = e->split.find(w.gate_w[g]);
+    if (it == e->split.end() || (plane >= 0 && (int64_t)it->second.n != plane)) return false;
+    plane = (int64_t)it->second.n;
+    g4.a_tab[g] = (g < 2) ? XC : XN, g4.w_tab[g] = w.gate_w[g], g4.c_tab[g] = gates + (int64_t)g * Hs;
+    g4.w3_tab[g] = it->second.p;
+  }
+  g4.w3 = g4.w3_tab[0], g4.w3_plane = plane;
+  return gemm_bf16x3_supported(g4) && !gemm_small_m(g4);
+}
+
 void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice& sl) {
   const lram_config& c = e->cfg;
   const int D = c.d_model, NH = c.n_heads, SDH = e->sdh(), F = c.ffn_dim, Hs = D, rows = sl.nb * T;
@@ -1172,6 +1189,11 @@ void slstm_block(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
       g4.a_tab[g] = (g < 2) ? XC : XN, g4.w_tab[g] = w.gate_w[g], g4.c_tab[g] = gates + (int64_t)g * Hs;
     launch_gemm_skinny(g4, s);
     count_gemm(e, 3, g4);
+  } else if (slstm_gates_one_bf16x3(e, g4, w, XC, XN, gates, Hs)) {
+    // larger slices: the same ONE launch on the bf16x3 kernel (operand tables; every gate's tiles in one grid instead of four
+    // short launches of 48-144 workgroups each on the slice's chain) -- bit-identical to the four launches
+    launch_gemm_bf16x3(g4, s);
+    count_gemm(e, 1, g4);
   } else {
     for (int g = 0; g < 4; ++g) {
       GemmArgs ga;
@@ -1709,6 +1731,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_MAMBA_DT_FUSE")) e->mamba_dt_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_GN_AMAX")) e->gn_amax_handover = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_SLSTM_GATES_ONE")) e->slstm_gates_one = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_NARROW")) e->gemm_narrow_on = std::atoi(v) != 0, e->gemm_narrow_f16 = std::atoi(v) != 2;
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0, e->slstm_seq_f32 = std::atoi(v) == 2;

@@ -58,9 +58,12 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmArgs g) {
 
   const int z = blockIdx.y;
   const int z1 = z / g.nb2, z2 = z - z1 * g.nb2;
-  const float* A = g.a + z1 * g.sA1 + z2 * g.sA2;
-  const __bf16* W3 = reinterpret_cast<const __bf16*>(g.w3) + z1 * g.sW1 + z2 * g.sW2;
-  float* C = g.c + z1 * g.sC1 + z2 * g.sC2;
+  // (operand tables: the outer batch index picks unrelated base pointers -- the four sLSTM gate projections as ONE launch)
+  const bool tab = g.w3_tab[0] != nullptr;
+  const float* A = tab ? g.a_tab[z2] + z1 * g.sA1 : g.a + z1 * g.sA1 + z2 * g.sA2;
+  const __bf16* W3 = tab ? reinterpret_cast<const __bf16*>(g.w3_tab[z2]) + z1 * g.sW1
+                         : reinterpret_cast<const __bf16*>(g.w3) + z1 * g.sW1 + z2 * g.sW2;
+  float* C = tab ? g.c_tab[z2] + z1 * g.sC1 : g.c + z1 * g.sC1 + z2 * g.sC2;
   const float* R = HAS_RES ? g.residual + z1 * g.sC1 + z2 * g.sC2 : nullptr;
   const float* bias = HAS_BIAS ? g.bias + z1 * g.sBias1 + z2 * g.sBias2 : nullptr;
 

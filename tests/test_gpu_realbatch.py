@@ -228,3 +228,21 @@ def test_group_norm_row_maxima_handover_is_bit_identical(hip_lib, monkeypatch, g
     assert torch.equal(a["acts"], b["acts"]) and torch.equal(a["hidden"], b["hidden"]) and torch.equal(a["logits"], b["logits"])
     for k in keys:
         assert torch.equal(a["state"][k], b["state"][k]), k
+
+
+@pytest.mark.parametrize("name,B", [("xlstm_16m", 1024), ("xlstm_206m_cut", 600)])
+def test_slstm_gate_projections_as_one_launch_are_bit_identical(hip_lib, monkeypatch, name, B):
+    """Slices beyond the few-row kernel's run the four sLSTM gate projections (i / f on the conv branch, z / o on the norm;
+    per-head blocks) as ONE bf16x3 launch with operand tables instead of four launches (LRAM_SLSTM_GATES_ONE=0): same kernel,
+    same tiles, same sums -- bit for bit, at the 16M geometry (128-wide heads, 1536-row slices) and the 206M one (320-wide)."""
+    from lram_amd.config import ModelSpec
+    spec = preset(name) if name != "xlstm_206m_cut" else ModelSpec(backbone="xlstm", d_model=1280, n_blocks=3, slstm_at=[1])
+    sd = init_state_dict(spec, seed=0)
+    seq = _inputs(spec, B, 3, seed=5)
+    keys = [(1, 0)]
+    monkeypatch.delenv("LRAM_SLSTM_GATES_ONE", raising=False)
+    a = _run(spec, sd, seq, want_state=keys)
+    monkeypatch.setenv("LRAM_SLSTM_GATES_ONE", "0")
+    b = _run(spec, sd, seq, want_state=keys)
+    assert torch.equal(a["acts"], b["acts"]) and torch.equal(a["hidden"], b["hidden"]) and torch.equal(a["logits"], b["logits"])
+    assert torch.equal(a["state"][(1, 0)], b["state"][(1, 0)])
