@@ -749,7 +749,7 @@ def main(argv=None, engine_factory=None, device=None):
         eng.set_micro_batches(args.micro)
     # HBM bytes per launch come from a separate rocprofv3 --pmc pass (scripts/pmc_pass.sh -> profiles/): a constant
     # read from a committed file, labelled as such
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tag = "" if args.config == "xlstm_16m" else "_" + args.config   # (scripts/parse_pmc.py names the other configs' files)
         pmc_file = os.path.join(ROOT, "profiles", "%s_cell_kernel_hbm_traffic%s%s.json" % (rnd, tag, "_lazy" if lazy else ""))
         if not os.path.exists(pmc_file):
@@ -788,7 +788,7 @@ def main(argv=None, engine_factory=None, device=None):
              "peak": MFMA_PEAK_PFLOPS, "unit": "PFLOP/s", "frac_over_step": issued / (wall / K) / 1e15 / MFMA_PEAK_PFLOPS,
              "note": "matrix-core work of the projections averaged over the WHOLE env-step (state update, conv, norms "
                      "included in the time); f32 kind: peak is 0.157 PFLOP/s, frac not comparable"}
-        for rnd in ("r05", "r04", "r03"):
+        for rnd in ("r06", "r05", "r04", "r03"):
             pmc = os.path.join(ROOT, "profiles", "%s_gemm_mfma_busy.json" % rnd)
             if not os.path.exists(pmc):
                 continue

@@ -132,13 +132,14 @@ def test_gemm_bf16x3_matches_fp64(hip_lib, m, n, k):
     e1 = ((out1.cpu().double() - ref).abs() / scale).max().item()
     # e1: the exact fp32 fma-chain kernel on the same data.  No additive slack (round 4 removed it from the f16x2 gate, round 5
     # here): a single 8-deep K tile, where the chain is all but exact, gets the measured factor instead
-    assert e3 < (1.5 if k >= 32 else 3.0) * e1, (m, n, k, e3, e1, e3 / e1)
+    # (floor of a third of an fp32 ulp on e1: where the fma chain happens to be exact on a shape the ratio would be against 0)
+    assert e3 < (1.5 if k >= 32 else 3.0) * max(e1, 2e-8), (m, n, k, e3, e1)
     base = torch.randn(m, n, generator=g)
     out2 = gemm_f32(a.cuda(), w.cuda(), None, out=base.clone().cuda(), accumulate=True, kernel="bf16x3")
     torch.cuda.synchronize()
     ref2 = base.double() + a.double() @ w.double().t()
     # (accumulating into a base tensor adds one fp32 rounding of |base| ~ 1 per output: 6e-8 on the (scale + 1) metric)
-    assert ((out2.cpu().double() - ref2).abs() / (scale + 1)).max().item() < (1.5 if k >= 32 else 3.0) * e1 + 6e-8
+    assert ((out2.cpu().double() - ref2).abs() / (scale + 1)).max().item() < (1.5 if k >= 32 else 3.0) * max(e1, 2e-8) + 6e-8
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 32), (96, 2192, 512), (300, 80, 1536), (1000, 1408, 512),
