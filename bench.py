@@ -357,7 +357,8 @@ def parse_args(argv=None):
     ap.add_argument("--host-io-steps", type=int, default=48, help="steps of the host-inclusive leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
-                    help="skip the `configs` legs (BASELINE configs 2-5 at their per-GPU sizes; default-workload N = 1 runs only)")
+                    help="skip the `configs` legs (BASELINE configs 2-5 at their per-GPU sizes; they run on default-workload N = 1 runs "
+                         "that also take the CPU baseline, i.e. the driver's command line)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="live HIP-event timing of the dominant kernel on every n-th step of the timed region (1 = every step)")
@@ -846,7 +847,8 @@ def main(argv=None, engine_factory=None, device=None):
     out["whole_step_8d_GBps"] = out["algorithmic_bytes_per_env_step"] * value / world / 1e9
     default_workload = (args.config == "xlstm_16m" and args.obs == "state" and args.batch == 4096 and args.global_batch == 0
                         and not args.mamba_compat and not args.graph)
-    if rank == 0 and world == 1 and not dist_on and default_workload and not args.no_configs:
+    # (measurement scripts pass --no-cpu-baseline: profiler / counter / A-B runs of the headline must not drag five other engines along)
+    if rank == 0 and world == 1 and not dist_on and default_workload and not args.no_configs and not args.no_cpu_baseline:
         # BASELINE.json's other configurations, each on a fresh engine after the headline's is gone
         eng.close()
         eng = None

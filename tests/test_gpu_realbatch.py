@@ -154,12 +154,14 @@ def test_c4_206m_at_512_slots_state_obs(hip_lib):
     _real_batch_suite(spec, sd, 512, 3, torch.tensor([0, 255, 256, 511]))
 
 
-def test_c4_206m_at_512_slots_uint8_frames(hip_lib):
-    """Frames -> lram_embed_images -> 20 blocks -> argmax over the first 18 logits, at one GPU's share of C4."""
+@pytest.mark.parametrize("scheme", ["exercise", "reference"])
+def test_c4_206m_at_512_slots_uint8_frames(hip_lib, scheme):
+    """Frames -> lram_embed_images -> 20 blocks -> argmax over the first 18 logits, at one GPU's share of C4; on the weights every
+    other test uses and on the distribution a freshly built reference model has (scheme "reference": lram_amd/weights.py)."""
     spec = preset("xlstm_206m")
-    sd = init_state_dict(spec, seed=0, with_image_encoder=True)
+    sd = init_state_dict(spec, seed=0, with_image_encoder=True, scheme=scheme)
     B, sample = 512, torch.tensor([0, 255, 256, 511])
-    seq = _inputs(spec, B, 2, seed=77, image=True)
+    seq = _inputs(spec, B, 2 if scheme == "exercise" else 4, seed=77, image=True)
     base = _run(spec, sd, seq, discrete=True)
     ora = OraclePolicy(spec, sd)
     ties = 0
