@@ -12,7 +12,7 @@ rows = collections.defaultdict(dict)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if ("gemm_bf16x3_kernel" in n or "gemm_f32_kernel" in n or "gemm_f16x2_kernel" in n or "gemm_f16x2p_kernel" in n):
+        if ("gemm_bf16x3_kernel" in n or "gemm_f32_kernel" in n or "gemm_f16x2_kernel" in n or "gemm_f16x2p_kernel" in n or "gemm_f16x2_8p_kernel" in n):
             rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(rows)
 i = 0
