@@ -215,10 +215,75 @@ __global__ __launch_bounds__(64 * WM * WN, NSTAGE == 1 ? 4 : 2) void gemm_f16x2p
     }
   }
 
-  // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5));
-  // un-scale with the exact inverse powers of two of the row (A) and column (W) scales
+  // epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)): a lane holds ONE
+  // column of 16 rows, so storing from the accumulators is 16 single-dword stores per tile and lane, two 128-byte row pieces each --
+  // store-issue-bound (~7 B / clock / CU: measured on the 256 x 256 kernel, gemm_f16x2_8p.hip, where it was 21-24 us per workgroup),
+  // and on grids of one round of workgroups every workgroup stores at the same time with nothing left to overlap it.  Round 6: each
+  // wave turns its tile through the operand stages (free once every wave has left the K loop) -- ds_write_b32 in [row][col]
+  // order, ds_read_b128 of whole 256-byte rows, float4 un-scale + bias + residual + activation, dwordx4 stores.  Same arithmetic
+  // per element: acc * (w_inv * a_inv) + bias, + residual, silu.  Row pitches / column counts that are not multiples of 4 keep
+  // the accumulator-order stores.
   float* C = g.c;
   float* S = g.split_k > 1 ? g.splitk_ws + (int64_t)blockIdx.z * g.m * g.n : nullptr;
+  typedef float __attribute__((may_alias)) lds_f32;
+  typedef float4 __attribute__((may_alias)) lds_f32x4;
+  const int64_t ld_out = S != nullptr ? (int64_t)g.n : g.ldc;
+  float* outp = S != nullptr ? S : C;
+  const bool vec = (ld_out & 3) == 0 && (g.n & 3) == 0 && (reinterpret_cast<uintptr_t>(outp) & 15) == 0 &&
+                   (!HAS_BIAS || (reinterpret_cast<uintptr_t>(g.bias + n0) & 15) == 0) &&
+                   (!HAS_RES || (reinterpret_cast<uintptr_t>(g.residual) & 15) == 0);
+  constexpr int PR = (NSTAGE * STG * 2 >= NW * 32 * 64 * 4) ? 32 : 16;   // rows a wave stages per pass (its share of the stages)
+  if (vec) {
+    if (NSTAGE == 2) __syncthreads();   // (the one-stage loop ends on a barrier; here the last tile's fragment reads are still under way)
+    lds_f32* stg = reinterpret_cast<lds_f32*>(lds) + wave * (PR * 64);
+    const int c4 = (lane & 15) * 4, rq = lane >> 4;
+    const int gcol = n0 + 64 * wn + c4;
+    const bool col_in = gcol < g.n;   // (n is a multiple of 4: a float4 is inside or outside as a whole)
+    float4 wi4 = make_float4(0.f, 0.f, 0.f, 0.f), bv4 = wi4;
+    if (col_in) {
+      const int cl = BMT + gcol - n0;
+      wi4 = make_float4(NSTAGE == 1 ? scl[cl] : sclf[cl], NSTAGE == 1 ? scl[cl + 1] : sclf[cl + 1],
+                        NSTAGE == 1 ? scl[cl + 2] : sclf[cl + 2], NSTAGE == 1 ? scl[cl + 3] : sclf[cl + 3]);
+      if (HAS_BIAS && S == nullptr) bv4 = *reinterpret_cast<const float4*>(g.bias + gcol);
+    }
+    const int act_from = S == nullptr ? g.act_silu_from : -1;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int h = 0; h < 32 / PR; ++h) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);            // + 4 lh: row inside the 32-row tile
+            if (PR == 32 || (ro >> 4) == h) stg[((ro & (PR - 1)) + 4 * lh) * 64 + 32 * j + li] = acc[i][j][r];
+          }
+        const int rl0 = 32 * TI * wm + 32 * i + PR * h + rq;   // row inside the workgroup tile
+#pragma unroll
+        for (int it = 0; it < PR / 4; ++it) {
+          const int rl = rl0 + 4 * it, grow = m0 + rl;
+          const float4 t = *reinterpret_cast<const lds_f32x4*>(stg + (4 * it + rq) * 64 + c4);
+          if (grow < g.m && col_in) {
+            const float ai = NSTAGE == 1 ? scl[rl] : sclf[rl];
+            float4 v;
+            v.x = t.x * (wi4.x * ai) + bv4.x, v.y = t.y * (wi4.y * ai) + bv4.y;
+            v.z = t.z * (wi4.z * ai) + bv4.z, v.w = t.w * (wi4.w * ai) + bv4.w;
+            if (HAS_RES && S == nullptr) {
+              const float4 rr = *reinterpret_cast<const float4*>(g.residual + (int64_t)grow * g.ldc + gcol);
+              v.x += rr.x, v.y += rr.y, v.z += rr.z, v.w += rr.w;
+            }
+            if (act_from >= 0) {
+              if (gcol + 0 >= act_from) v.x = silu_hw(v.x);
+              if (gcol + 1 >= act_from) v.y = silu_hw(v.y);
+              if (gcol + 2 >= act_from) v.z = silu_hw(v.z);
+              if (gcol + 3 >= act_from) v.w = silu_hw(v.w);
+            }
+            *reinterpret_cast<float4*>(outp + (int64_t)grow * ld_out + gcol) = v;
+          }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
     float ainv[16];
