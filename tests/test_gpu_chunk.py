@@ -144,8 +144,7 @@ def test_chunkwise_prefill_on_the_weight_distributions_the_reference_runs(hip_li
     ties = assert_actions_match(a_chunk, a_ref, dbg["logits"], spec, what=f"prefill {scheme}")
     ties += assert_actions_match(a_step, a_ref, dbg["logits"], spec, what=f"steps {scheme}")
     assert ties <= (0 if scheme == "reference" else 2), ties
-    _, hid_c, _ = e_chunk.taps()
-    assert rel_err(hid_c, dbg["hidden"]) < tol, rel_err(hid_c, dbg["hidden"])
+    # (no hidden-state tap here: after a prefill the tap buffer holds the last CHUNK's rows, not one env-step's)
     for blk in (0, 7):
         for which in (0, 1, 2):
             want = ora.state[f"block_{blk}"]["mlstm_state"][which]
