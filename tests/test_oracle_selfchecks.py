@@ -20,6 +20,31 @@ def test_mlstm_step_equals_parallel_form():
     assert rel_err(hs, hp) < 5e-5
 
 
+@pytest.mark.parametrize("scheme", ["reference", "trained_like"])
+def test_mlstm_step_equals_parallel_form_on_the_long_memory_weight_distributions(scheme):
+    """The same identity where the recurrence is hard: forget gates of 0.95-0.998 ("reference": a freshly built model) and
+    input-gate pre-activations of +-16 with the stabiliser far from 0 ("trained_like"), 96 tokens.  Evaluated in float64 -- the
+    regime is ill-conditioned for fp32 (profiles/r06_trained_like_conditioning.txt) and this is a check of the oracle's ALGEBRA
+    (stabilised step == row-stabilised parallel form), the thing the GPU parity tests on these distributions lean on."""
+    spec = preset("xlstm_c1")
+    sd = {k: v.double() for k, v in init_state_dict(spec, seed=2, scheme=scheme).items()}
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        x = torch.randn(2, 96, spec.d_model, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+        if scheme == "trained_like":
+            x[:, :, 3] *= 30.0
+        hs, state = xlstm_ref.encoder_forward_cached(spec, sd, x, None)
+        hp = xlstm_ref.stack_forward_parallel(spec, sd, x)
+    finally:
+        torch.set_default_dtype(prev)
+    # (the forms differ by where eps = 1e-6 enters the denominator: measured 5e-8 on "trained_like")
+    assert hs.dtype == torch.float64 and rel_err(hs, hp) < 1e-6, rel_err(hs, hp)
+    m = state["block_0"]["mlstm_state"][2]
+    if scheme == "trained_like":
+        assert float(m.abs().max()) > 4.0      # the stabiliser really left the neighbourhood of 0
+
+
 @pytest.mark.parametrize("name", ["xlstm_tiny", "mamba_tiny"])
 def test_batched_equals_single_env(name):
     """Guards cross-env leakage and the sLSTM `n == 0` rule: B envs at once == each env alone."""
@@ -83,11 +108,14 @@ def test_state_layout_matches_reference_past_key_values():
     assert ms[0][0].shape == (2, 1536, 4) and ms[0][1].shape == (2, 1536, 16)
 
 
-def test_mamba_step_matches_transformers_mixer():
-    """T sequential oracle steps == the full-sequence scan of transformers' pure-torch MambaMixer."""
+@pytest.mark.parametrize("regime", ["exercise", "trained_like"])
+def test_mamba_step_matches_transformers_mixer(regime):
+    """T sequential oracle steps == the full-sequence scan of transformers' pure-torch MambaMixer; "trained_like": dt_proj.bias at
+    both ends of the initialiser's range (softplus^-1 of 1e-3 / 1e-1), A_log up to log 16 + 2, 40 tokens (the corner
+    lram_amd/weights.py::init_state_dict(scheme="trained_like") puts the engine tests in)."""
     tm = pytest.importorskip("transformers.models.mamba.modeling_mamba")
     from transformers import MambaConfig
-    D, N, K, R, T, B = 64, 16, 4, 4, 7, 3
+    D, N, K, R, T, B = 64, 16, 4, 4, (7 if regime == "exercise" else 40), 3
     cfg = MambaConfig(hidden_size=D, state_size=N, conv_kernel=K, expand=2, time_step_rank=R, num_hidden_layers=1,
                       use_bias=False, use_conv_bias=True, vocab_size=8)
     try:
@@ -100,6 +128,10 @@ def test_mamba_step_matches_transformers_mixer():
             if p.dim() >= 2 and p is not mixer.A_log:
                 p.copy_(torch.randn(p.shape, generator=g) * (1.0 / p.shape[-1] ** 0.5))
         mixer.A_log.add_(torch.randn(mixer.A_log.shape, generator=g) * 0.1)
+        if regime == "trained_like":
+            mixer.A_log.add_(torch.rand(mixer.A_log.shape, generator=g) * 2.0)
+            dt = torch.where(torch.rand(mixer.dt_proj.bias.shape, generator=g) < 0.5, torch.tensor(1e-3), torch.tensor(1e-1))
+            mixer.dt_proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))
     x = torch.randn(B, T, D, generator=g)
     with torch.no_grad():
         try:
