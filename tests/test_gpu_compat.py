@@ -97,12 +97,19 @@ def test_compat_modes_match_oracle_with_random_resets(hip_lib, repeat, stale):
     eng.close()
 
 
-def test_compat_mode_at_mamba_48m_shapes(hip_lib):
+@pytest.mark.parametrize("scheme,steps", [("exercise", 4), ("reference", 30), ("trained_like", 30)])
+def test_compat_mode_at_mamba_48m_shapes(hip_lib, scheme, steps):
+    """The reference Mamba agent's trajectory (4 forwards per env-step, layer-0-only resets) at Mamba-48M shapes, also on the weight
+    distributions a fresh / a trained model has (dt bias from the initialiser's range resp. at both of its ends, A_log up to
+    log 16 + 2: lram_amd/weights.py), 120 state advances per env."""
     from lram_amd.engine import Engine
     spec = preset("mamba_48m")
-    sd = init_state_dict(spec, seed=0)
+    sd = init_state_dict(spec, seed=0, scheme=scheme)
     B = 3
-    seq = make_inputs(spec, B, 4, seed=5, reset_prob=0.3)
+    seq = make_inputs(spec, B, steps, seed=5, reset_prob=0.3 if scheme == "exercise" else 0.05)
+    if scheme == "trained_like":
+        for x in seq:
+            x[0][:, 3] *= 30.0
     eng = Engine(spec, sd, B, device="cuda:0")
     eng.set_compat_mode(4, True)   # Meta-World: env_act_dim 4
     ora = OraclePolicy(spec, sd, mamba_repeat=4, stale_state=True)

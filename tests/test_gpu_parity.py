@@ -499,6 +499,18 @@ def test_mamba_lane_state_update_at_ragged_env_counts(hip_lib, B):
     assert _run_parity(f"mamba_768_b{B}", B=B, steps=5, spec=spec) == 0
 
 
+@pytest.mark.parametrize("scheme", ["reference", "trained_like"])
+@pytest.mark.parametrize("name,B,steps,discrete", [("xlstm_c1", 32, 24, False), ("xlstm_tiny", 16, 24, True), ("mamba_tiny", 8, 24, False)])
+def test_small_configurations_on_the_weight_distributions_the_reference_runs(hip_lib, scheme, name, B, steps, discrete):
+    """BASELINE config 1 (xLSTM[1:0], 2 layers, D = 128, 32 envs: the materialised small-batch kernels, few-row projections), the
+    18-way discrete head, and the tiny Mamba stack on the fresh-model and trained-like weight distributions (as
+    test_weight_distributions_the_reference_actually_runs does for the 16M / 48M stacks)."""
+    gain = (3, 30.0) if scheme == "trained_like" else None
+    ties = _run_parity(name, B=B, steps=steps, scheme=scheme, reset_prob=0.03, obs_gain=gain, cond_aware=True, pooled=True,
+                       discrete=discrete)
+    assert ties <= (2 if scheme == "trained_like" else 0), ties
+
+
 def test_mamba_x_proj_narrow_kernel_against_the_tile_gemm_path(hip_lib, monkeypatch):
     """x_proj through the narrow-output kernel (default from 256 operand rows: one launch; f16x2 split products fed with the conv
     kernel's row maxima, or exact fp32 with LRAM_GEMM_NARROW=2) and through the f16x2 tile GEMM + split-K reduce it replaced
