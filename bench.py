@@ -213,6 +213,15 @@ def step_leg(tag, cfg, B, K, W, dev, ep_len, rtg0, drtg, native, image=False, co
     spec = preset(cfg)
     sd = init_state_dict(spec, seed=0, with_image_encoder=image)
     eng = Engine(spec, sd, B, device=dev)
+    try:
+        return _step_leg_run(eng, spec, tag, cfg, B, K, W, dev, ep_len, rtg0, drtg, native, image, compat_act_dim, what)
+    finally:   # (a leg that fails must not leave its state -- up to 57 GB at 206M / 512 slots -- behind for the next one)
+        eng.close()
+        del eng, sd
+        torch.cuda.empty_cache()
+
+
+def _step_leg_run(eng, spec, tag, cfg, B, K, W, dev, ep_len, rtg0, drtg, native, image, compat_act_dim, what):
     T = spec.tokens_per_step
     prime = 16 if eng.state_mode == "lazy" else 2
     ring, rtgs, masks, g = _leg_inputs(spec, B, prime + W + K, ep_len, rtg0, drtg, native, dev, 4321)
@@ -253,9 +262,6 @@ def step_leg(tag, cfg, B, K, W, dev, ep_len, rtg0, drtg, native, image=False, co
            "mfma": mfma_block(ran, wall)}
     if spec.backbone == "xlstm":
         leg["whole_step_8d_GBps"] = (2 * spec.state_bytes_per_env() + 4 * spec.state_dim + 4 * spec.act_dim) * leg["value"] / 1e9
-    eng.close()
-    del eng, sd
-    torch.cuda.empty_cache()
     return leg
 
 
@@ -267,6 +273,15 @@ def prefill_leg(tag, cfg, B, L, n_decode, dev, what=""):
     spec = preset(cfg)
     sd = init_state_dict(spec, seed=0)
     eng = Engine(spec, sd, B, device=dev)
+    try:
+        return _prefill_leg_run(eng, spec, tag, cfg, B, L, n_decode, dev, what)
+    finally:
+        eng.close()
+        del eng, sd
+        torch.cuda.empty_cache()
+
+
+def _prefill_leg_run(eng, spec, tag, cfg, B, L, n_decode, dev, what):
     g = torch.Generator(device=dev).manual_seed(77)
     obs = torch.zeros(B, L, spec.state_dim, device=dev)
     obs[:, :, :168] = torch.rand(B, L, 168, generator=g, device=dev) * 2 - 1          # Mimicgen: 168-dim full state space
@@ -295,9 +310,6 @@ def prefill_leg(tag, cfg, B, L, n_decode, dev, what=""):
            "projections": projection_label(ran, "f16x2"), "mfma": mfma_block(ran, wall),
            "decode": {"steps": n_decode, "ms_per_step": wall_d / n_decode * 1e3, "value": B * n_decode / wall_d,
                       "unit": "env-steps/s", "state_mode": eng.state_mode}}
-    eng.close()
-    del eng, sd
-    torch.cuda.empty_cache()
     return leg
 
 
