@@ -104,6 +104,10 @@ struct GemmArgs {
   // ... or (panel_w > 0) the panel order: the tile grid is cut into column panels of panel_w tiles, walked row by row (odd
   // panels bottom-up), and every XCD takes one contiguous eighth of that walk
   int panel_w = 0;
+  // caller's hint (pre-split kernel): this projection runs BESIDE another env slice's memory-bound kernels -- where the launch is
+  // 64 .. 160 tiles of 256 x 256 the 8-phase kernel (one workgroup per CU on part of the chip, half the L2 -> CU traffic) is slower
+  // alone and faster for the step (Mamba-48M in_proj at 2048 slots: 65 vs 53 us alone, step +2.8 %: profiles/r06_ab_mamba_in_proj_8phase.txt)
+  int beside_memory_bound = 0;
   int mfma_prio = 0;      // set by the launcher: raise the wave's issue priority around the MFMA block
   int split_k = 1;        // set by the launcher
   int k_tiles_per_split = 0;

@@ -113,6 +113,7 @@ struct lram_engine {
   std::map<const float*, DevBuf> narrow;   // narrow-output weights (Mamba x_proj) packed for gemm_narrow.hip (built in finalize)
   bool gemm_narrow_on = true;     // LRAM_GEMM_NARROW=0: x_proj through the tile GEMMs (split-K + reduce) as before round 6
   int gemm_narrow_min_rows = 256;
+  int mamba_slices_now = 1;       // env slices of the Mamba step under way (run_mamba_stack)
   bool slstm_gates_one = true;    // LRAM_SLSTM_GATES_ONE=0: the four sLSTM gate projections of larger slices as four bf16x3 launches
   bool gemm_narrow_f16 = true;    // LRAM_GEMM_NARROW=2: its exact-fp32 form even where the projections run as f16x2
   bool gn_amax_handover = true;   // LRAM_GN_AMAX=0: proj_down's operand row maxima from their own launch, not from the group norm
@@ -1454,6 +1455,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     in.a = XN, in.lda = D, in.w = w.in_proj, in.ldw = D, in.c = U, in.ldc = 2 * di, in.bias = w.in_proj_b;
     in.m = rows, in.n = 2 * di, in.k = D, in.a_amax = amx_xn;
     if (ps_in) in.a = nullptr, in.a_amax = nullptr, in.a2 = xn2, in.a2_plane = (int64_t)e->XN2.n, in.a2_kt = xn2_kt, in.a2_inv = amx_xn;
+    in.beside_memory_bound = e->mamba_slices_now > 1 ? 1 : 0;   // (the other slice's conv / state update / norm run beside it)
     gemm(e, in, gs);
   } else if (stage == 1) {
     GemmArgs xp;
@@ -1484,6 +1486,7 @@ void run_mamba_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   const int D = c.d_model;
   const int n_stages = 3 * c.n_blocks;
   const int ns = (int)sl.size();
+  e->mamba_slices_now = ns;
   for (int k = 0; k < n_stages + ns - 1; ++k)   // slice j is enqueued j stages behind slice 0
     for (int j = 0; j < ns; ++j)
       if (k - j >= 0 && k - j < n_stages) mamba_stage(e, (k - j) / 3, (k - j) % 3, T, reset, sl[j]);

@@ -425,7 +425,12 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
   {
     const int force = gemm_knobs().tile;
     const long t256 = (long)((g.m + 255) / 256) * ((g.n + 255) / 256);
-    if (force == 256 || (force == 0 && t256 >= 700 && g.k >= 512 && g.n >= 1024)) {
+    const bool big = t256 >= 700 && g.k >= 512 && g.n >= 1024;
+    // ... and where the caller says the launch shares the chip with another slice's memory-bound kernels and covers 0.25-0.63 of
+    // the CUs as 256 x 256 tiles (Mamba's in_proj in the two-slice pipeline: 1024 slots +1 %, 2048 +2.8 %; 4096 slots = 288
+    // tiles -5 %, hence the upper limit)
+    const bool beside = g.beside_memory_bound != 0 && t256 >= 64 && t256 <= 160 && g.k >= 512;
+    if (force == 256 || (force == 0 && (big || beside))) {
       launch_gemm_f16x2_8p(g_in, stream);
       return;
     }
