@@ -113,6 +113,7 @@ struct lram_engine {
   std::map<const float*, DevBuf> narrow;   // narrow-output weights (Mamba x_proj) packed for gemm_narrow.hip (built in finalize)
   bool gemm_narrow_on = true;     // LRAM_GEMM_NARROW=0: x_proj through the tile GEMMs (split-K + reduce) as before round 6
   int gemm_narrow_min_rows = 256;
+  bool upz_beside = true;         // LRAM_UPZ_8P=0: proj_up's z half (issued beside the slice's own state pass) never through the 8-phase kernel
   int mamba_slices_now = 1;       // env slices of the Mamba step under way (run_mamba_stack)
   bool slstm_gates_one = true;    // LRAM_SLSTM_GATES_ONE=0: the four sLSTM gate projections of larger slices as four bf16x3 launches
   bool gemm_narrow_f16 = true;    // LRAM_GEMM_NARROW=2: its exact-fp32 form even where the projections run as f16x2
@@ -1079,6 +1080,7 @@ void mlstm_up_z(lram_engine* e, int i, int T, const Slice& sl) {
     up.a2_inv = e->AMX_XN.p + r0;
   }
   if (gn_fused(e, T)) up.act_silu_from = 0;
+  up.beside_memory_bound = e->upz_beside ? 1 : 0;   // (issued beside this slice's own state pass)
   gemm(e, up, sl.s);
 }
 
@@ -1735,6 +1737,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
     if (const char* v = std::getenv("LRAM_GN_AMAX")) e->gn_amax_handover = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_SLSTM_GATES_ONE")) e->slstm_gates_one = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_UPZ_8P")) e->upz_beside = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_NARROW")) e->gemm_narrow_on = std::atoi(v) != 0, e->gemm_narrow_f16 = std::atoi(v) != 2;
     if (const char* v = std::getenv("LRAM_SLSTM_FUSED_ROWS")) e->slstm_fused_rows = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("LRAM_SLSTM_SEQ")) e->slstm_seq = std::atoi(v) != 0, e->slstm_seq_f32 = std::atoi(v) == 2;
