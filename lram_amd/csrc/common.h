@@ -302,6 +302,7 @@ struct MlstmCellArgs {
   int min_lds_bytes = 0;  // > 0: request at least this much LDS per workgroup (occupancy cap, see launcher)
   const float* amat = nullptr;  // chunkwise prefill only (written by launch_mlstm_chunk_pre)
   const float* vec = nullptr;
+  int chunk_exact_fp32 = 0;     // chunkwise cell on the fp32-input matrix cores (LRAM_CHUNK_CELL=0) instead of the bf16x3 form
 };
 void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream);
 void launch_mlstm_chunk_cell(const MlstmCellArgs& a, hipStream_t stream);

@@ -3,6 +3,7 @@
 // the next block runs, so each block's recurrent state is read and written once per env-step).
 // C ABI in include/lram_hip.h.
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -175,6 +176,16 @@ struct lram_engine {
   DevBuf GATES, AMAT, VEC;           // chunkwise mLSTM prefill work buffers (allocated with the first long chunk)
   int tok_cap = 0;                   // tokens per env the activation workspace holds (kMaxTokens until a prefill grows it)
   bool chunk_prefill = true;         // LRAM_PREFILL_CHUNK=0: keep the token-sequential kernels for prefill
+  bool chunk_exact_fp32 = false;     // LRAM_PREFILL_CHUNK=2: chunkwise cell on the fp32-input matrix cores (the round 1-5 form)
+  // Chunk lanes of lram_prefill: consecutive chunks of a stored context alternate between two activation workspaces and two
+  // streams; block i of chunk c + 1 waits for block i of chunk c only (its recurrent state), so two chunks are in flight one
+  // block apart -- the matrix-core-bound projections of one beside the HBM-bound state passes of the other, and the
+  // token-sequential sLSTM launches of either hidden behind both (one env slice only; LRAM_PREFILL_CHUNK=3: off).
+  bool chunk_lanes = true;
+  DevBuf twin[18];                   // second copy of the per-token activation workspace (see workspace_set())
+  std::vector<hipEvent_t> lane_ev[2];                     // "block i of the lane's current chunk is done"
+  const std::vector<hipEvent_t>* lane_wait = nullptr;     // set by timesteps_launches around run_stack
+  const std::vector<hipEvent_t>* lane_rec = nullptr;
   DevBuf SK;                         // split-K partial slabs: one slot per stream that may run a GEMM
   static constexpr size_t kSplitKSlotElems = 6u << 20;  // 6 Mi floats (24 MiB) >= S*M*N for any GEMM the chooser splits
   static constexpr int kSplitKSlots = 9;                 // caller's stream + up to 8 micro-batch streams
@@ -219,6 +230,8 @@ struct lram_engine {
     for (hipStream_t ms : micro_streams) (void)hipStreamDestroy(ms);
     for (hipEvent_t ev : sync_events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : edge_events) (void)hipEventDestroy(ev);
+    for (auto& v : lane_ev)
+      for (hipEvent_t ev : v) (void)hipEventDestroy(ev);
     for (auto& e : prof_events) {
       (void)hipEventDestroy(e.first);
       (void)hipEventDestroy(e.second);
@@ -268,6 +281,7 @@ struct lram_engine {
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
                       &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &X0, &U0})
       b->release();
+    for (DevBuf& b : twin) b.release();
     ascale_rows = 0;
     img_cap = 0;
     B = 0;
@@ -585,6 +599,33 @@ void alloc_workspace(lram_engine* e, int tokens) {
     }
   }
   e->tok_cap = tokens;
+}
+
+// The per-token activation buffers a chunk of a stored context goes through (xLSTM): what a second chunk in flight needs its own copy of.
+// (SK / ASCALE are per stream already; LOGITS / TOK belong to the last timestep, which always runs on the primary set.)
+std::array<DevBuf*, 18> workspace_set(lram_engine* e) {
+  return {&e->X, &e->XN, &e->XN2, &e->HID, &e->U, &e->Q, &e->K, &e->V, &e->XA, &e->H, &e->G, &e->SCAL, &e->RY, &e->GATES,
+          &e->AMAT, &e->VEC, &e->AMX_XN, &e->AMX_H};
+}
+void swap_workspace(lram_engine* e) {
+  const auto ws = workspace_set(e);
+  for (size_t i = 0; i < ws.size(); ++i) std::swap(*ws[i], e->twin[i]);
+}
+// Second workspace for the chunk lanes, sized like the first; false (no lanes) if the device has no room for it.
+bool twin_ready(lram_engine* e) {
+  const auto ws = workspace_set(e);
+  bool same = true;
+  size_t want = 0;
+  for (size_t i = 0; i < ws.size(); ++i) same = same && e->twin[i].n == ws[i]->n, want += ws[i]->n * sizeof(float);
+  if (same) return true;
+  LRAM_HIP_CHECK(hipDeviceSynchronize());
+  for (DevBuf& b : e->twin) b.release();
+  size_t free_b = 0, total_b = 0;
+  LRAM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+  if (want + ((size_t)2 << 30) > free_b) return false;  // keep 2 GiB of headroom
+  for (size_t i = 0; i < ws.size(); ++i) e->twin[i].alloc(ws[i]->n);
+  LRAM_HIP_CHECK(hipDeviceSynchronize());
+  return true;
 }
 
 // Timesteps per state pass for a stored context of L timesteps.  xLSTM geometries the chunkwise kernels cover
@@ -1101,6 +1142,7 @@ void mlstm_cell(lram_engine* e, int i, int T, const uint8_t* reset, const Slice&
   if (T > kMaxTokens) {
     ca.amat = e->AMAT.p + b0 * NH * kChunkMaxTokens * kChunkMaxTokens;
     ca.vec = e->VEC.p + b0 * NH * 3 * kChunkMaxTokens;
+    ca.chunk_exact_fp32 = e->chunk_exact_fp32 ? 1 : 0;
   }
   prof_record(e, s, true);
   launch_mlstm_cell(ca, s);
@@ -1323,6 +1365,8 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
     for (int i = next_mlstm(-1); i >= 0 && k < lram_engine::fold_bubbles; i = next_mlstm(i), ++k) launch_folds(i);
   }
   for (int i = 0; i < c.n_blocks; ++i) {
+    if (i > 0 && e->lane_rec) LRAM_HIP_CHECK(hipEventRecord((*e->lane_rec)[i - 1], sl[0].s));   // (chunk lanes: one slice, one stream)
+    if (e->lane_wait) LRAM_HIP_CHECK(hipStreamWaitEvent(sl[0].s, (*e->lane_wait)[i], 0));
     if (c.block_is_slstm[i]) {
       // (enqueued BEFORE the sLSTM block's ~50 launches: with short kernels the host is only just ahead of the device
       // there, and folds queued behind them reached the state-pass stream 0.26 ms after it had gone idle -- 206M, 512 slots)
@@ -1380,6 +1424,7 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
     }
     for (const Slice& x : sl) mlstm_back(e, i, T, x);
   }
+  if (e->lane_rec) LRAM_HIP_CHECK(hipEventRecord((*e->lane_rec)[c.n_blocks - 1], sl[0].s));
   if (lazy) {
     ++e->lazy_step;
     e->lazy_dirty = true;
@@ -1574,12 +1619,37 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   const std::vector<Slice> sl = make_slices(e, s, &hbm);
   const bool multi = sl.size() > 1;
   if (multi) fork_slices(e, sl, hbm, s);
+  // chunk lanes (see lram_engine::chunk_lanes): the last chunk -- the one the action head reads -- is on lane 0 = the primary
+  // workspace and the caller's stream
+  const int n_chunks = (L + kChunk - 1) / kChunk;
+  const bool lanes = !multi && n_chunks >= 2 && kChunk * T > kMaxTokens && e->chunk_lanes && c.backbone == LRAM_BACKBONE_XLSTM &&
+                     shared_passes <= 1 && twin_ready(e);
+  hipStream_t lane_s[2] = {s, s};
+  if (lanes) {
+    if (e->micro_streams.empty()) {
+      hipStream_t ns;
+      LRAM_HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+      e->micro_streams.push_back(ns);
+    }
+    lane_s[1] = e->micro_streams[0];
+    for (auto& v : e->lane_ev)
+      while ((int)v.size() < c.n_blocks) {
+        hipEvent_t nev;
+        LRAM_HIP_CHECK(hipEventCreateWithFlags(&nev, hipEventDisableTiming | (e->event_device_scope ? hipEventDisableSystemFence : 0u)));
+        v.push_back(nev);
+      }
+    stream_after(e, lane_s[1], s, true);
+  }
   int Tc = T, last_steps = 1;
-  for (int l = 0; l < L; l += kChunk) {
+  for (int l = 0, ci = 0; l < L; l += kChunk, ++ci) {
     const int Lc = std::min(kChunk, L - l);
     Tc = T * Lc;
     last_steps = Lc;
-    for (const Slice& x : sl) {
+    const int lane = lanes ? ((n_chunks - 1 - ci) & 1) : 0;
+    const std::vector<Slice> lane_sl = {Slice{0, e->B, lane_s[lane]}};
+    const std::vector<Slice>& use = lanes ? lane_sl : sl;
+    if (lane) swap_workspace(e);
+    for (const Slice& x : use) {
       if (shared_passes > 1 && col_begin > 0) break;  // the tokens of this env-step were embedded by pass 0 (X0 / U0)
       const size_t r0 = (size_t)x.b0 * Tc, b0 = x.b0;
       float* X = e->X.p + r0 * D;
@@ -1609,8 +1679,12 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
       launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s,
                       (L == 1 && e->B <= kTokenTapMaxBatch) ? e->TOK.p + r0 * D : nullptr, nullptr, stok_on ? &stok : nullptr);
     }
-    run_stack(e, Tc, l == 0 ? reset : nullptr, sl, hbm);
+    if (lanes) e->lane_wait = ci > 0 ? &e->lane_ev[lane ^ 1] : nullptr, e->lane_rec = &e->lane_ev[lane];
+    run_stack(e, Tc, l == 0 ? reset : nullptr, use, lanes ? lane_s[lane] : hbm);
+    e->lane_wait = e->lane_rec = nullptr;
+    if (lane) swap_workspace(e);
   }
+  if (lanes) stream_after(e, s, lane_s[1], true);
   if (actions != nullptr) {
     const int64_t nlog = (int64_t)c.act_dim * c.n_vocab;
     const int pred = T * (last_steps - 1) + c.pred_token;  // rtg token of the last timestep in the last chunk
@@ -1724,7 +1798,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     e->device = device;
     // Environment knobs (measurement / test switches; the table is in DESIGN.md section 5)
     gemm_knobs_reload();   // the projection launchers' process-wide knobs: read here, never on the step path
-    if (const char* v = std::getenv("LRAM_PREFILL_CHUNK")) e->chunk_prefill = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_PREFILL_CHUNK")) e->chunk_prefill = std::atoi(v) != 0, e->chunk_exact_fp32 = std::atoi(v) == 2, e->chunk_lanes = std::atoi(v) != 3;
     if (const char* v = std::getenv("LRAM_STATE")) {
       const std::string m(v);
       e->lazy_mode = m == "lazy" ? 1 : (m == "eager" || m == "materialised" || m == "materialized") ? 0 : 2;

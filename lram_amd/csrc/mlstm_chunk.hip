@@ -555,6 +555,277 @@ __global__ __launch_bounds__(kThreads) void mlstm_cell_chunk_kernel(MlstmCellArg
   }
 }
 
+
+// =============================================================================================
+// Cell, bf16x3 form (the default): the same three contractions on the bf16 matrix cores.  Every fp32 operand is
+// split exactly into three bf16 pieces and a product is the six largest piece products, as in gemm_bf16x3.hip
+// (error <= 2^-23 relative: one fp32 rounding) -- `v_mfma_f32_32x32x16_bf16` runs at 16 x the rate of the fp32-input
+// MFMA, so the pass drops from matrix-core-bound (85 TF/s of exact fp32 products) to the HBM time of C once in, once out.
+//   * C_0 never goes through LDS: lane (column li, half lh) loads exactly the 16 rows of its 32 x 32 accumulator
+//     tile, acc_row(i, lh); they seed the C_T accumulator (fall * C_0) AND, split in registers, are the B operand of
+//     Q C_0 -- the contraction runs over the tile's rows in THAT order, and the Q planes are stored in LDS in the
+//     same order (position 16 lh + i <-> row acc_row(i, lh)).
+//   * V planes [column][token] stay in LDS for the whole pass (B operand of both token contractions), (fcum Q) and
+//     (w Khat)^T planes are staged per 32-row tile; 16-byte granules XOR-swizzled so ds_read_b128 / ds_write_b128 /
+//     ds_write_b64 are conflict-free without padding: 72 KB of LDS, two workgroups per CU.
+// =============================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kVPlane = kCW * kLp;   // bf16 elements per V plane   [128 columns][64 tokens]
+constexpr int kQPlane = kLp * kRT;   // per (fcum Q) plane          [64 tokens][32 row slots]
+constexpr int kKPlane = kRT * kLp;   // per (w Khat)^T plane        [32 rows][64 tokens]
+constexpr int kCell3Lds = 3 * (kVPlane + kQPlane + kKPlane) * 2;  // 73,728 B
+
+__device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  mid = (__bf16)r1;
+  lo = (__bf16)(r1 - (float)mid);
+}
+template <typename V, int N>
+__device__ __forceinline__ void split3v(const float (&x)[N], V& hi, V& mid, V& lo) {
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    __bf16 h, m, l;
+    split3(x[e], h, m, l);
+    hi[e] = h, mid[e] = m, lo[e] = l;
+  }
+}
+// acc += a * b with a = a[0] + a[1] + a[2], b likewise; smallest terms first
+__device__ __forceinline__ void mfma6(f32x16& acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(kThreads) void mlstm_cell_chunk3_kernel(MlstmCellArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* Vp = reinterpret_cast<__bf16*>(smem_raw);  // [3][128][64]: granule g of row c at g ^ ((c >> 1) & 7)
+  __bf16* Qp = Vp + 3 * kVPlane;                     // [3][64][32]:  granule g of row t at g ^ ((t >> 2) & 3)
+  __bf16* Kp = Qp + 3 * kQPlane;                     // [3][32][64]:  granule g of row r at g ^ ((r >> 1) & 7)
+  __shared__ float s_fc[kLp], s_w[kLp], s_den[kLp];
+
+  const int T = a.T, NH = a.NH, DH = a.DH, inner = NH * DH;
+  const int nslices = DH / kCW;
+  int wid = blockIdx.x;  // XCD-aware order, as the fp32 form
+  const int nwg = gridDim.x;
+  if ((nwg & 7) == 0) wid = (wid & 7) * (nwg >> 3) + (wid >> 3);
+  const int slice = wid % nslices;
+  const int bh = wid / nslices;
+  const int h = bh % NH, b = bh / NH;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const bool rs = a.reset != nullptr && a.reset[b] != 0;
+  const bool two = T > 32;
+  const int kt16 = (T + 15) >> 4;  // 16-token steps of the contractions over tokens
+  const float sqrt_dh = sqrtf((float)DH);
+
+  const float* vec = a.vec + ((int64_t)b * NH + h) * 3 * kLp;
+  if (tid < kLp) {
+    s_fc[tid] = vec[tid];
+    s_w[tid] = vec[kLp + tid];
+    s_den[tid] = vec[2 * kLp + tid];
+  }
+  const int col0 = slice * kCW;
+  // Buffer resources: one 32-bit lane offset + a scalar offset per access (no 64-bit address arithmetic in the loop), and the
+  // range check does the masking -- rows of q / k / v beyond T and the matrix of a reset env read as zero without a branch
+  // (the check sees the LANE offset only, not the scalar one: token offsets ride in the lane offset).
+  const uint32_t tok_bytes = (uint32_t)T * (uint32_t)inner * 4u;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q) + (int64_t)b * T * inner, 0, tok_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.k) + (int64_t)b * T * inner, 0, tok_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.v) + (int64_t)b * T * inner, 0, tok_bytes, 0x00020000);
+  float* Cm = a.C + (((int64_t)b * NH + h) * DH) * DH;
+  const uint32_t c_bytes = (uint32_t)DH * (uint32_t)DH * 4u;
+  const __amdgpu_buffer_rsrc_t rc_in = __builtin_amdgcn_make_buffer_rsrc(Cm, 0, rs ? 0u : c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc_out = __builtin_amdgcn_make_buffer_rsrc(Cm, 0, c_bytes, 0x00020000);
+  constexpr int kNt = 2;  // cache policy: non-temporal (C is touched once per pass)
+  const int row_b = DH * 4, tok_b = inner * 4;
+  // ---- V planes: thread (column, token half) gathers 8 consecutive tokens of its column per granule ----
+  {
+    const int col = tid & 127, th = tid >> 7;
+    const int voff = (h * DH + col0 + col) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rv, voff + (32 * th + 8 * g + j) * tok_b, 0, 0));
+      bf16x8 p0, p1, p2;
+      split3v(x, p0, p1, p2);
+      __bf16* d = Vp + col * kLp + (((4 * th + g) ^ ((col >> 1) & 7)) << 3);
+      *reinterpret_cast<bf16x8*>(d) = p0;
+      *reinterpret_cast<bf16x8*>(d + kVPlane) = p1;
+      *reinterpret_cast<bf16x8*>(d + 2 * kVPlane) = p2;
+    }
+  }
+  __syncthreads();
+  const float fall = s_fc[T - 1];
+
+  f32x16 hacc0, hacc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) hacc0[r] = hacc1[r] = 0.f;
+  float ws[8];   // w_t / sqrt(DH) of this thread's eight tokens: (w_t / s) k instead of w_t (k / s), one division per pass
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ws[j] = s_w[8 * (tid >> 5) + j] / sqrt_dh;
+
+  const int c_voff = (4 * lh * DH + col0 + 32 * w + li) * 4;   // + (r0 + (i & 3) + 8 (i >> 2)) rows as the scalar offset
+  const int qt = tid >> 2, qd = tid & 3;   // Q staging: token qt, rows 8 qd .. 8 qd + 7 of the tile
+  const int kr = tid & 31, kg = tid >> 5;  // K staging: row kr, tokens 8 kg .. 8 kg + 7
+  const int q_voff = (qt * inner + h * DH + 8 * qd) * 4;
+  const int k_voff = (8 * kg * inner + h * DH + kr) * 4;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  float kn[8];
+  v4f qn[2];
+  auto load_c = [&](float (&c)[16], int r0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      c[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc_in, c_voff, (r0 + (i & 3) + 8 * (i >> 2)) * row_b, kNt));
+  };
+  auto load_qk = [&](int r0) {
+    qn[0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rq, q_voff, r0 * 4, 0));
+    qn[1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rq, q_voff, r0 * 4 + 16, 0));
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      kn[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, k_voff + j * tok_b, r0 * 4, 0));
+  };
+  auto store_tile = [&](const f32x16& c, int r0) {   // (one iteration late: see the fp32 form)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = c[r];
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rc_out, c_voff, (r0 + (r & 3) + 8 * (r >> 2)) * row_b, kNt);
+    }
+  };
+  const int ntiles = DH / kRT;   // a multiple of 4 (DH % 128 == 0)
+  f32x16 cprev;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cprev[r] = 0.f;
+  // one tile of the main loop; cx holds C_0 of tile `it` on entry and is refilled with tile it + 2 (two tiles of C in flight)
+  auto tile = [&](int it, float (&cx)[16]) {
+    const int r0 = it * kRT;
+    // ---- stage (fcum Q) and (w Khat)^T planes of this tile ----
+    {
+      const float fc = s_fc[qt];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {   // u = lane half the four rows belong to: row 8 qd + 4 u + e <-> slot 16 u + 4 qd + e
+        const float x[4] = {fc * qn[u][0], fc * qn[u][1], fc * qn[u][2], fc * qn[u][3]};
+        bf16x4 p0, p1, p2;
+        split3v(x, p0, p1, p2);
+        __bf16* d = Qp + qt * kRT + ((((2 * u + (qd >> 1)) ^ ((qt >> 2) & 3))) << 3) + 4 * (qd & 1);
+        *reinterpret_cast<bf16x4*>(d) = p0;
+        *reinterpret_cast<bf16x4*>(d + kQPlane) = p1;
+        *reinterpret_cast<bf16x4*>(d + 2 * kQPlane) = p2;
+      }
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = ws[j] * kn[j];
+      bf16x8 p0, p1, p2;
+      split3v(x, p0, p1, p2);
+      __bf16* d = Kp + kr * kLp + ((kg ^ ((kr >> 1) & 7)) << 3);
+      *reinterpret_cast<bf16x8*>(d) = p0;
+      *reinterpret_cast<bf16x8*>(d + kKPlane) = p1;
+      *reinterpret_cast<bf16x8*>(d + 2 * kKPlane) = p2;
+    }
+    float cc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cc[i] = cx[i];
+    __syncthreads();
+    if (it > 0) store_tile(cprev, r0 - kRT);
+    if (it + 2 < ntiles) load_c(cx, r0 + 2 * kRT);
+    if (it + 1 < ntiles) load_qk(r0 + kRT);
+    // ---- H += (fcum Q)[:, tile] C_0[tile, cols] ----
+    f32x16 cacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cacc[r] = fall * cc[r];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 cb[3], qf[3];
+      const float x[8] = {cc[8 * ks], cc[8 * ks + 1], cc[8 * ks + 2], cc[8 * ks + 3],
+                          cc[8 * ks + 4], cc[8 * ks + 5], cc[8 * ks + 6], cc[8 * ks + 7]};
+      split3v(x, cb[0], cb[1], cb[2]);
+      {
+        const __bf16* src = Qp + li * kRT + (((2 * lh + ks) ^ ((li >> 2) & 3)) << 3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) qf[p] = *reinterpret_cast<const bf16x8*>(src + p * kQPlane);
+        mfma6(hacc0, qf, cb);
+      }
+      if (two) {
+        const __bf16* src = Qp + (32 + li) * kRT + (((2 * lh + ks) ^ ((li >> 2) & 3)) << 3);   // ((32 + li) >> 2) & 3 == (li >> 2) & 3
+#pragma unroll
+        for (int p = 0; p < 3; ++p) qf[p] = *reinterpret_cast<const bf16x8*>(src + p * kQPlane);
+        mfma6(hacc1, qf, cb);
+      }
+    }
+    // ---- C_T[tile, cols] = fcum_{T-1} C_0[tile, cols] + (w Khat)[:, tile]^T V[:, cols] ----
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < kt16) {
+        bf16x8 kf[3], vf[3];
+        const __bf16* ksrc = Kp + li * kLp + (((2 * ks + lh) ^ ((li >> 1) & 7)) << 3);
+        const int vc = 32 * w + li;
+        const __bf16* vsrc = Vp + vc * kLp + (((2 * ks + lh) ^ ((vc >> 1) & 7)) << 3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          kf[p] = *reinterpret_cast<const bf16x8*>(ksrc + p * kKPlane);
+          vf[p] = *reinterpret_cast<const bf16x8*>(vsrc + p * kVPlane);
+        }
+        mfma6(cacc, kf, vf);
+      }
+    }
+    cprev = cacc;
+    __syncthreads();
+  };
+  float ca[16], cb2[16];
+  load_c(ca, 0);
+  load_c(cb2, kRT);
+  load_qk(0);
+  for (int it = 0; it < ntiles; it += 2) {
+    tile(it, ca);
+    tile(it + 1, cb2);
+  }
+  store_tile(cprev, (ntiles - 1) * kRT);
+
+  // ---- H += A V  (A rows from global / L2, split in registers; A[t][s] == 0 for s > t: token tile 0 stops at s < 32) ----
+  {
+    const float* Ag = a.amat + ((int64_t)b * NH + h) * kLp * kLp;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < kt16) {
+        bf16x8 vf[3], af[3];
+        const int vc = 32 * w + li;
+        const __bf16* vsrc = Vp + vc * kLp + (((2 * ks + lh) ^ ((vc >> 1) & 7)) << 3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const bf16x8*>(vsrc + p * kVPlane);
+        if (ks < 2) {
+          const float4 a0 = *reinterpret_cast<const float4*>(Ag + li * kLp + 16 * ks + 8 * lh);
+          const float4 a1 = *reinterpret_cast<const float4*>(Ag + li * kLp + 16 * ks + 8 * lh + 4);
+          const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          split3v(x, af[0], af[1], af[2]);
+          mfma6(hacc0, af, vf);
+        }
+        if (two) {
+          const float4 a0 = *reinterpret_cast<const float4*>(Ag + (32 + li) * kLp + 16 * ks + 8 * lh);
+          const float4 a1 = *reinterpret_cast<const float4*>(Ag + (32 + li) * kLp + 16 * ks + 8 * lh + 4);
+          const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          split3v(x, af[0], af[1], af[2]);
+          mfma6(hacc1, af, vf);
+        }
+      }
+    }
+  }
+
+  // ---- h_t = H[t] / den_t ----
+  float* hb = a.h + (int64_t)b * T * inner + (int64_t)h * DH + col0 + 32 * w + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t0 = acc_row(r, lh);
+    if (t0 < T) hb[(int64_t)t0 * inner] = hacc0[r] / s_den[t0];
+    if (two && 32 + t0 < T) hb[(int64_t)(32 + t0) * inner] = hacc1[r] / s_den[32 + t0];
+  }
+}
+
 }  // namespace
 
 bool mlstm_chunk_supported(int inner, int NH, int K) {
@@ -587,9 +858,14 @@ void launch_mlstm_chunk_cell(const MlstmCellArgs& a, hipStream_t stream) {
   if (first_use_on_device(raised)) {
     LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_cell_chunk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCellChunkLds));
+    LRAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlstm_cell_chunk3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kCell3Lds));
   }
   const long nwg = (long)a.B * a.NH * (a.DH / kCW);
-  hipLaunchKernelGGL(mlstm_cell_chunk_kernel, dim3((unsigned)nwg), dim3(kThreads), kCellChunkLds, stream, a);
+  if (a.chunk_exact_fp32)
+    hipLaunchKernelGGL(mlstm_cell_chunk_kernel, dim3((unsigned)nwg), dim3(kThreads), kCellChunkLds, stream, a);
+  else
+    hipLaunchKernelGGL(mlstm_cell_chunk3_kernel, dim3((unsigned)nwg), dim3(kThreads), kCell3Lds, stream, a);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 

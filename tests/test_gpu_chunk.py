@@ -111,6 +111,51 @@ def test_chunkwise_prefill_equals_sequential_steps(hip_lib, monkeypatch, L):
         e.close()
 
 
+def test_chunk_lanes_and_the_bf16x3_cell_against_one_chunk_at_a_time_on_the_fp32_matrix_cores(hip_lib, monkeypatch):
+    """lram_prefill of 130 timesteps (7 chunks) at 8 envs, 16M geometry.  Default: two chunks in flight on two streams and two
+    workspaces (block i of chunk c + 1 waits for block i of chunk c), chunk cell as bf16x3.  LRAM_PREFILL_CHUNK=3: one chunk at
+    a time, same kernels -> BIT-identical actions and states, three prefills in a row (a missing dependency between the lanes
+    would show as a difference).  LRAM_PREFILL_CHUNK=2: the cell on the fp32-input matrix cores (exact products): the bf16x3
+    form stays within 2e-6 of it on every state tensor."""
+    from lram_amd.engine import Engine
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=43)
+    B, L = 8, 130
+    seq = make_inputs(spec, B, L, seed=8, reset_prob=0.0)
+    obs_seq = torch.stack([x[0] for x in seq], 1).contiguous().cuda()
+    rtg_seq = torch.stack([x[1] for x in seq], 1).contiguous().cuda()
+    rew_seq = torch.stack([x[2] for x in seq], 1).contiguous().cuda()
+    e_lanes = Engine(spec, sd, B, device="cuda:0")
+    monkeypatch.setenv("LRAM_PREFILL_CHUNK", "3")
+    e_serial = Engine(spec, sd, B, device="cuda:0")
+    monkeypatch.setenv("LRAM_PREFILL_CHUNK", "2")
+    e_fp32 = Engine(spec, sd, B, device="cuda:0")
+    monkeypatch.delenv("LRAM_PREFILL_CHUNK")
+    ones = torch.ones(B, dtype=torch.uint8).cuda()
+    for rep in range(3):
+        mask = ones if rep == 0 else None   # the later prefills continue from the state the first one left
+        a_l, _ = e_lanes.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=mask)
+        a_s, _ = e_serial.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=mask)
+        a_f, _ = e_fp32.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=mask)
+        torch.cuda.synchronize()
+        assert torch.equal(a_l, a_s), rep
+        assert float((a_l - a_f).abs().max()) <= 1e-5, rep
+        for blk in range(spec.n_blocks):
+            kinds = (0, 3) if blk in spec.slstm_at else (0, 1, 2, 3)
+            for which in kinds:
+                t_l = e_lanes.export_state_tensor(blk, which)
+                assert torch.equal(t_l, e_serial.export_state_tensor(blk, which)), (rep, blk, which)
+                assert rel_err(t_l, e_fp32.export_state_tensor(blk, which)) < 2e-6, (rep, blk, which)
+    # a step after the prefill uses the primary workspace again
+    obs, rtg, rew, _ = seq[0]
+    s_l, _ = e_lanes.step(obs.cuda(), rtg.cuda(), rew.cuda(), None)
+    s_s, _ = e_serial.step(obs.cuda(), rtg.cuda(), rew.cuda(), None)
+    torch.cuda.synchronize()
+    assert torch.equal(s_l, s_s)
+    for e in (e_lanes, e_serial, e_fp32):
+        e.close()
+
+
 @pytest.mark.parametrize("scheme", ["reference", "trained_like"])
 def test_chunkwise_prefill_on_the_weight_distributions_the_reference_runs(hip_lib, scheme):
     """lram_prefill (chunkwise kernels: 100 timesteps = 300 tokens in 63-token state passes) on the long-memory weight
