@@ -226,6 +226,9 @@ void launch_embed_scalars(float* x, const float* rtg, const float* rew, int64_t 
                           hipStream_t stream);
 // copy caller-provided state embeddings [B,D] into token slot 0 of x [B,T,D]
 void launch_scatter_token0(float* x, const float* emb, int64_t emb_stride, int B, int T, int D, hipStream_t stream);
+void launch_embed_chunk(float* x, const float* emb, int64_t emb_stride, const float* rtg, const float* rew, int64_t in_stride,
+                        const float* w_rtg, const float* b_rtg, const float* w_rew, const float* b_rew, int B, int steps, int T,
+                        int D, hipStream_t stream);
 // argmax over logits [B, act_dim*n_vocab] (+ de-tokenise)
 void launch_action_argmax(const float* logits, float* actions, int32_t* tokens, int B, int act_dim, int n_vocab,
                           int n_discrete, int action_channels, float tok_min, float tok_max, int discrete,

@@ -174,6 +174,7 @@ struct lram_engine {
   DevBuf XN2;   // the norm output as f16x2 operand planes [2][B*T, D] f16 (pre-split projections): its own buffer -- a slice inside an
                 // sLSTM block uses XN as fp32 while another slice's mLSTM block holds planes
   DevBuf GATES, AMAT, VEC;           // chunkwise mLSTM prefill work buffers (allocated with the first long chunk)
+  DevBuf SEQ_EMB;                    // state embeddings of a stored context [B, L, D] (lram_prefill)
   int tok_cap = 0;                   // tokens per env the activation workspace holds (kMaxTokens until a prefill grows it)
   bool chunk_prefill = true;         // LRAM_PREFILL_CHUNK=0: keep the token-sequential kernels for prefill
   bool chunk_exact_fp32 = false;     // LRAM_PREFILL_CHUNK=2: chunkwise cell on the fp32-input matrix cores (the round 1-5 form)
@@ -182,8 +183,10 @@ struct lram_engine {
   // block apart -- the matrix-core-bound projections of one beside the HBM-bound state passes of the other, and the
   // token-sequential sLSTM launches of either hidden behind both (one env slice only; LRAM_PREFILL_CHUNK=3: off).
   bool chunk_lanes = true;
-  DevBuf twin[18];                   // second copy of the per-token activation workspace (see workspace_set())
-  std::vector<hipEvent_t> lane_ev[2];                     // "block i of the lane's current chunk is done"
+  static constexpr int kMaxLanes = 3;
+  static constexpr int n_lanes = 3;  // chunks in flight (206M, 64 envs x 512 timesteps, same box: 1 lane 385 ms, 2 lanes 326, 3 lanes 305, 4 lanes 303)
+  DevBuf twin[kMaxLanes - 1][18];    // further copies of the per-token activation workspace (see workspace_set())
+  std::vector<hipEvent_t> lane_ev[kMaxLanes];             // "block i of the lane's current chunk is done"
   const std::vector<hipEvent_t>* lane_wait = nullptr;     // set by timesteps_launches around run_stack
   const std::vector<hipEvent_t>* lane_rec = nullptr;
   DevBuf SK;                         // split-K partial slabs: one slot per stream that may run a GEMM
@@ -279,9 +282,10 @@ struct lram_engine {
     lazy_ready = false;
     st.clear();
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
-                      &AMAT, &VEC, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &X0, &U0})
+                      &AMAT, &VEC, &SEQ_EMB, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &X0, &U0})
       b->release();
-    for (DevBuf& b : twin) b.release();
+    for (auto& t : twin)
+      for (DevBuf& b : t) b.release();
     ascale_rows = 0;
     img_cap = 0;
     B = 0;
@@ -607,23 +611,26 @@ std::array<DevBuf*, 18> workspace_set(lram_engine* e) {
   return {&e->X, &e->XN, &e->XN2, &e->HID, &e->U, &e->Q, &e->K, &e->V, &e->XA, &e->H, &e->G, &e->SCAL, &e->RY, &e->GATES,
           &e->AMAT, &e->VEC, &e->AMX_XN, &e->AMX_H};
 }
-void swap_workspace(lram_engine* e) {
+void swap_workspace(lram_engine* e, int lane) {   // lane >= 1: primary <-> that lane's copy
   const auto ws = workspace_set(e);
-  for (size_t i = 0; i < ws.size(); ++i) std::swap(*ws[i], e->twin[i]);
+  for (size_t i = 0; i < ws.size(); ++i) std::swap(*ws[i], e->twin[lane - 1][i]);
 }
 // Second workspace for the chunk lanes, sized like the first; false (no lanes) if the device has no room for it.
 bool twin_ready(lram_engine* e) {
   const auto ws = workspace_set(e);
   bool same = true;
   size_t want = 0;
-  for (size_t i = 0; i < ws.size(); ++i) same = same && e->twin[i].n == ws[i]->n, want += ws[i]->n * sizeof(float);
+  for (int l = 0; l + 1 < e->n_lanes; ++l)
+    for (size_t i = 0; i < ws.size(); ++i) same = same && e->twin[l][i].n == ws[i]->n, want += ws[i]->n * sizeof(float);
   if (same) return true;
   LRAM_HIP_CHECK(hipDeviceSynchronize());
-  for (DevBuf& b : e->twin) b.release();
+  for (auto& t : e->twin)
+    for (DevBuf& b : t) b.release();
   size_t free_b = 0, total_b = 0;
   LRAM_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
   if (want + ((size_t)2 << 30) > free_b) return false;  // keep 2 GiB of headroom
-  for (size_t i = 0; i < ws.size(); ++i) e->twin[i].alloc(ws[i]->n);
+  for (int l = 0; l + 1 < e->n_lanes; ++l)
+    for (size_t i = 0; i < ws.size(); ++i) e->twin[l][i].alloc(ws[i]->n);
   LRAM_HIP_CHECK(hipDeviceSynchronize());
   return true;
 }
@@ -1615,6 +1622,24 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   // up to 21 (63 tokens) through the chunkwise matrix-core kernels (mlstm_chunk.hip).
   const int kChunk = L > 1 ? prefill_chunk_steps(e, L) : 1;
   if (L > 1 || !lazy_active(e, T)) lazy_materialize(e, s);  // stored contexts go through the materialised kernels
+  // Stored contexts: the state embeddings of ALL timesteps as one GEMM ahead of the chunks (rows b * L + l, as the input lies),
+  // instead of one few-row GEMM per timestep (206M, 64 envs x 512 timesteps: 1024 launches of 12-26 us -> 1 + one per chunk)
+  const float* seq_emb = nullptr;
+  if (L > 1 && T == 3 && D % 4 == 0 && shared_passes <= 1) {
+    if (emb) {
+      seq_emb = obs;
+    } else if ((size_t)e->B * L * D <= ((size_t)1 << 29)) {   // <= 2 GiB
+      if (e->SEQ_EMB.n < (size_t)e->B * L * D) {
+        LRAM_HIP_CHECK(hipDeviceSynchronize());
+        e->SEQ_EMB.alloc((size_t)e->B * L * D);
+      }
+      GemmArgs ge;
+      ge.a = obs, ge.lda = c.state_dim, ge.w = e->w_state, ge.ldw = c.state_dim, ge.c = e->SEQ_EMB.p, ge.ldc = D;
+      ge.bias = e->b_state, ge.m = e->B * L, ge.n = D, ge.k = c.state_dim;
+      gemm(e, ge, s);
+      seq_emb = e->SEQ_EMB.p;
+    }
+  }
   hipStream_t hbm;
   const std::vector<Slice> sl = make_slices(e, s, &hbm);
   const bool multi = sl.size() > 1;
@@ -1624,35 +1649,42 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   const int n_chunks = (L + kChunk - 1) / kChunk;
   const bool lanes = !multi && n_chunks >= 2 && kChunk * T > kMaxTokens && e->chunk_lanes && c.backbone == LRAM_BACKBONE_XLSTM &&
                      shared_passes <= 1 && twin_ready(e);
-  hipStream_t lane_s[2] = {s, s};
+  const int NL = lanes ? e->n_lanes : 1;
+  hipStream_t lane_s[lram_engine::kMaxLanes] = {s, s, s};
   if (lanes) {
-    if (e->micro_streams.empty()) {
+    while ((int)e->micro_streams.size() < NL - 1) {
       hipStream_t ns;
       LRAM_HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
       e->micro_streams.push_back(ns);
     }
-    lane_s[1] = e->micro_streams[0];
+    for (int k = 1; k < NL; ++k) lane_s[k] = e->micro_streams[k - 1];
     for (auto& v : e->lane_ev)
       while ((int)v.size() < c.n_blocks) {
         hipEvent_t nev;
         LRAM_HIP_CHECK(hipEventCreateWithFlags(&nev, hipEventDisableTiming | (e->event_device_scope ? hipEventDisableSystemFence : 0u)));
         v.push_back(nev);
       }
-    stream_after(e, lane_s[1], s, true);
+    for (int k = 1; k < NL; ++k) stream_after(e, lane_s[k], s, true);
   }
   int Tc = T, last_steps = 1;
   for (int l = 0, ci = 0; l < L; l += kChunk, ++ci) {
     const int Lc = std::min(kChunk, L - l);
     Tc = T * Lc;
     last_steps = Lc;
-    const int lane = lanes ? ((n_chunks - 1 - ci) & 1) : 0;
+    const int lane = (n_chunks - 1 - ci) % NL;
     const std::vector<Slice> lane_sl = {Slice{0, e->B, lane_s[lane]}};
     const std::vector<Slice>& use = lanes ? lane_sl : sl;
-    if (lane) swap_workspace(e);
+    if (lane) swap_workspace(e, lane);
     for (const Slice& x : use) {
       if (shared_passes > 1 && col_begin > 0) break;  // the tokens of this env-step were embedded by pass 0 (X0 / U0)
       const size_t r0 = (size_t)x.b0 * Tc, b0 = x.b0;
       float* X = e->X.p + r0 * D;
+      if (seq_emb != nullptr) {  // stored context: the chunk's token rows in one launch
+        launch_embed_chunk(X, seq_emb + (b0 * L + l) * D, (int64_t)L * D, rtg + b0 * L + l, rew + b0 * L + l, L, e->w_rtg, e->b_rtg,
+                           e->w_rew, e->b_rew, x.nb, Lc, Tc, D, x.s);
+        launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s);
+        continue;
+      }
       for (int j = 0; j < Lc; ++j) {
         const float* o = obs + (b0 * L + l + j) * obs_w;
         float* Xj = X + (size_t)(T * j) * D;  // token slots 3j .. 3j+2 of every env row group
@@ -1679,12 +1711,12 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
       launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s,
                       (L == 1 && e->B <= kTokenTapMaxBatch) ? e->TOK.p + r0 * D : nullptr, nullptr, stok_on ? &stok : nullptr);
     }
-    if (lanes) e->lane_wait = ci > 0 ? &e->lane_ev[lane ^ 1] : nullptr, e->lane_rec = &e->lane_ev[lane];
+    if (lanes) e->lane_wait = ci > 0 ? &e->lane_ev[(lane + 1) % NL] : nullptr, e->lane_rec = &e->lane_ev[lane];
     run_stack(e, Tc, l == 0 ? reset : nullptr, use, lanes ? lane_s[lane] : hbm);
     e->lane_wait = e->lane_rec = nullptr;
-    if (lane) swap_workspace(e);
+    if (lane) swap_workspace(e, lane);
   }
-  if (lanes) stream_after(e, s, lane_s[1], true);
+  for (int k = 1; k < NL; ++k) stream_after(e, s, lane_s[k], true);
   if (actions != nullptr) {
     const int64_t nlog = (int64_t)c.act_dim * c.n_vocab;
     const int pred = T * (last_steps - 1) + c.pred_token;  // rtg token of the last timestep in the last chunk

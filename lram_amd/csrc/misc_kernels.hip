@@ -182,6 +182,27 @@ __global__ __launch_bounds__(256) void scatter_token0_kernel(float* x, const flo
   x[(int64_t)b * T * D + d] = emb[(int64_t)b * emb_stride + d];
 }
 
+// The (state, rtg, reward) token rows of `steps` consecutive timesteps of every env in one launch (stored contexts): token 0 from the
+// state embeddings emb[b][j][:] (a GEMM over all timesteps, or the caller's own embeddings), tokens 1 / 2 as embed_scalars_kernel.
+__global__ __launch_bounds__(256) void embed_chunk_kernel(float* x, const float* emb, int64_t emb_stride, const float* rtg,
+                                                          const float* rew, int64_t in_stride, const float* w_rtg,
+                                                          const float* b_rtg, const float* w_rew, const float* b_rew, int B,
+                                                          int steps, int T, int D) {
+  const int d4 = D >> 2;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)B * steps * d4) return;
+  const int d = (int)(gid % d4) << 2;
+  const int64_t bj = gid / d4;
+  const int j = (int)(bj % steps), b = (int)(bj / steps);
+  float* row = x + ((int64_t)b * T + 3 * j) * D + d;
+  *reinterpret_cast<float4*>(row) = *reinterpret_cast<const float4*>(emb + (int64_t)b * emb_stride + (int64_t)j * D + d);
+  const float g = rtg[b * in_stride + j], r = rew[b * in_stride + j];
+  const float4 wg = *reinterpret_cast<const float4*>(w_rtg + d), bg = *reinterpret_cast<const float4*>(b_rtg + d);
+  const float4 wr = *reinterpret_cast<const float4*>(w_rew + d), br = *reinterpret_cast<const float4*>(b_rew + d);
+  *reinterpret_cast<float4*>(row + D) = make_float4(g * wg.x + bg.x, g * wg.y + bg.y, g * wg.z + bg.z, g * wg.w + bg.w);
+  *reinterpret_cast<float4*>(row + 2 * D) = make_float4(r * wr.x + br.x, r * wr.y + br.y, r * wr.z + br.z, r * wr.w + br.w);
+}
+
 // One wave per (env, action dim): first index of the maximum (torch.argmax tie rule), then
 // inv_tokenize: max(tok - shift, 0) * ((max - min) / channels) + min.
 __global__ __launch_bounds__(256) void action_argmax_kernel(const float* logits, float* actions, int32_t* tokens,
@@ -358,6 +379,16 @@ void launch_scatter_token0(float* x, const float* emb, int64_t emb_stride, int B
   const int64_t n = (int64_t)B * D;
   hipLaunchKernelGGL(scatter_token0_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, emb,
                      emb_stride, B, T, D);
+  LRAM_HIP_CHECK(hipGetLastError());
+}
+
+void launch_embed_chunk(float* x, const float* emb, int64_t emb_stride, const float* rtg, const float* rew, int64_t in_stride,
+                        const float* w_rtg, const float* b_rtg, const float* w_rew, const float* b_rew, int B, int steps, int T,
+                        int D, hipStream_t stream) {
+  LRAM_REQUIRE(T >= 3 * steps && D % 4 == 0, "embed: 3 token rows per timestep, d_model a multiple of 4");
+  const int64_t n = (int64_t)B * steps * (D >> 2);
+  hipLaunchKernelGGL(embed_chunk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, emb, emb_stride, rtg, rew,
+                     in_stride, w_rtg, b_rtg, w_rew, b_rew, B, steps, T, D);
   LRAM_HIP_CHECK(hipGetLastError());
 }
 
