@@ -1080,6 +1080,7 @@ void mlstm_front(lram_engine* e, int i, int T, const uint8_t* reset, const Slice
                     ps ? amx : nullptr, xn2_kt);
     up.a_amax = amx;
     if (ps) up.a = nullptr, up.a_amax = nullptr, up.a2 = xn2, up.a2_plane = (int64_t)e->XN2.n, up.a2_kt = xn2_kt, up.a2_inv = amx;
+    if (e->lane_rec != nullptr) up.beside_memory_bound = 2;   // a chunk lane of lram_prefill
     gemm(e, up, sl.s);
   }
   if (e->front_multi && lean_front(e, T) && sl.nb >= e->front_min_envs && e->gate_coef[i].p != nullptr &&

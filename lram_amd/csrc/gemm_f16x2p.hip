@@ -429,7 +429,8 @@ void launch_gemm_f16x2p(const GemmArgs& g_in, hipStream_t stream) {
     // ... and where the caller says the launch shares the chip with another slice's memory-bound kernels and covers 0.25-0.63 of
     // the CUs as 256 x 256 tiles (Mamba's in_proj in the two-slice pipeline: 1024 slots +1 %, 2048 +2.8 %; 4096 slots = 288
     // tiles -5 %, hence the upper limit)
-    const bool beside = g.beside_memory_bound != 0 && t256 >= 64 && t256 <= 160 && g.k >= 512;
+    // (2: a chunk of lram_prefill beside the other chunk lanes' state passes -- 206M, 64 envs x 63 tokens = 320 tiles: 308 -> 304 ms per prefill)
+    const bool beside = g.beside_memory_bound != 0 && t256 >= 64 && t256 <= (g.beside_memory_bound == 2 ? 400 : 160) && g.k >= 512;
     if (force == 256 || (force == 0 && (big || beside))) {
       launch_gemm_f16x2_8p(g_in, stream);
       return;
