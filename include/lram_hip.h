@@ -182,7 +182,7 @@ int32_t lram_set_graph_mode(lram_engine* e, int32_t enable);
  *           per env (0 = keep the current period, default 13; the folds of different envs are staggered).  Same
  *           mathematics as recurrent_step_stabilized_simple ([3P]), ~0.6x the HBM bytes of the
  *           materialised update.  Needs an xLSTM head dim that is a multiple of 128.
- *   mode 2 (default): lazy where one block's matrix memory over the batch is at least 512 MiB, else materialised.
+ *   mode 2 (default): lazy where one block's matrix memory over the batch is at least 128 MiB (16M: 128 env slots, 206M: 21), else materialised.
  * lram_state_export / import, lram_prefill, hipGraph mode and calls with more than 4 tokens fold every pending window
  * first, so they always see the reference state layout.  LRAM_STATE=eager|lazy|auto (and LRAM_LAZY_PERIOD) in the
  * environment at lram_create set the initial mode.  lram_profile_end in lazy mode: total_ms includes the fold launches,

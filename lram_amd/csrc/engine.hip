@@ -699,14 +699,16 @@ void lazy_alloc(lram_engine* e) {
   e->lazy_ready = true;
 }
 
-// auto: lazy where the state pass dominates -- one mLSTM block's matrix memory of at least 512 MiB over the batch
-// (16M geometry from 512 env slots, 206M from 82); below that the two extra launches per block cost more than the
-// saved bytes (measured: 16M / 256 envs 174k lazy vs 178k materialised, 64 envs 69k vs 82k).
+// auto: lazy where the state pass dominates -- one mLSTM block's matrix memory of at least 128 MiB over the batch
+// (16M geometry from 128 env slots, 206M from 21); below that the extra launches per block cost more than the saved
+// bytes.  Round 6, one box, lazy vs materialised env-steps/s: 16M at 128 / 256 / 384 envs 151.4k vs 145.4k / 207.2k vs 191.0k /
+// 269.8k vs 233.1k; 206M at 8 / 16 / 32 / 64 envs 3.27k vs 3.69k / 6.00k vs 6.13k / 9.78k vs 9.33k / 12.35k vs 11.21k.
+// (Rounds 2-5 used 512 MiB, from round 2's kernels: 16M at 256 envs 174k lazy vs 178k materialised then.)
 bool lazy_choice(const lram_engine* e) {
   if (e->lazy_mode == 0 || !lazy_geometry_ok(e)) return false;
   if (e->lazy_mode == 1) return true;
   const double dh = e->cfg.inner / e->cfg.n_heads;
-  return (double)e->B * e->cfg.n_heads * dh * dh * 4.0 >= 512.0 * 1024 * 1024;
+  return (double)e->B * e->cfg.n_heads * dh * dh * 4.0 >= 128.0 * 1024 * 1024;
 }
 
 bool lazy_active(const lram_engine* e, int T) {

@@ -142,7 +142,10 @@ def test_auto_mode_picks_lazy_only_where_the_state_pass_dominates(hip_lib):
     small = Engine(spec, sd, 8, device="cuda:0")          # 8 MiB of matrix memory per block: materialised
     assert small.state_mode == "materialised"
     small.close()
-    big = Engine(spec, sd, 512, device="cuda:0")          # 512 MiB per block: lazy
+    mid = Engine(spec, sd, 96, device="cuda:0")           # 96 MiB: still materialised
+    assert mid.state_mode == "materialised"
+    mid.close()
+    big = Engine(spec, sd, 128, device="cuda:0")          # 128 MiB per block: lazy
     assert big.state_mode == "lazy"
     big.set_state_mode("eager")
     assert big.state_mode == "materialised"
