@@ -1677,6 +1677,15 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
     const int lane = (n_chunks - 1 - ci) % NL;
     const std::vector<Slice> lane_sl = {Slice{0, e->B, lane_s[lane]}};
     const std::vector<Slice>& use = lanes ? lane_sl : sl;
+    // (scope guard: an exception out of a launch below must not leave the engine on a lane's workspace or with lane events set)
+    struct LaneScope {
+      lram_engine* e;
+      int lane;
+      ~LaneScope() {
+        e->lane_wait = e->lane_rec = nullptr;
+        if (lane) swap_workspace(e, lane);
+      }
+    } lane_scope{e, lane};
     if (lane) swap_workspace(e, lane);
     for (const Slice& x : use) {
       if (shared_passes > 1 && col_begin > 0) break;  // the tokens of this env-step were embedded by pass 0 (X0 / U0)
@@ -1716,8 +1725,6 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
     }
     if (lanes) e->lane_wait = ci > 0 ? &e->lane_ev[(lane + 1) % NL] : nullptr, e->lane_rec = &e->lane_ev[lane];
     run_stack(e, Tc, l == 0 ? reset : nullptr, use, lanes ? lane_s[lane] : hbm);
-    e->lane_wait = e->lane_rec = nullptr;
-    if (lane) swap_workspace(e, lane);
   }
   for (int k = 1; k < NL; ++k) stream_after(e, s, lane_s[k], true);
   if (actions != nullptr) {

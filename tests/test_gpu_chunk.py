@@ -157,6 +157,34 @@ def test_chunk_lanes_and_the_bf16x3_cell_against_one_chunk_at_a_time_on_the_fp32
         e.close()
 
 
+def test_chunkwise_prefill_over_two_env_slices(hip_lib):
+    """From 512 env slots a stored context goes through the step path's two env slices (no chunk lanes): 600 envs x 25 timesteps =
+    two chunks (13 + 12 timesteps) per slice, token rows of both slices from the one whole-sequence embedding GEMM.  Against 25
+    lram_step calls of a second engine: same actions (a rounding-level tie may flip one in ten thousand), same states."""
+    from lram_amd.engine import Engine
+    spec = preset("xlstm_16m")
+    sd = init_state_dict(spec, seed=44)
+    B, L = 600, 25
+    seq = make_inputs(spec, B, L, seed=9, reset_prob=0.0)
+    obs_seq = torch.stack([x[0] for x in seq], 1).contiguous().cuda()
+    rtg_seq = torch.stack([x[1] for x in seq], 1).contiguous().cuda()
+    rew_seq = torch.stack([x[2] for x in seq], 1).contiguous().cuda()
+    e_step = Engine(spec, sd, B, device="cuda:0")
+    e_pre = Engine(spec, sd, B, device="cuda:0")
+    ones = torch.ones(B, dtype=torch.uint8).cuda()
+    for obs, rtg, rew, _ in seq:
+        a_step, _ = e_step.step(obs.cuda(), rtg.cuda(), rew.cuda(), None)
+    a_pre, _ = e_pre.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=ones)
+    torch.cuda.synchronize()
+    assert float((a_step != a_pre).float().mean()) <= 1e-4
+    for blk in range(spec.n_blocks):
+        kinds = (0, 3) if blk in spec.slstm_at else (0, 1, 2, 3)
+        for which in kinds:
+            assert rel_err(e_pre.export_state_tensor(blk, which), e_step.export_state_tensor(blk, which)) < 1e-4, (blk, which)
+    e_step.close()
+    e_pre.close()
+
+
 @pytest.mark.parametrize("scheme", ["reference", "trained_like"])
 def test_chunkwise_prefill_on_the_weight_distributions_the_reference_runs(hip_lib, scheme):
     """lram_prefill (chunkwise kernels: 100 timesteps = 300 tokens in 63-token state passes) on the long-memory weight
