@@ -157,10 +157,12 @@ def test_chunk_lanes_and_the_bf16x3_cell_against_one_chunk_at_a_time_on_the_fp32
         e.close()
 
 
-def test_chunkwise_prefill_over_two_env_slices(hip_lib):
-    """From 512 env slots a stored context goes through the step path's two env slices (no chunk lanes): 600 envs x 25 timesteps =
-    two chunks (13 + 12 timesteps) per slice, token rows of both slices from the one whole-sequence embedding GEMM.  Against 25
-    lram_step calls of a second engine: same actions (a rounding-level tie may flip one in ten thousand), same states."""
+@pytest.mark.parametrize("micro", [0, 2])
+def test_chunkwise_prefill_at_a_two_slice_batch_size(hip_lib, micro):
+    """600 envs x 25 timesteps = two chunks (13 + 12 timesteps).  micro 0 (automatic): the chunk lanes take the whole batch, where
+    a step would use two env slices; micro 2: two env slices asked for explicitly -> no lanes, both slices' token rows from the one
+    whole-sequence embedding GEMM.  Against 25 lram_step calls of a second engine: same actions (a rounding-level tie may flip one
+    in ten thousand), same states."""
     from lram_amd.engine import Engine
     spec = preset("xlstm_16m")
     sd = init_state_dict(spec, seed=44)
@@ -171,6 +173,7 @@ def test_chunkwise_prefill_over_two_env_slices(hip_lib):
     rew_seq = torch.stack([x[2] for x in seq], 1).contiguous().cuda()
     e_step = Engine(spec, sd, B, device="cuda:0")
     e_pre = Engine(spec, sd, B, device="cuda:0")
+    e_pre.set_micro_batches(micro)
     ones = torch.ones(B, dtype=torch.uint8).cuda()
     for obs, rtg, rew, _ in seq:
         a_step, _ = e_step.step(obs.cuda(), rtg.cuda(), rew.cuda(), None)
