@@ -41,6 +41,9 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+# image observations: lram_step_images (one call) unless LRAM_BENCH_TWO_CALL_IMAGES=1 (lram_embed_images + lram_step: A/B of the two)
+TWO_CALL_IMAGES = os.environ.get("LRAM_BENCH_TWO_CALL_IMAGES", "0") == "1"
+
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s float4 copy measured)
 LAZY_PERIOD = 13        # engine default fold period (lram_set_state_mode)
 
@@ -233,9 +236,11 @@ def _step_leg_run(eng, spec, tag, cfg, B, K, W, dev, ep_len, rtg0, drtg, native,
         eng.set_compat_mode(compat_act_dim, True)
 
     def one(t):
-        if image:
+        if image and TWO_CALL_IMAGES:
             eng.embed_images(frames[t % 2], emb)
             eng.step(emb, rtgs[t], zero, masks[t], discrete=True, obs_is_embedding=True)
+        elif image:
+            eng.step_images(frames[t % 2], rtgs[t], zero, masks[t], discrete=True)
         else:
             eng.step(ring[t % 4], rtgs[t], zero, masks[t])
 
@@ -577,9 +582,11 @@ def main(argv=None, engine_factory=None, device=None):
 
     def one_step(_t=None):
         t = next_t()
-        if img_ring is not None:
+        if img_ring is not None and TWO_CALL_IMAGES:
             eng.embed_images(img_ring[t % n_ring], emb)
             a, _ = eng.step(emb, rtgs[t], reward_tok, masks[t], discrete=True, obs_is_embedding=True)
+        elif img_ring is not None:
+            a, _ = eng.step_images(img_ring[t % n_ring], rtgs[t], reward_tok, masks[t], discrete=True)
         else:
             a, _ = eng.step(obs_ring[t % n_ring], rtgs[t], reward_tok, masks[t])
         if dist_on:

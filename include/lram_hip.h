@@ -296,6 +296,14 @@ int32_t lram_gemm_f16x2_presplit(const float* dev_a, int64_t lda, const float* d
  * lram_prefill with obs_is_embedding = 1. */
 int32_t lram_embed_images(lram_engine* e, const uint8_t* dev_images, int32_t channels, int32_t height, int32_t width,
                           float* dev_embeddings, void* stream);
+/* One env-step from image observations: lram_embed_images + lram_step(obs_is_embedding = 1) as ONE call -- what the reference's
+ * forward does with image states (`compute_inputs`: `state_embeddings = self.embed_image(states / 255)` then the token stack,
+ * online_decision_transformer_model.py:463-530).  Same results as the two calls; the engine runs the CNN per env slice on the
+ * slice's own stream and starts the step's state-pass work that does not depend on the observation (the lazy matrix memory's
+ * folds) beside it.  Frames uint8 [batch, channels, height, width]; other arguments as lram_step. */
+int32_t lram_step_images(lram_engine* e, const uint8_t* dev_images, int32_t channels, int32_t height, int32_t width,
+                         const float* dev_rtg, const float* dev_reward, const uint8_t* dev_reset_mask, int32_t discrete,
+                         float* dev_actions_out, int32_t* dev_tokens_out, void* stream);
 
 /* Observation front end on the device: native obs [batch, n_native] -> model input [batch, state_dim].
  * dev_inv_index == NULL: zero-pad (DecisionXLSTM.pad_inputs, src/algos/decision_xlstm.py:16-19); otherwise

@@ -174,7 +174,13 @@ class RecurrentAgent:
         """observation [B, obs_dim] (or uint8 [B,3,64,64]), returns_to_go [B] -> actions [B, env_act_dim]
         (float32; for discrete agents int64 [B, 1]).  The returned tensor is a view of an engine-owned
         buffer that the next call overwrites."""
-        obs, is_emb = self._prepare_obs(observation)
+        images = observation.dim() == 4
+        if images:   # frames go to the engine as they are: lram_step_images runs the CNN inside the step (per env slice)
+            if not self.has_image_encoder:
+                raise RuntimeError("image observation given but the state dict has no embed_image.* weights")
+            obs, is_emb = observation.to(self.device).to(torch.uint8).contiguous(), True
+        else:
+            obs, is_emb = self._prepare_obs(observation)
         rtg = returns_to_go.to(self.device, torch.float32).reshape(-1).contiguous()
         rew = self._zero_reward if rewards is None else rewards.to(self.device, torch.float32).reshape(-1).contiguous()
         if reset_mask is not None:
@@ -185,7 +191,10 @@ class RecurrentAgent:
             if rep != self._compat_repeat_now:
                 self.engine.set_compat_mode(rep, self.compat_stale_state)
                 self._compat_repeat_now = rep
-        actions, _ = self.engine.step(obs, rtg, rew, reset_mask, discrete=self.is_discrete, obs_is_embedding=is_emb)
+        if images:
+            actions, _ = self.engine.step_images(obs, rtg, rew, reset_mask, discrete=self.is_discrete)
+        else:
+            actions, _ = self.engine.step(obs, rtg, rew, reset_mask, discrete=self.is_discrete, obs_is_embedding=is_emb)
         if self.is_discrete:
             return actions[:, :1].to(torch.int64)
         return actions if env_act_dim is None else actions[:, :env_act_dim]

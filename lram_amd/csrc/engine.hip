@@ -143,6 +143,15 @@ struct lram_engine {
   const float *img_lin_w = nullptr, *img_lin_b = nullptr;
   int img_channels = 0, img_flat = 0;  // input channels, flattened feature count of the linear layer
   DevBuf IMG_P, IMG_X0, IMG_X1, IMG_T;
+  DevBuf IMG_EMB;                      // [B, D] state-token embeddings of lram_step_images
+  // lram_step_images: the frames of the env-step under way (set around step_launches): every env slice runs the IMPALA-CNN on
+  // its own frames on its own stream, and the state-pass stream takes fold_bubbles_images folds ahead of the first read pass --
+  // the VALU-bound CNN and the HBM-bound folds share the start of the step
+  const uint8_t* step_images = nullptr;
+  int step_img_c = 0, step_img_h = 0, step_img_w = 0;
+  // (206M, 512 slots, same box: two calls 31.03k env-steps/s; one call with 2 / 5 / 8 / 11 / 14 folds ahead 31.36k / 31.68k / 31.81k /
+  // 31.65k / 31.31k; the second slice's CNN held back until the first slice's is done: 31.4k -- not kept)
+  static constexpr int fold_bubbles_images = 8;
   size_t img_cap = 0;  // batch * input pixels the image buffers were sized for
   // lazy matrix memory: C_base read once per step, rewritten once per `lazy_period` steps (see mlstm_lazy.hip)
   int lazy_mode = 2;        // 0 materialised, 1 lazy, 2 auto (LRAM_STATE / lram_set_state_mode)
@@ -282,7 +291,7 @@ struct lram_engine {
     lazy_ready = false;
     st.clear();
     for (DevBuf* b : {&X, &XN, &TOK, &HID, &U, &Q, &K, &V, &XA, &H, &G, &SCAL, &RY, &LOGITS, &RES, &DTP, &SK, &GATES,
-                      &AMAT, &VEC, &SEQ_EMB, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &X0, &U0})
+                      &AMAT, &VEC, &SEQ_EMB, &IMG_EMB, &IMG_P, &IMG_X0, &IMG_X1, &IMG_T, &XN2, &ASCALE, &AMX_XN, &AMX_XA, &AMX_H, &X0, &U0})
       b->release();
     for (auto& t : twin)
       for (DevBuf& b : t) b.release();
@@ -1372,7 +1381,8 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   };
   if (bubbles) {
     int k = 0;
-    for (int i = next_mlstm(-1); i >= 0 && k < lram_engine::fold_bubbles; i = next_mlstm(i), ++k) launch_folds(i);
+    const int ahead = e->step_images != nullptr ? e->fold_bubbles_images : lram_engine::fold_bubbles;
+    for (int i = next_mlstm(-1); i >= 0 && k < ahead; i = next_mlstm(i), ++k) launch_folds(i);
   }
   for (int i = 0; i < c.n_blocks; ++i) {
     if (i > 0 && e->lane_rec) LRAM_HIP_CHECK(hipEventRecord((*e->lane_rec)[i - 1], sl[0].s));   // (chunk lanes: one slice, one stream)
@@ -1563,23 +1573,34 @@ void run_stack(lram_engine* e, int T, const uint8_t* reset, const std::vector<Sl
 
 // uint8 frames [B, C, H, W] -> state-token embeddings [B, d_model] (reference: embed_image(x / 255),
 // online_decision_transformer_model.py:523-526 + image_encoders.py:58-66)
-void embed_images(lram_engine* e, const uint8_t* images, int C, int H, int W, float* out, hipStream_t s) {
+// Image work buffers for B frames of H x W (synchronises when it has to grow them: never called between a fork and a join)
+void image_buffers(lram_engine* e, int H, int W) {
+  const size_t B = e->B, px = B * H * W;
+  if (px <= e->img_cap) return;
+  LRAM_HIP_CHECK(hipDeviceSynchronize());
+  const size_t hp = (H - 1) / 2 + 1, wp = (W - 1) / 2 + 1;
+  e->IMG_P.alloc(B * 16 * H * W);       // stage-1 conv output before its pool (the largest tensor)
+  e->IMG_X0.alloc(B * 32 * hp * wp);    // pooled maps never exceed 32 channels at half resolution
+  e->IMG_X1.alloc(B * 32 * hp * wp);
+  e->IMG_T.alloc(B * 32 * hp * wp);
+  e->img_cap = px;
+}
+
+// envs b0 .. b0 + nb - 1 (`images` / `out` point at env b0's frame / row; every env slice keeps to its own fixed region of the
+// work buffers, so slices at different stages of the CNN never touch each other's maps)
+void embed_images(lram_engine* e, const uint8_t* images, int C, int H, int W, float* out, hipStream_t s, int b0 = 0, int nb = -1) {
   LRAM_REQUIRE(e->img_lin_w != nullptr, "lram_embed_images: no embed_image.* weights were uploaded");
   LRAM_REQUIRE(C == e->img_channels, "lram_embed_images: channel count does not match embed_image.cnn.0.conv.weight");
-  const int B = e->B, D = e->cfg.d_model;
+  const int B = nb < 0 ? e->B : nb, D = e->cfg.d_model;
   int h = H, w = W;
   for (int k = 0; k < 3; ++k) h = (h - 1) / 2 + 1, w = (w - 1) / 2 + 1;
   LRAM_REQUIRE(32 * h * w == e->img_flat, "lram_embed_images: image size does not match embed_image.linear.0.weight");
-  const size_t px = (size_t)B * H * W;
-  if (px > e->img_cap) {
-    LRAM_HIP_CHECK(hipDeviceSynchronize());
-    const size_t hp = (H - 1) / 2 + 1, wp = (W - 1) / 2 + 1;
-    e->IMG_P.alloc((size_t)B * 16 * H * W);       // stage-1 conv output before its pool (the largest tensor)
-    e->IMG_X0.alloc((size_t)B * 32 * hp * wp);    // pooled maps never exceed 32 channels at half resolution
-    e->IMG_X1.alloc((size_t)B * 32 * hp * wp);
-    e->IMG_T.alloc((size_t)B * 32 * hp * wp);
-    e->img_cap = px;
-  }
+  LRAM_REQUIRE((size_t)e->B * H * W <= e->img_cap, "image work buffers not allocated");
+  const size_t hp0 = (H - 1) / 2 + 1, wp0 = (W - 1) / 2 + 1;
+  float* const P = e->IMG_P.p + (size_t)b0 * 16 * H * W;
+  float* const X0 = e->IMG_X0.p + (size_t)b0 * 32 * hp0 * wp0;
+  float* const X1 = e->IMG_X1.p + (size_t)b0 * 32 * hp0 * wp0;
+  float* const Tb = e->IMG_T.p + (size_t)b0 * 32 * hp0 * wp0;
   const void* in = images;
   int in_u8 = 1;
   h = H, w = W;
@@ -1592,19 +1613,19 @@ void embed_images(lram_engine* e, const uint8_t* images, int C, int H, int W, fl
       a.B = B, a.CIN = c.cin, a.COUT = c.cout, a.H = h, a.W = w, a.in_relu = relu_in, a.out_relu = relu_out, a.in_u8 = u8;
       launch_conv3x3(a, s);
     };
-    conv(cv[0], in, in_u8, 0, nullptr, e->IMG_P.p, 0);
-    launch_maxpool3s2(e->IMG_P.p, e->IMG_X0.p, (int64_t)B * cv[0].cout, h, w, s);
+    conv(cv[0], in, in_u8, 0, nullptr, P, 0);
+    launch_maxpool3s2(P, X0, (int64_t)B * cv[0].cout, h, w, s);
     h = (h - 1) / 2 + 1, w = (w - 1) / 2 + 1;
-    conv(cv[1], e->IMG_X0.p, 0, 1, nullptr, e->IMG_T.p, 0);
-    conv(cv[2], e->IMG_T.p, 0, 1, e->IMG_X0.p, e->IMG_X1.p, 0);
-    conv(cv[3], e->IMG_X1.p, 0, 1, nullptr, e->IMG_T.p, 0);
-    conv(cv[4], e->IMG_T.p, 0, 1, e->IMG_X1.p, e->IMG_X0.p, sidx == 2 ? 1 : 0);  // act_flatten's ReLU on the last map
-    in = e->IMG_X0.p;
+    conv(cv[1], X0, 0, 1, nullptr, Tb, 0);
+    conv(cv[2], Tb, 0, 1, X0, X1, 0);
+    conv(cv[3], X1, 0, 1, nullptr, Tb, 0);
+    conv(cv[4], Tb, 0, 1, X1, X0, sidx == 2 ? 1 : 0);  // act_flatten's ReLU on the last map
+    in = X0;
     in_u8 = 0;
   }
-  // stage s > 0 reads IMG_X0 and writes IMG_P, then pools back into IMG_X0: no aliasing within a launch
+  // stage s > 0 reads X0 and writes P, then pools back into X0: no aliasing within a launch
   GemmArgs g;
-  g.a = e->IMG_X0.p, g.lda = e->img_flat, g.w = e->img_lin_w, g.ldw = e->img_flat, g.c = out, g.ldc = D;
+  g.a = X0, g.lda = e->img_flat, g.w = e->img_lin_w, g.ldw = e->img_flat, g.c = out, g.ldc = D;
   g.bias = e->img_lin_b, g.m = B, g.n = D, g.k = e->img_flat;
   gemm(e, g, s);
   launch_relu(out, (int64_t)B * D, s);
@@ -1698,6 +1719,9 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
         launch_row_norm(X, D, X, D, e->eln_g, e->eln_b, x.nb * Tc, D, 1e-5f, 0, x.s);
         continue;
       }
+      if (e->step_images != nullptr)   // lram_step_images: this slice's frames -> its rows of `obs` (= IMG_EMB), on its own stream
+        embed_images(e, e->step_images + b0 * e->step_img_c * e->step_img_h * e->step_img_w, e->step_img_c, e->step_img_h,
+                     e->step_img_w, e->IMG_EMB.p + b0 * D, x.s, (int)b0, x.nb);
       for (int j = 0; j < Lc; ++j) {
         const float* o = obs + (b0 * L + l + j) * obs_w;
         float* Xj = X + (size_t)(T * j) * D;  // token slots 3j .. 3j+2 of every env row group
@@ -1988,6 +2012,34 @@ int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding
       step_launches(e, dev_obs, obs_is_embedding, dev_rtg, dev_reward, dev_reset_mask, discrete, dev_actions,
                     dev_tokens, s);
     }
+  });
+}
+
+int32_t lram_step_images(lram_engine* e, const uint8_t* dev_images, int32_t channels, int32_t height, int32_t width,
+                         const float* dev_rtg, const float* dev_reward, const uint8_t* dev_reset_mask, int32_t discrete,
+                         float* dev_actions, int32_t* dev_tokens, void* stream) {
+  return guarded([&] {
+    LRAM_REQUIRE(e && e->B > 0, "lram_step_images: state not allocated (call lram_state_alloc)");
+    LRAM_REQUIRE(dev_images && dev_rtg && dev_reward && dev_actions && channels > 0 && height > 0 && width > 0,
+                 "lram_step_images: bad argument");
+    LRAM_REQUIRE(e->cfg.tokens_per_step == 3, "lram_step_images: the (state, rtg, reward) front end needs tokens_per_step == 3");
+    LRAM_REQUIRE(e->img_lin_w != nullptr, "lram_step_images: no embed_image.* weights were uploaded");
+    LRAM_HIP_CHECK(hipSetDevice(e->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    image_buffers(e, height, width);
+    if (e->IMG_EMB.n < (size_t)e->B * e->cfg.d_model) {
+      LRAM_HIP_CHECK(hipDeviceSynchronize());
+      e->IMG_EMB.alloc((size_t)e->B * e->cfg.d_model);
+    }
+    compat_prepare(e, discrete);
+    prof_tick(e);
+    struct Scope {   // (the frames belong to this call only)
+      lram_engine* e;
+      ~Scope() { e->step_images = nullptr; }
+    } scope{e};
+    e->step_images = dev_images, e->step_img_c = channels, e->step_img_h = height, e->step_img_w = width;
+    // (launch-per-kernel path also in graph mode: a captured step would pin one frame buffer)
+    step_launches(e, e->IMG_EMB.p, 1, dev_rtg, dev_reward, dev_reset_mask, discrete, dev_actions, dev_tokens, s);
   });
 }
 
@@ -2441,6 +2493,7 @@ int32_t lram_embed_images(lram_engine* e, const uint8_t* dev_images, int32_t cha
     LRAM_REQUIRE(e && e->B > 0, "lram_embed_images: state not allocated (call lram_state_alloc)");
     LRAM_REQUIRE(dev_images && dev_embeddings && channels > 0 && height > 0 && width > 0, "lram_embed_images: bad argument");
     LRAM_HIP_CHECK(hipSetDevice(e->device));
+    image_buffers(e, height, width);
     embed_images(e, dev_images, channels, height, width, dev_embeddings, static_cast<hipStream_t>(stream));
   });
 }

@@ -81,6 +81,8 @@ _SYMBOLS = {
     "lram_gemm_f16x2_presplit": (ctypes.c_int32, [_VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _VP,
                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP]),
     "lram_embed_images": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
+    "lram_step_images": (ctypes.c_int32, [_VP, _VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _VP, _VP, _VP, ctypes.c_int32,
+                         _VP, _VP, _VP]),
     "lram_set_state_mode": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32]),
     "lram_get_state_mode": (ctypes.c_int32, [_VP]),
     "lram_lazy_peek": (ctypes.c_int32, [_VP, ctypes.c_int32, ctypes.c_int32, _VP, _VP]),
@@ -286,6 +288,29 @@ class Engine:
         _check(self.lib, self.lib.lram_embed_images(self._h, _ptr(images), int(images.shape[1]), int(images.shape[2]),
                                                     int(images.shape[3]), _ptr(out), _stream_ptr(self.device)))
         return out
+
+    def step_images(self, images: torch.Tensor, rtg: torch.Tensor, reward: torch.Tensor,
+                    reset_mask: Optional[torch.Tensor] = None, discrete: bool = False,
+                    out_actions: Optional[torch.Tensor] = None, out_tokens: Optional[torch.Tensor] = None):
+        """One env-step from uint8 frames [B, C, H, W]: embed_images + step(obs_is_embedding=True) as one call (the reference's
+        forward embeds image states inside `compute_inputs`, online_decision_transformer_model.py:463-530).  Same results as the two
+        calls; the CNN runs per env slice beside the step's observation-independent state-pass work."""
+        B, spec = self.batch, self.spec
+        if images.dim() != 4:
+            raise ValueError("images must be [B, C, H, W]")
+        _chk_dev(images, torch.uint8, (B, *images.shape[1:]), self.device, "images")
+        _chk_dev(rtg, torch.float32, (B,), self.device, "rtg")
+        _chk_dev(reward, torch.float32, (B,), self.device, "reward")
+        if reset_mask is not None:
+            _chk_dev(reset_mask, torch.uint8, (B,), self.device, "reset_mask")
+        actions = self._actions if out_actions is None else out_actions
+        tokens = self._tokens if out_tokens is None else out_tokens
+        _chk_dev(actions, torch.float32, (B, spec.act_dim), self.device, "out_actions")
+        _chk_dev(tokens, torch.int32, (B, spec.act_dim), self.device, "out_tokens")
+        _check(self.lib, self.lib.lram_step_images(self._h, _ptr(images), int(images.shape[1]), int(images.shape[2]),
+                                                   int(images.shape[3]), _ptr(rtg), _ptr(reward), _ptr(reset_mask),
+                                                   int(discrete), _ptr(actions), _ptr(tokens), _stream_ptr(self.device)))
+        return actions, tokens
 
     def encoder_step(self, inputs_embeds: torch.Tensor, reset_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`self.encoder(inputs_embeds=[B,T,D], use_cache=True)` plug point (decision_xlstm.py:138-169)."""

@@ -44,7 +44,7 @@ def _inputs(spec, B, steps, seed, image=False, reset_every=0):
     return seq
 
 
-def _run(spec, sd, seq, discrete=False, order=None, sub=None, micro=None, want_state=None):
+def _run(spec, sd, seq, discrete=False, order=None, sub=None, micro=None, want_state=None, one_call_images=False):
     """One engine over the whole sequence; returns actions [steps, n, A], hidden of the last step, logits of the last
     step and the requested state tensors."""
     from lram_amd.engine import Engine
@@ -59,7 +59,9 @@ def _run(spec, sd, seq, discrete=False, order=None, sub=None, micro=None, want_s
         if sub is not None:
             x = [v[sub].contiguous() for v in x]
         obs, rtg, rew, mask = [v.cuda() for v in x]
-        if emb is not None:
+        if emb is not None and one_call_images:
+            a, _ = eng.step_images(obs, rtg, rew, mask, discrete=True)
+        elif emb is not None:
             eng.embed_images(obs, emb)
             a, _ = eng.step(emb, rtg, rew, mask, discrete=True, obs_is_embedding=True)
         else:
@@ -172,6 +174,19 @@ def test_c4_206m_at_512_slots_uint8_frames(hip_lib, scheme):
     assert int(base["acts"][..., 0].max()) < 18
     again = _run(spec, sd, seq, discrete=True)
     assert torch.equal(base["acts"], again["acts"])
+    # lram_step_images: the CNN per env slice on the slices' streams, more folds ahead of the first read pass -- same kernels on the
+    # same data: bit-identical actions, hidden states and logits
+    # -- with ONE env slice the same launches on the same data: bit-identical; with the default two slices the image Linear
+    # runs as two 256-row launches instead of one of 512 rows (another split of its K = 2048 sum): same actions, hidden states
+    # to fp32 rounding through 20 blocks
+    one = _run(spec, sd, seq, discrete=True, one_call_images=True)
+    assert torch.equal(base["acts"], one["acts"])
+    assert rel_err(one["hidden"], base["hidden"]) < 1e-3 and rel_err(one["logits"], base["logits"]) < 1e-3
+    if scheme == "exercise":
+        two1 = _run(spec, sd, seq, discrete=True, micro=1)
+        one1 = _run(spec, sd, seq, discrete=True, micro=1, one_call_images=True)
+        assert torch.equal(two1["acts"], one1["acts"])
+        assert torch.equal(two1["hidden"], one1["hidden"]) and torch.equal(two1["logits"], one1["logits"])
 
 
 def test_c2_16m_at_1024_slots(hip_lib):
