@@ -201,7 +201,8 @@ int32_t lram_lazy_peek(lram_engine* e, int32_t block, int32_t which, float* dev_
 
 /* Micro-batch pipeline (xLSTM): the env slots are processed as `n` slices on engine-owned HIP streams; the
  * HBM-bound matrix-memory kernels of all slices run back to back on one stream while the other slices'
- * fp32-MFMA projections overlap them.  n = 1 disables it, 0 = automatic (2 slices from 512 env slots), max 8.
+ * fp32-MFMA projections overlap them.  n = 1 disables it, 0 = automatic (2 slices where one mLSTM block's matrix memory over the batch reaches 512 MiB -- 16M from 512 env slots,
+ * 206M from 82 -- and for Mamba from 1024 env slots), max 8.
  * Results do not depend on n (envs are independent). */
 int32_t lram_set_micro_batches(lram_engine* e, int32_t n);
 

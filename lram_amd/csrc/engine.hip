@@ -97,7 +97,7 @@ struct lram_engine {
   // f16x2 projection kernel (gemm_f16x2.hip): un-batched weights also get two row-scaled f16 planes + inverse scales;
   // LRAM_GEMM=bf16x3 keeps the three-plane bf16 kernel for them too
   bool use_f16x2 = true;
-  int f16x2_min_rows = 1024;  // LRAM_F16_MIN_ROWS
+  int f16x2_min_rows = 256;   // LRAM_F16_MIN_ROWS
   struct Split16 {
     uint16_t* planes;  // [2][rows][k] f16
     float* inv;        // [rows] exact inverse of each weight row's power-of-two scale
@@ -831,12 +831,13 @@ void count_gemm(lram_engine* e, int family, const GemmArgs& g) {
 }
 
 // ---- which projections take the f16x2 kernels: ONE predicate for the dispatcher and for the producers of the operands ------
-// Row threshold: from 1024 rows -- below that a step is launch-bound (16M at 32 envs 0.66 ms on bf16x3, 0.83 ms with the f16x2
-// kernel's extra row-maximum launches) and the three-workgroups-per-CU advantage needs a grid that fills the chip; wide
-// weights -- the 206M stack's 5120 x 1280 / 1280 x 2560 -- pay from 512 rows (206M at 512 slots runs 768-row slices, 28.1k
-// env-steps/s on bf16x3 vs 29.5k on f16x2).
+// Row threshold: from 256 rows, wide weights -- the 206M stack's 5120 x 1280 / 1280 x 2560 -- from 96.  (Rounds 3-5: 1024 / 512, from
+// the time the f16x2 kernels needed a row-maximum launch per projection; the producers hand the maxima over since round 5.)
+// Round 6, one box, one env slice, env-steps/s with the old / new thresholds: 206M at 64 / 128 / 256 envs 12.4k / 17.9k / 24.8k ->
+// 15.0k / 21.1k / 25.1k; Mamba-48M at 128 / 256 envs 84.2k / 149.6k -> 99.2k / 178.7k; 16M at 64 / 128 / 256 envs 95.8k / 150.6k /
+// 207.4k -> 95.8k / 151.7k / 219.5k (16M at 64 envs = 192 rows on f16x2: 94.0k, hence 256 for the narrow weights).
 bool f16x2_rows(const lram_engine* e, int rows, int n, int k) {
-  return e->use_f16x2 && (rows >= e->f16x2_min_rows || (rows >= 512 && (int64_t)n * k >= 2500000));
+  return e->use_f16x2 && (rows >= e->f16x2_min_rows || (rows >= 96 && (int64_t)n * k >= 2500000));
 }
 // The f16 planes of the weight tensor that contains w (a GEMM may address a row range of a weight: proj_up's halves): fills the
 // operand fields of g and returns true when w starts on a whole row of a split weight whose K equals ldw.
@@ -1006,8 +1007,19 @@ void stream_after(lram_engine* e, hipStream_t dst, hipStream_t src, bool boundar
 // engine-owned streams plus one stream that serialises the HBM-bound cell kernels (see run_xlstm_stack).
 std::vector<Slice> make_slices(lram_engine* e, hipStream_t s, hipStream_t* hbm) {
   int n = e->n_micro;
-  if (n == 0) n = e->B >= 512 ? 2 : 1;  // auto
-  if (e->cfg.backbone == LRAM_BACKBONE_MAMBA && e->n_micro == 0) n = std::min(n, 2);
+  if (n == 0) {
+    // auto: two slices where the second one has something long to hide behind.  xLSTM: one mLSTM block's matrix memory over the
+    // batch of at least 512 MiB (16M from 512 env slots, 206M from 82); Mamba: from 1024 env slots.  Round 6, one box, one vs two
+    // slices, env-steps/s: 206M at 64 / 96 / 128 / 256 envs 15.1k vs 14.9k / 18.5k vs 18.5k / 21.1k vs 21.6k / 25.1k vs 29.1k
+    // (rounds 2-5 split from 512 envs only); 16M at 256 / 512 / 640 envs 219.8k vs 194.1k / 296.2k vs 297.1k / 304.8k vs 314.1k;
+    // Mamba-48M at 512 / 768 / 1024 / 1536 envs 288.6k vs 275.0k / 380.4k vs 367.7k / 410.5k vs 416.9k / 432.8k vs 479.4k.
+    if (e->cfg.backbone == LRAM_BACKBONE_MAMBA) {
+      n = e->B >= 1024 ? 2 : 1;
+    } else {
+      const double dh = e->cfg.n_heads > 0 ? (double)e->cfg.inner / e->cfg.n_heads : 0.0;
+      n = (double)e->B * e->cfg.n_heads * dh * dh * 4.0 >= 512.0 * 1024 * 1024 ? 2 : 1;
+    }
+  }
   if (e->graph_mode) n = 1;  // graph replay targets small, launch-bound batches: one slice, one stream
   n = std::max(1, std::min(n, std::min(e->B, 8)));
   *hbm = s;

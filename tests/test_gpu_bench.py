@@ -16,10 +16,11 @@ def test_bench_line_contract_and_physical_roofline(hip_lib, capsys):
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2 and out["vs_baseline"] is None
     assert out["config"]["state_mode"] == "lazy"
     # the workload line names the projection kernel that actually served most of the FLOPs (engine dispatch counters), not
-    # the LRAM_GEMM default: at 512 env slots the slices hold 768 operand rows, below the f16x2 kernel's 1024-row threshold
+    # the LRAM_GEMM default: at 512 env slots the two slices hold 768 operand rows each, above the f16x2 kernels' 256-row
+    # threshold (1024 until round 6: bf16x3 then) -- and LRAM_F16_MIN_ROWS=2048 puts the same run on bf16x3
     disp = out["gemm_dispatch_per_step"]
     main = max(disp, key=lambda k: disp[k]["gflop"])
-    assert main == "bf16x3" and "bf16x3" in out["config"]["workload"] and disp[main]["launches"] > 0
+    assert main == "f16x2" and "f16x2" in out["config"]["workload"] and disp[main]["launches"] > 0
     assert out["ranks_seen"] == 1
     assert abs(out["value"] - 512 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
     r = out["roofline"]

@@ -124,7 +124,12 @@ def _run_xlstm(mode, slots, where, case="xlstm", scheme="exercise"):
                 nn = eng.export_state_tensor(i, 1)[where].squeeze(-1)
                 n_hi = max(n_hi, float(nn.abs().max()))
                 close(nn, f"{tag}_b{i}_n", f"{name} {tag} block {i} n")
-                assert rel_err(eng.export_state_tensor(i, 2)[where], fx[f"{tag}_b{i}_m"]) < 1e-4, (tag, i)
+                # (the stabiliser: 1e-4 on the well-conditioned distributions; the long-memory one -- gate pre-activations of +-10 ...
+                # +-16 on an observation with a x 30 outlier channel -- gets the bar every other tensor has, 2e-4 or the float64 rule)
+                if scheme == "trained_like":
+                    close(eng.export_state_tensor(i, 2)[where].reshape(fx[f"{tag}_b{i}_m"].shape), f"{tag}_b{i}_m", f"{name} {tag} block {i} m")
+                else:
+                    assert rel_err(eng.export_state_tensor(i, 2)[where], fx[f"{tag}_b{i}_m"]) < 1e-4, (tag, i)
                 close(eng.export_state_tensor(i, 3)[where], f"{tag}_b{i}_conv", f"{name} {tag} block {i} conv")
             close(eng.export_state_tensor(c["slstm"], 0)[:, where], f"{tag}_b{c['slstm']}_slstm", f"{name} {tag} sLSTM state")
     frac = relaxed_rows_fraction()
