@@ -831,13 +831,16 @@ void count_gemm(lram_engine* e, int family, const GemmArgs& g) {
 }
 
 // ---- which projections take the f16x2 kernels: ONE predicate for the dispatcher and for the producers of the operands ------
-// Row threshold: from 256 rows, wide weights -- the 206M stack's 5120 x 1280 / 1280 x 2560 -- from 96.  (Rounds 3-5: 1024 / 512, from
+// Row threshold: from 256 rows, wider weights earlier (below).  (Rounds 3-5: 1024 / 512, from
 // the time the f16x2 kernels needed a row-maximum launch per projection; the producers hand the maxima over since round 5.)
 // Round 6, one box, one env slice, env-steps/s with the old / new thresholds: 206M at 64 / 128 / 256 envs 12.4k / 17.9k / 24.8k ->
 // 15.0k / 21.1k / 25.1k; Mamba-48M at 128 / 256 envs 84.2k / 149.6k -> 99.2k / 178.7k; 16M at 64 / 128 / 256 envs 95.8k / 150.6k /
 // 207.4k -> 95.8k / 151.7k / 219.5k (16M at 64 envs = 192 rows on f16x2: 94.0k, hence 256 for the narrow weights).
+// Below 256 rows by weight size: >= 2.5 M elements (206M stack) from 48 rows (206M at 16 envs 6.13k -> 6.65k), >= 1.1 M (Mamba-48M's
+// in_proj / out_proj; not the 16M stack's 2048 x 512) from 96 (Mamba-48M at 32 / 64 envs 37.4k / 50.7k -> 40.1k / 52.7k).
 bool f16x2_rows(const lram_engine* e, int rows, int n, int k) {
-  return e->use_f16x2 && (rows >= e->f16x2_min_rows || (rows >= 96 && (int64_t)n * k >= 2500000));
+  const int64_t nk = (int64_t)n * k;
+  return e->use_f16x2 && (rows >= e->f16x2_min_rows || (rows >= 96 && nk >= 1100000) || (rows >= 48 && nk >= 2500000));
 }
 // The f16 planes of the weight tensor that contains w (a GEMM may address a row range of a weight: proj_up's halves): fills the
 // operand fields of g and returns true when w starts on a whole row of a split weight whose K equals ldw.
