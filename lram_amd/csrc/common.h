@@ -371,7 +371,12 @@ struct GroupNormArgs {
   float* out;          // mode 0: g [rows, NH*DH]; mode 1: x [rows, NH*DH] (+=)
   int rows, NH, DH, mode;
   float eps;
-  float* amax = nullptr;  // mode 0, optional: [rows, NH] max |out| of the (row, head) segment (partial row maxima for the f16x2 GEMM)
+  float* amax = nullptr;  // mode 0, optional: [rows, NH] max |out| of the (row, head) segment (partial row maxima for the f16x2 GEMM)  // mode 0, optional: the output as the pre-split f16x2 GEMM's A operand instead of fp32 -- two f16 planes, K-tile-major
+  // [inner / 32][rows][32] with K-tile pitch h2_kt elements, the lo plane h2_plane elements after the hi plane, of the row scaled by
+  // pow2_scale(row maximum over ALL heads); h2_inv[row] = the exact inverse scale.  One workgroup per row (NH waves).
+  uint16_t* h2 = nullptr;
+  int64_t h2_plane = 0, h2_kt = 0;
+  float* h2_inv = nullptr;
 };
 void launch_group_norm(const GroupNormArgs& a, hipStream_t stream);
 

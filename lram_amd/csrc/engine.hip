@@ -119,6 +119,8 @@ struct lram_engine {
   bool slstm_gates_one = true;    // LRAM_SLSTM_GATES_ONE=0: the four sLSTM gate projections of larger slices as four bf16x3 launches
   bool gemm_narrow_f16 = true;    // LRAM_GEMM_NARROW=2: its exact-fp32 form even where the projections run as f16x2
   bool gn_amax_handover = true;   // LRAM_GN_AMAX=0: proj_down's operand row maxima from their own launch, not from the group norm
+  bool gn_planes = true;          // LRAM_GN_AMAX=1: the group norm writes fp32 + partial row maxima (round 5) instead of proj_down's operand planes
+  int xlstm_slices_now = 1;       // env slices of the stack pass under way (set by run_xlstm_stack)
   bool slstm_seq_f32 = false;     // LRAM_SLSTM_SEQ=2: its exact-fp32 form even where the projections run as f16x2
   bool slstm_seq = true;          // LRAM_SLSTM_SEQ=0: per-token recurrent GEMM + pointwise launches for slices beyond the token kernel's
   std::vector<DevBuf> gate_coef;  // mLSTM: folded i / f gate coefficients per block (mlstm_front.hip), geometries it covers
@@ -1206,12 +1208,29 @@ void mlstm_back(lram_engine* e, int i, int T, const Slice& sl) {
   // (LRAM_GN_AMAX=0, test switch: the standalone row-maximum launch instead; bit-identical by construction -- a maximum of
   // partial maxima is exact -- and tests/test_gpu_realbatch.py holds it to that)
   const bool hand_over = e->gn_amax_handover && e->AMX_H.p != nullptr && f16x2_rows(e, rows, D, inner);
-  ga.amax = hand_over ? e->AMX_H.p + r0 * NH : nullptr;
-  launch_group_norm(ga, sl.s);
   GemmArgs dn;
   dn.a = e->G.p + r0 * e->icols, dn.lda = inner, dn.w = w.proj_down, dn.ldw = inner, dn.c = X, dn.ldc = D, dn.residual = X;
   dn.m = rows, dn.n = D, dn.k = inner;
-  if (hand_over) dn.a_amax = ga.amax, dn.amax_parts = NH;
+  // ... or (round 6; one env slice: stored contexts, small and mid-size batches) the norm writes proj_down's operand itself: the two
+  // f16 planes of the row scaled by its maximum over all heads -- the same 4 bytes per element as the fp32 row, into G's memory --
+  // and the projection runs on the pre-split kernel (LDS-DMA staging, no conversion in its loop: 15-28 % faster on every
+  // down-projection shape alone, profiles/r06_gemm_durations.txt).  Bit-identical to the hand-over path.  Same box, hand-over vs
+  // planes: C5's prefill 297.9 -> 292.0 ms, 206M at 64 envs 14.98k -> 15.18k env-steps/s; NOT inside the two-slice pipelines, where
+  // the pre-split kernel's 48 KB workgroups wait for the other slice's read pass to leave a CU: 16M at 1024 slots 378.6k -> 368.8k,
+  // 206M at 512 slots +-0.
+  const int64_t bt = (int64_t)(e->G.n / e->icols);   // rows the workspace holds
+  GemmArgs probe;
+  const bool planes = hand_over && e->gn_planes && e->xlstm_slices_now == 1 && e->gemm_presplit && NH <= 8 && (inner & 31) == 0 && bt * inner * 4 < (1ll << 31) &&
+                      f16x2_weight(e, w.proj_down, inner, &probe) && 4 * probe.w2_plane < (1ll << 31);
+  if (planes) {
+    ga.out = nullptr;
+    ga.h2 = reinterpret_cast<uint16_t*>(e->G.p) + r0 * 32, ga.h2_plane = bt * inner, ga.h2_kt = bt * 32, ga.h2_inv = e->AMX_H.p + r0;
+    dn.a = nullptr, dn.a2 = ga.h2, dn.a2_plane = ga.h2_plane, dn.a2_kt = ga.h2_kt, dn.a2_inv = ga.h2_inv;
+  } else {
+    ga.amax = hand_over ? e->AMX_H.p + r0 * NH : nullptr;
+    if (hand_over) dn.a_amax = ga.amax, dn.amax_parts = NH;
+  }
+  launch_group_norm(ga, sl.s);
   gemm(e, dn, sl.s);
 }
 
@@ -1354,6 +1373,7 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   const lram_config& c = e->cfg;
   const int D = c.d_model;
   const bool lazy = lazy_active(e, T);
+  e->xlstm_slices_now = (int)sl.size();
   if (lazy) {
     // Upper bound of pending tokens per fold class (env index mod period), tracked on the host: while no class can
     // overflow its window before its turn, the fold launch only covers the envs whose turn it is.
@@ -1891,7 +1911,7 @@ int32_t lram_create(const lram_config* cfg, int32_t device, lram_engine** out) {
     if (const char* v = std::getenv("LRAM_COMPAT_SHARE")) e->compat_share = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_MAMBA_DT_FUSE")) e->mamba_dt_fuse = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GN_FUSE")) e->gn_fuse = std::max(0, std::min(2, std::atoi(v)));
-    if (const char* v = std::getenv("LRAM_GN_AMAX")) e->gn_amax_handover = std::atoi(v) != 0;
+    if (const char* v = std::getenv("LRAM_GN_AMAX")) e->gn_amax_handover = std::atoi(v) != 0, e->gn_planes = std::atoi(v) >= 2;
     if (const char* v = std::getenv("LRAM_SLSTM_GATES_ONE")) e->slstm_gates_one = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_UPZ_8P")) e->upz_beside = std::atoi(v) != 0;
     if (const char* v = std::getenv("LRAM_GEMM_NARROW")) e->gemm_narrow_on = std::atoi(v) != 0, e->gemm_narrow_f16 = std::atoi(v) != 2;

@@ -802,6 +802,83 @@ __global__ __launch_bounds__(256) void slstm_token_kernel(SlstmTokenArgs a) {
   a.yout[row * H + c] = ynew;
 }
 
+// The same norm + skip + gate with the output written as proj_down's pre-split operand (GroupNormArgs::h2): one workgroup per row,
+// wave = head; the row's largest magnitude over all heads meets in LDS, then every wave scales and splits its own segment.  Same
+// values as group_norm_kernel's mode 0 (same order of operations); the planes hold exactly what gemm_f16x2.hip would make of the
+// fp32 row with that maximum, so the projection's result is bit-identical to the fp32 + partial-maxima hand-over.
+__global__ __launch_bounds__(512) void group_norm_planes_kernel(GroupNormArgs a) {
+  __shared__ float s_max[8];
+  const int row = blockIdx.x, h = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int DH = a.DH, D = a.NH * a.DH;
+  const int nv = DH >> 2;
+  const float* src = a.h + (int64_t)row * D + (int64_t)h * DH;
+  float4 v[kGnMaxV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = i < nv ? *reinterpret_cast<const float4*>(src + 4 * i) : f4_zero();
+    s += v[j].x + v[j].y + v[j].z + v[j].w;
+  }
+  const float mean = wave_sum(s) / (float)DH;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i < nv) {
+      const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+      q += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+  }
+  const float var = wave_sum(q) / (float)DH;
+  const float rstd = 1.f / sqrtf(var + a.eps);
+  float omax = 0.f;
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i >= nv) continue;
+    const int hd = h * DH + 4 * i;
+    const float4 g = *reinterpret_cast<const float4*>(a.gamma + hd);
+    float4 o;
+    o.x = (v[j].x - mean) * rstd * g.x;
+    o.y = (v[j].y - mean) * rstd * g.y;
+    o.z = (v[j].z - mean) * rstd * g.z;
+    o.w = (v[j].w - mean) * rstd * g.w;
+    if (a.beta != nullptr) {
+      const float4 bb = *reinterpret_cast<const float4*>(a.beta + hd);
+      o.x += bb.x;
+      o.y += bb.y;
+      o.z += bb.z;
+      o.w += bb.w;
+    }
+    const float4 sk = *reinterpret_cast<const float4*>(a.skip + hd);
+    const float4 xa = *reinterpret_cast<const float4*>(a.xa + (int64_t)row * D + hd);
+    const float4 z = *reinterpret_cast<const float4*>(a.u + (int64_t)row * 2 * D + D + hd);
+    o.x = (o.x + sk.x * xa.x) * silu_f(z.x);
+    o.y = (o.y + sk.y * xa.y) * silu_f(z.y);
+    o.z = (o.z + sk.z * xa.z) * silu_f(z.z);
+    o.w = (o.w + sk.w * xa.w) * silu_f(z.w);
+    v[j] = o;
+    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+  }
+  omax = wave_max(omax);
+  if (lane == 0) s_max[h] = omax;
+  __syncthreads();
+  float mx = s_max[0];
+  for (int k = 1; k < a.NH; ++k) mx = fmaxf(mx, s_max[k]);
+  const float sc = pow2_scale(mx);
+  _Float16* h2 = reinterpret_cast<_Float16*>(a.h2);
+#pragma unroll
+  for (int j = 0; j < kGnMaxV; ++j) {
+    const int i = lane + 64 * j;
+    if (i >= nv) continue;
+    const int k0 = h * DH + 4 * i;   // (DH a multiple of 4: the four elements stay inside one 32-deep K tile)
+    split2_store4(v[j], sc, h2 + (int64_t)(k0 >> 5) * a.h2_kt + (int64_t)row * 32 + (k0 & 31), a.h2_plane);
+  }
+  if (threadIdx.x == 0) a.h2_inv[row] = 1.f / sc;
+}
+
 __global__ __launch_bounds__(256) void gelu_gate_kernel(const float* p, float* out, int64_t rows, int F) {
   const int nv = F >> 2;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -931,6 +1008,13 @@ void launch_mlstm_cell(const MlstmCellArgs& a, hipStream_t stream) {
 
 void launch_group_norm(const GroupNormArgs& a, hipStream_t stream) {
   LRAM_REQUIRE(a.DH % 4 == 0 && a.DH <= 4 * 64 * kGnMaxV, "group norm: head dim must be a multiple of 4 and <= 1024");
+  if (a.h2 != nullptr) {
+    LRAM_REQUIRE(a.mode == 0 && a.NH >= 1 && a.NH <= 8 && a.h2_inv != nullptr && a.h2_kt >= 32 * (int64_t)a.rows && (a.NH * a.DH) % 32 == 0,
+                 "group norm: operand planes need mode 0, <= 8 heads, the inverse-scale output and the K-tile pitch");
+    hipLaunchKernelGGL(group_norm_planes_kernel, dim3(a.rows), dim3(64 * a.NH), 0, stream, a);
+    LRAM_HIP_CHECK(hipGetLastError());
+    return;
+  }
   hipLaunchKernelGGL(group_norm_kernel, dim3(a.rows, a.NH), dim3(64), 0, stream, a);
   LRAM_HIP_CHECK(hipGetLastError());
 }

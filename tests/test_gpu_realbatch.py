@@ -231,7 +231,9 @@ def test_group_norm_row_maxima_handover_is_bit_identical(hip_lib, monkeypatch, g
     """proj_down's operand row maxima come from the output group norm's waves as NH partial maxima per row (round 5) instead of a
     row-maximum launch of their own (LRAM_GN_AMAX=0): a maximum of partial maxima is exact, so the two forms must agree bit for
     bit -- 16M at 1024 slots (f16x2 projections, two 512-slot slices), with the group norm un-fused (LRAM_GN_FUSE=0: every block
-    takes the hand-over) and in the default form."""
+    takes the hand-over) and in the default form.  Round 6: the norm writes the projection's f16x2 operand planes itself (one
+    workgroup per row, the row maximum over all heads in LDS) and proj_down runs on the pre-split kernel: the planes are what the
+    on-the-fly kernel makes of the fp32 row, the products and their order are the same -- bit for bit again."""
     spec = preset("xlstm_16m")
     sd = init_state_dict(spec, seed=0)
     seq = _inputs(spec, 1024, 4, seed=77)
@@ -239,12 +241,16 @@ def test_group_norm_row_maxima_handover_is_bit_identical(hip_lib, monkeypatch, g
         monkeypatch.setenv("LRAM_GN_FUSE", gn_fuse)
     keys = [(0, 0), (6, 1)]
     monkeypatch.delenv("LRAM_GN_AMAX", raising=False)
-    a = _run(spec, sd, seq, want_state=keys)
-    monkeypatch.setenv("LRAM_GN_AMAX", "0")
-    b = _run(spec, sd, seq, want_state=keys)
-    assert torch.equal(a["acts"], b["acts"]) and torch.equal(a["hidden"], b["hidden"]) and torch.equal(a["logits"], b["logits"])
-    for k in keys:
-        assert torch.equal(a["state"][k], b["state"][k]), k
+    # micro 1: one env slice -> round 6's form: the norm writes proj_down's operand planes (pre-split kernel); the default two
+    # slices keep the hand-over
+    micro = 1 if gn_fuse == "0" else None
+    a = _run(spec, sd, seq, want_state=keys, micro=micro)
+    for form in ("1", "0"):                       # round 5: fp32 + partial maxima; before: fp32 + a row-maximum launch
+        monkeypatch.setenv("LRAM_GN_AMAX", form)
+        b = _run(spec, sd, seq, want_state=keys, micro=micro)
+        assert torch.equal(a["acts"], b["acts"]) and torch.equal(a["hidden"], b["hidden"]) and torch.equal(a["logits"], b["logits"]), form
+        for k in keys:
+            assert torch.equal(a["state"][k], b["state"][k]), (form, k)
 
 
 @pytest.mark.parametrize("name,B", [("xlstm_16m", 1024), ("xlstm_206m_cut", 600)])
