@@ -279,20 +279,53 @@ def prefill_leg(tag, cfg, B, L, n_decode, dev, what=""):
     sd = init_state_dict(spec, seed=0)
     eng = Engine(spec, sd, B, device=dev)
     try:
-        return _prefill_leg_run(eng, spec, tag, cfg, B, L, n_decode, dev, what)
+        leg = _prefill_leg_run(eng, spec, tag, cfg, B, L, n_decode, dev, what)
     finally:
         eng.close()
-        del eng, sd
+        del eng
         torch.cuda.empty_cache()
+    # the same state pass with the chip to itself: one chunk at a time (LRAM_PREFILL_CHUNK=3), one un-timed prefill under events
+    if leg.get("roofline"):
+        old = os.environ.get("LRAM_PREFILL_CHUNK")
+        os.environ["LRAM_PREFILL_CHUNK"] = "3"
+        try:
+            solo = Engine(spec, sd, B, device=dev)
+        finally:
+            if old is None:
+                del os.environ["LRAM_PREFILL_CHUNK"]
+            else:
+                os.environ["LRAM_PREFILL_CHUNK"] = old
+        try:
+            obs, rtg, rew, ones = _prefill_inputs(spec, B, L, dev)
+            solo.prefill(obs, rtg, rew, ones)
+            solo.profile_begin()
+            solo.prefill(obs, rtg, rew, ones)
+            torch.cuda.synchronize()
+            ms, n, _, _ = solo.profile_end_split()
+            if n > 0:
+                r = leg["roofline"]
+                ach = r["algorithmic_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
+                r["standalone"] = {"avg_launch_ms": ms / n, "achieved": ach, "frac": ach / HBM_PEAK_GBPS, "launches_timed": n,
+                                   "note": "one chunk at a time: the launch has the chip to itself"}
+        finally:
+            solo.close()
+            del solo
+            torch.cuda.empty_cache()
+    return leg
 
 
-def _prefill_leg_run(eng, spec, tag, cfg, B, L, n_decode, dev, what):
+def _prefill_inputs(spec, B, L, dev):
     g = torch.Generator(device=dev).manual_seed(77)
     obs = torch.zeros(B, L, spec.state_dim, device=dev)
     obs[:, :, :168] = torch.rand(B, L, 168, generator=g, device=dev) * 2 - 1          # Mimicgen: 168-dim full state space
     rtg = (6.0 - 0.01 * torch.arange(L, device=dev).float()).repeat(B, 1).contiguous()
     rew = torch.zeros(B, L, device=dev)
     ones = torch.ones(B, dtype=torch.uint8, device=dev)
+    return obs, rtg, rew, ones
+
+
+def _prefill_leg_run(eng, spec, tag, cfg, B, L, n_decode, dev, what):
+    obs, rtg, rew, ones = _prefill_inputs(spec, B, L, dev)
     eng.prefill(obs, rtg, rew, ones)                                                   # warm-up pass (allocations, first launches)
     torch.cuda.synchronize()
     eng.gemm_counts(reset=True)
@@ -310,8 +343,28 @@ def _prefill_leg_run(eng, spec, tag, cfg, B, L, n_decode, dev, what):
         eng.step(o1, r1, z1, None)
     torch.cuda.synchronize()
     wall_d = time.perf_counter() - t1
+    # the chunkwise state pass (mlstm_cell_chunk3_kernel: C of every (env, head) read once and written once per chunk) timed by
+    # live HIP events in a THIRD, un-timed prefill (the events sit on the chunk lanes' streams): its own roofline
+    roof = None
+    if spec.backbone == "xlstm":
+        eng.profile_begin()
+        eng.prefill(obs, rtg, rew, ones)
+        torch.cuda.synchronize()
+        ms, n, _, _ = eng.profile_end_split()
+        if n > 0:
+            n_rec = spec.n_blocks - len(spec.slstm_at)
+            chunks = n / n_rec                                     # state passes per block
+            tok = 3.0 * L / chunks                                 # tokens per pass (mean)
+            per_env = 2 * spec.n_heads * spec.head_dim ** 2 * 4 + tok * 4 * spec.inner * 4 + spec.n_heads * 64 * 64 * 4
+            ab, avg = per_env * B, ms / n
+            roof = {"bound": "hbm", "kernel": "mlstm_cell_chunk3_kernel (chunkwise state pass, bf16x3)", "achieved": ab / (avg * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ab / (avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                    "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg, "launches_timed": n, "state_passes_per_block": chunks,
+                    "note": "C read + written once per pass, q / k / v read and h written for its tokens, the 64 x 64 intra-chunk "
+                            "matrix; three chunks are in flight, so a launch shares the chip with the other lanes' kernels"}
     leg = {"id": tag, "workload": what or f"{cfg} prefill", "preset": cfg, "batch": B, "context_timesteps": L,
            "steps": 1, "warmup": 1, "value": B * L / wall, "unit": "env-timesteps/s", "ms_per_step": wall * 1e3,
+           "roofline": roof,
            "projections": projection_label(ran, "f16x2"), "mfma": mfma_block(ran, wall),
            "decode": {"steps": n_decode, "ms_per_step": wall_d / n_decode * 1e3, "value": B * n_decode / wall_d,
                       "unit": "env-steps/s", "state_mode": eng.state_mode}}

@@ -73,4 +73,9 @@ def test_bench_config_legs_contract(hip_lib, capsys):
     assert c5["unit"] == "env-timesteps/s" and c5["context_timesteps"] == 512 and c5["batch"] == 64
     assert abs(c5["value"] - 64 * 512 * 1e3 / c5["ms_per_step"]) < 1e-6 * c5["value"]
     assert c5["decode"]["steps"] == 16 and c5["decode"]["value"] > 0
+    # the chunkwise state pass's own roofline: 17 mLSTM blocks x 25 chunks of the 512-timestep context, timed by live events
+    r5 = c5["roofline"]
+    assert r5["bound"] == "hbm" and r5["peak"] == 8000.0 and 0.0 < r5["frac"] <= 1.0 and r5["launches_timed"] == 17 * 25
+    assert abs(r5["frac"] - r5["achieved"] / r5["peak"]) < 1e-12 and abs(r5["state_passes_per_block"] - 25) < 1e-9
+    assert r5["standalone"]["launches_timed"] == 17 * 25 and r5["frac"] <= r5["standalone"]["frac"] <= 1.0   # (one chunk at a time)
     capsys.readouterr()
