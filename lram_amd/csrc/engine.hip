@@ -196,7 +196,7 @@ struct lram_engine {
   bool chunk_lanes = true;
   static constexpr int kMaxLanes = 3;
   static constexpr int n_lanes = 3;  // chunks in flight (206M, 64 envs x 512 timesteps, same box: 1 lane 385 ms, 2 lanes 326, 3 lanes 305, 4 lanes 303)
-  DevBuf twin[kMaxLanes - 1][18];    // further copies of the per-token activation workspace (see workspace_set())
+  DevBuf twin[kMaxLanes - 1][21];    // further copies of the per-token activation workspace (see workspace_set())
   std::vector<hipEvent_t> lane_ev[kMaxLanes];             // "block i of the lane's current chunk is done"
   const std::vector<hipEvent_t>* lane_wait = nullptr;     // set by timesteps_launches around run_stack
   const std::vector<hipEvent_t>* lane_rec = nullptr;
@@ -616,11 +616,11 @@ void alloc_workspace(lram_engine* e, int tokens) {
   e->tok_cap = tokens;
 }
 
-// The per-token activation buffers a chunk of a stored context goes through (xLSTM): what a second chunk in flight needs its own copy of.
+// The per-token activation buffers a chunk of a stored context goes through (xLSTM and Mamba): what a second chunk in flight needs its own copy of.
 // (SK / ASCALE are per stream already; LOGITS / TOK belong to the last timestep, which always runs on the primary set.)
-std::array<DevBuf*, 18> workspace_set(lram_engine* e) {
+std::array<DevBuf*, 21> workspace_set(lram_engine* e) {
   return {&e->X, &e->XN, &e->XN2, &e->HID, &e->U, &e->Q, &e->K, &e->V, &e->XA, &e->H, &e->G, &e->SCAL, &e->RY, &e->GATES,
-          &e->AMAT, &e->VEC, &e->AMX_XN, &e->AMX_H};
+          &e->AMAT, &e->VEC, &e->AMX_XN, &e->AMX_H, &e->RES, &e->DTP, &e->AMX_XA};
 }
 void swap_workspace(lram_engine* e, int lane) {   // lane >= 1: primary <-> that lane's copy
   const auto ws = workspace_set(e);
@@ -1557,7 +1557,7 @@ void mamba_stage(lram_engine* e, int i, int stage, int T, const uint8_t* reset, 
     in.a = XN, in.lda = D, in.w = w.in_proj, in.ldw = D, in.c = U, in.ldc = 2 * di, in.bias = w.in_proj_b;
     in.m = rows, in.n = 2 * di, in.k = D, in.a_amax = amx_xn;
     if (ps_in) in.a = nullptr, in.a_amax = nullptr, in.a2 = xn2, in.a2_plane = (int64_t)e->XN2.n, in.a2_kt = xn2_kt, in.a2_inv = amx_xn;
-    in.beside_memory_bound = e->mamba_slices_now > 1 ? 1 : 0;   // (the other slice's conv / state update / norm run beside it)
+    in.beside_memory_bound = (e->mamba_slices_now > 1 || e->lane_rec != nullptr) ? 1 : 0;   // (the other slice's conv / state update / norm run beside it)
     gemm(e, in, gs);
   } else if (stage == 1) {
     GemmArgs xp;
@@ -1591,7 +1591,13 @@ void run_mamba_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   e->mamba_slices_now = ns;
   for (int k = 0; k < n_stages + ns - 1; ++k)   // slice j is enqueued j stages behind slice 0
     for (int j = 0; j < ns; ++j)
-      if (k - j >= 0 && k - j < n_stages) mamba_stage(e, (k - j) / 3, (k - j) % 3, T, reset, sl[j]);
+      if (k - j >= 0 && k - j < n_stages) {
+        const int layer = (k - j) / 3, stage = (k - j) % 3;
+        // chunk lanes of lram_prefill (one slice): layer i of this chunk after layer i of the chunk before it (conv + SSM state)
+        if (stage == 0 && e->lane_wait) LRAM_HIP_CHECK(hipStreamWaitEvent(sl[j].s, (*e->lane_wait)[layer], 0));
+        mamba_stage(e, layer, stage, T, reset, sl[j]);
+        if (stage == 2 && e->lane_rec) LRAM_HIP_CHECK(hipEventRecord((*e->lane_rec)[layer], sl[j].s));
+      }
   for (const Slice& x : sl) {
     const size_t r0 = (size_t)x.b0 * T;
     launch_add_rms_norm(e->X.p + r0 * D, e->RES.p + r0 * D, nullptr, e->HID.p + r0 * D, e->post_g, x.nb * T, D,
@@ -1703,8 +1709,9 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   // workspace and the caller's stream.  Where they apply they replace the automatic env slices of large batches as well: whole-batch
   // launches, three chunks in flight (16M, 1024 envs x 252 timesteps: 224.4 -> 215.5 ms; 206M, 512 envs x 63: 295.3 -> 274.0 ms).
   const int n_chunks = (L + kChunk - 1) / kChunk;
-  const bool lanes = e->n_micro <= 1 && n_chunks >= 2 && kChunk * T > kMaxTokens && e->chunk_lanes &&
-                     c.backbone == LRAM_BACKBONE_XLSTM && shared_passes <= 1 && twin_ready(e);
+  // (Mamba's stored contexts go through the token-sequential kernels in chunks of 4 timesteps: the lanes apply to them as they are)
+  const bool lanes = e->n_micro <= 1 && n_chunks >= 2 && e->chunk_lanes && !e->graph_mode && shared_passes <= 1 &&
+                     (c.backbone == LRAM_BACKBONE_MAMBA || kChunk * T > kMaxTokens) && twin_ready(e);
   hipStream_t hbm = s;
   const std::vector<Slice> sl = lanes ? std::vector<Slice>{Slice{0, e->B, s}} : make_slices(e, s, &hbm);
   const bool multi = sl.size() > 1;

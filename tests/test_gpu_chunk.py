@@ -188,6 +188,42 @@ def test_chunkwise_prefill_at_a_two_slice_batch_size(hip_lib, micro):
     e_pre.close()
 
 
+def test_mamba_prefill_chunk_lanes_equal_one_chunk_at_a_time_and_the_step_path(hip_lib, monkeypatch):
+    """Mamba's stored contexts go through the step kernels in chunks of 4 timesteps; with the chunk lanes three chunks are in flight
+    (layer i of chunk c + 1 waits for layer i of chunk c: conv + SSM state).  50 timesteps = 13 chunks at 48 envs: bit-identical to one
+    chunk at a time (LRAM_PREFILL_CHUNK=3), three prefills in a row; actions and states equal to 50 lram_step calls."""
+    from lram_amd.engine import Engine
+    spec = preset("mamba_48m")
+    sd = init_state_dict(spec, seed=45)
+    B, L = 48, 50
+    seq = make_inputs(spec, B, L, seed=10, reset_prob=0.0)
+    obs_seq = torch.stack([x[0] for x in seq], 1).contiguous().cuda()
+    rtg_seq = torch.stack([x[1] for x in seq], 1).contiguous().cuda()
+    rew_seq = torch.stack([x[2] for x in seq], 1).contiguous().cuda()
+    e_step = Engine(spec, sd, B, device="cuda:0")
+    e_lanes = Engine(spec, sd, B, device="cuda:0")
+    monkeypatch.setenv("LRAM_PREFILL_CHUNK", "3")
+    e_serial = Engine(spec, sd, B, device="cuda:0")
+    monkeypatch.delenv("LRAM_PREFILL_CHUNK")
+    ones = torch.ones(B, dtype=torch.uint8).cuda()
+    for rep in range(3):
+        mask = ones if rep == 0 else None
+        a_l, _ = e_lanes.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=mask)
+        a_s, _ = e_serial.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=mask)
+        for t, (obs, rtg, rew, _) in enumerate(seq):
+            a_step, _ = e_step.step(obs.cuda(), rtg.cuda(), rew.cuda(), mask if t == 0 else None)
+        torch.cuda.synchronize()
+        assert torch.equal(a_l, a_s), rep
+        assert float((a_l - a_step).abs().max()) <= 1e-4, rep
+        for blk in (0, spec.n_blocks // 2, spec.n_blocks - 1):
+            for which in (0, 3):   # SSM state, conv state
+                t_l = e_lanes.export_state_tensor(blk, which)
+                assert torch.equal(t_l, e_serial.export_state_tensor(blk, which)), (rep, blk, which)
+                assert rel_err(t_l, e_step.export_state_tensor(blk, which)) < 1e-4, (rep, blk, which)
+    for e in (e_step, e_lanes, e_serial):
+        e.close()
+
+
 @pytest.mark.parametrize("scheme", ["reference", "trained_like"])
 def test_chunkwise_prefill_on_the_weight_distributions_the_reference_runs(hip_lib, scheme):
     """lram_prefill (chunkwise kernels: 100 timesteps = 300 tokens in 63-token state passes) on the long-memory weight
