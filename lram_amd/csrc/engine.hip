@@ -1709,9 +1709,9 @@ void timesteps_launches(lram_engine* e, const float* obs, int emb, const float* 
   // workspace and the caller's stream.  Where they apply they replace the automatic env slices of large batches as well: whole-batch
   // launches, three chunks in flight (16M, 1024 envs x 252 timesteps: 224.4 -> 215.5 ms; 206M, 512 envs x 63: 295.3 -> 274.0 ms).
   const int n_chunks = (L + kChunk - 1) / kChunk;
-  // (Mamba's stored contexts go through the token-sequential kernels in chunks of 4 timesteps: the lanes apply to them as they are)
-  const bool lanes = e->n_micro <= 1 && n_chunks >= 2 && e->chunk_lanes && !e->graph_mode && shared_passes <= 1 &&
-                     (c.backbone == LRAM_BACKBONE_MAMBA || kChunk * T > kMaxTokens) && twin_ready(e);
+  // (Mamba's stored contexts and the xLSTM geometries without a chunkwise form go through the token-sequential kernels in chunks
+  // of 4 timesteps: the lanes apply to them as they are)
+  const bool lanes = e->n_micro <= 1 && n_chunks >= 2 && e->chunk_lanes && !e->graph_mode && shared_passes <= 1 && twin_ready(e);
   hipStream_t hbm = s;
   const std::vector<Slice> sl = lanes ? std::vector<Slice>{Slice{0, e->B, s}} : make_slices(e, s, &hbm);
   const bool multi = sl.size() > 1;

@@ -49,7 +49,7 @@ PREFILL_MODES=chunkwise bash scripts/gpu_prof_prefill.sh xlstm_206m 64 512 > $OU
 f=$(find $OUT/prof_prefill_xlstm_206m -name "*kernel_stats.csv" | head -1); cp $f profiles/${RND}_kernel_stats_prefill_xlstm206m_b64_l512.csv
 t=$(find $OUT/prof_prefill_xlstm_206m -name "*kernel_trace.csv" | head -1); python scripts/prefill_timeline.py $t > profiles/${RND}_prefill_timeline_xlstm206m_b64_l512.txt; rm -rf $OUT/prof_prefill_xlstm_206m
 { echo "# scripts/bench_prefill.py, same box, two rounds.  LRAM_PREFILL_CHUNK: 2 = chunk cell on the fp32-input matrix cores (rounds 1-5), three lanes;"
-  echo "# 3 = bf16x3 cell, one chunk at a time (no lanes); 1 = default (bf16x3 cell, three chunks in flight); 0 = token-sequential kernels"
+  echo "# 3 = bf16x3 cell, one chunk at a time (no lanes); 1 = default (bf16x3 cell, three chunks in flight); 0 = token-sequential kernels (4 timesteps per chunk, three chunks in flight as well)"
   for r in 1 2; do for v in 0 2 3 1; do
     LRAM_PREFILL_CHUNK=$v PREFILL_MODES=chunkwise python scripts/bench_prefill.py xlstm_206m 64 512 2>/dev/null | tail -1 | sed "s/^/LRAM_PREFILL_CHUNK=$v /"
     LRAM_PREFILL_CHUNK=$v PREFILL_MODES=chunkwise python scripts/bench_prefill.py xlstm_16m 64 512 2>/dev/null | tail -1 | sed "s/^/LRAM_PREFILL_CHUNK=$v /"
