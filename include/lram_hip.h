@@ -135,7 +135,11 @@ int32_t lram_step(lram_engine* e, const float* dev_obs, int32_t obs_is_embedding
  * chunk through the chunkwise matrix-core kernels (csrc/mlstm_chunk.hip: intra-chunk attention form + one rank-T
  * update of C); otherwise, or with LRAM_PREFILL_CHUNK=0 in the environment at lram_create, 4 timesteps (12 tokens)
  * per chunk through the token-sequential kernels.  The first long prefill grows the activation workspace to 64
- * tokens per env slot (device-synchronising, once).
+ * tokens per env slot (device-synchronising, once).  From two chunks on, three chunks are in flight on engine-owned
+ * streams (block i of chunk c + 1 waits for block i of chunk c only): the engine then holds two further copies of that
+ * workspace and, for raw observations, the [batch, timesteps, d_model] state embeddings of the context (allocated on the
+ * first such call; one chunk at a time if the device has less than 2 GiB to spare, or with LRAM_PREFILL_CHUNK=3).  Results
+ * are bit-identical to one chunk at a time and are on `stream` when the call returns.
  *   dev_obs_seq    device float[batch, timesteps, state_dim] (or [batch, timesteps, d_model] embeddings)
  *   dev_rtg_seq, dev_reward_seq   device float[batch, timesteps]
  *   dev_reset_mask applied before the first timestep;  dev_actions (nullable): action at the LAST timestep. */
