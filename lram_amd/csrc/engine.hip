@@ -989,6 +989,17 @@ struct Slice {
 // and invalidation for the host's and other devices' benefit -- ~150 times per env-step, between kernels of one device whose
 // launches already order their memory at device scope.  boundary = true (fork from / join into the caller's stream): default
 // events, the caller may hand the results to a copy engine or the host next.
+hipEvent_t ring_event(lram_engine* e) {   // an event of the engine's own ring (device scope), for a record / wait pair placed apart
+  constexpr size_t kRing = 512;
+  std::vector<hipEvent_t>& pool = e->sync_events;
+  if (pool.size() < kRing && e->sync_used >= pool.size()) {
+    hipEvent_t nev;
+    LRAM_HIP_CHECK(hipEventCreateWithFlags(&nev, hipEventDisableTiming | (e->event_device_scope ? hipEventDisableSystemFence : 0u)));
+    pool.push_back(nev);
+  }
+  return pool[e->sync_used++ % pool.size()];
+}
+
 void stream_after(lram_engine* e, hipStream_t dst, hipStream_t src, bool boundary = false) {
   if (dst == src) return;
   // ring of events: a wait captures the record that precedes it at call time, so re-recording an event later
@@ -1400,13 +1411,28 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   // (Measured and removed, profiles/EXPERIMENTS.md: folds on their own stream one block ahead of the cells, every fold queued
   // at the step start, folds fused with the readout of the envs they rewrite, gaps / staggered front ends.)
   const bool bubbles = lazy && sl.size() > 1;
+  // One slice (everything else on the caller's stream): ALL of the step's folds go to a side stream at the step's start -- they
+  // depend on nothing this step computes -- and the read pass of block i waits for fold i alone, instead of every fold sitting
+  // on the one stream ahead of its block (206M at 64 envs: 17 folds of ~21 us each = 8 % of the step).
+  // From 256 MiB of matrix memory per block (16M: 256 envs, 206M: 41); below, the extra stream's events cost more than the folds.
+  // Same box, folds on the one stream vs on the side stream, env-steps/s: 206M at 32 / 64 envs 10.56k vs 10.56k / 15.18k vs 15.67k;
+  // 16M at 128 / 256 / 448 envs 155.6k vs 149.5k / 224.2k vs 226.7k / 287.4k vs 297.2k.
+  const double dh_ = c.n_heads > 0 ? (double)c.inner / c.n_heads : 0.0;
+  const bool side_folds = lazy && sl.size() == 1 && (double)e->B * c.n_heads * dh_ * dh_ * 4.0 >= 256.0 * 1024 * 1024;
+  hipStream_t fold_stream = hbm;
+  std::vector<hipEvent_t> fold_done(side_folds ? c.n_blocks : 0, nullptr);
+  if (side_folds) {
+    if (!e->hbm_stream) LRAM_HIP_CHECK(hipStreamCreateWithFlags(&e->hbm_stream, hipStreamNonBlocking));
+    fold_stream = e->hbm_stream;
+    stream_after(e, fold_stream, sl[0].s);
+  }
   std::vector<char> folded(c.n_blocks, 0);
   auto launch_folds = [&](int i) {  // one launch per block over all env slots: folds do not care about the slices
     MlstmLazyArgs la = lazy_args(e, i, T, reset, 0, e->B);
     la.compact = e->lazy_compact ? 1 : 0;
-    prof_record(e, hbm, true, true);
-    launch_mlstm_lazy_fold(la, hbm);
-    prof_record(e, hbm, false, true);
+    prof_record(e, fold_stream, true, true);
+    launch_mlstm_lazy_fold(la, fold_stream);
+    prof_record(e, fold_stream, false, true);
     folded[i] = 1;
   };
   auto next_mlstm = [&](int i) {
@@ -1419,6 +1445,12 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
     const int ahead = e->step_images != nullptr ? e->fold_bubbles_images : lram_engine::fold_bubbles;
     for (int i = next_mlstm(-1); i >= 0 && k < ahead; i = next_mlstm(i), ++k) launch_folds(i);
   }
+  if (side_folds)
+    for (int i = next_mlstm(-1); i >= 0; i = next_mlstm(i)) {
+      launch_folds(i);
+      fold_done[i] = ring_event(e);
+      LRAM_HIP_CHECK(hipEventRecord(fold_done[i], fold_stream));
+    }
   for (int i = 0; i < c.n_blocks; ++i) {
     if (i > 0 && e->lane_rec) LRAM_HIP_CHECK(hipEventRecord((*e->lane_rec)[i - 1], sl[0].s));   // (chunk lanes: one slice, one stream)
     if (e->lane_wait) LRAM_HIP_CHECK(hipStreamWaitEvent(sl[0].s, (*e->lane_wait)[i], 0));
@@ -1465,6 +1497,7 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
           if (gn_fused(e, T)) la.gn_g = w.on_g, la.gn_b = w.on_b, la.gn_skip = w.skip, la.gn_eps = c.ln_eps;
         }
         stream_after(e, hbm, x.s);
+        if (side_folds) LRAM_HIP_CHECK(hipStreamWaitEvent(hbm, fold_done[i], 0));
         prof_record(e, hbm, true);
         launch_mlstm_lazy_cell(la, hbm);
         prof_record(e, hbm, false);
