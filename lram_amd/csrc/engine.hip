@@ -1418,7 +1418,9 @@ void run_xlstm_stack(lram_engine* e, int T, const uint8_t* reset, const std::vec
   // Same box, folds on the one stream vs on the side stream, env-steps/s: 206M at 32 / 64 envs 10.56k vs 10.56k / 15.18k vs 15.67k;
   // 16M at 128 / 256 / 448 envs 155.6k vs 149.5k / 224.2k vs 226.7k / 287.4k vs 297.2k.
   const double dh_ = c.n_heads > 0 ? (double)c.inner / c.n_heads : 0.0;
-  const bool side_folds = lazy && sl.size() == 1 && (double)e->B * c.n_heads * dh_ * dh_ * 4.0 >= 256.0 * 1024 * 1024;
+  // (Only where the ONE slice is the automatic choice: a forced single slice -- lram_set_micro_batches(1), bench.py's "chip to
+  // itself" measurement of the state pass -- keeps every kernel of the pass alone on the chip.)
+  const bool side_folds = lazy && sl.size() == 1 && e->n_micro == 0 && (double)e->B * c.n_heads * dh_ * dh_ * 4.0 >= 256.0 * 1024 * 1024;
   hipStream_t fold_stream = hbm;
   std::vector<hipEvent_t> fold_done(side_folds ? c.n_blocks : 0, nullptr);
   if (side_folds) {
