@@ -133,8 +133,10 @@ def test_chunk_lanes_and_the_bf16x3_cell_against_one_chunk_at_a_time_on_the_fp32
     e_fp32 = Engine(spec, sd, B, device="cuda:0")
     monkeypatch.delenv("LRAM_PREFILL_CHUNK")
     ones = torch.ones(B, dtype=torch.uint8).cuda()
+    some = (torch.arange(B) % 3 == 1).to(torch.uint8).cuda()
     for rep in range(3):
-        mask = ones if rep == 0 else None   # the later prefills continue from the state the first one left
+        # the later prefills continue from the state the first one left -- rep 1 with a third of the envs restarted
+        mask = ones if rep == 0 else (some if rep == 1 else None)
         a_l, _ = e_lanes.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=mask)
         a_s, _ = e_serial.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=mask)
         a_f, _ = e_fp32.prefill(obs_seq, rtg_seq, rew_seq, reset_mask=mask)
